@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by RUNNING the reference in the build container.
+
+Run from the repo root:  python tests/golden/make_golden.py
+Needs /root/reference (read-only); never runs on the GPU box.  Writes only numbers
+(.npz / .json) next to this file -- no reference source, bytecode or pickled modules.
+
+What is imported from the reference: pyfiles/model.py (networks), pyfiles/util.py
+(losses, class_encode), pyfiles/util_notebook.py (SRGAN_training).  Obstacles handled
+outside the reference: a stub ``prdc`` module, and optimisers with
+torch-1.4 arithmetic that write through ``p.data`` (modern torch.optim.Adam bumps the
+version counters and SRGAN_training.train raises at util_notebook.py:689).
+"""
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import params as oparams  # noqa: E402  (build-owned deterministic fill)
+
+_stub = types.ModuleType("prdc")
+_stub.compute_prdc = lambda *a, **k: None
+sys.modules["prdc"] = _stub
+import matplotlib  # noqa: E402
+matplotlib.use("Agg")
+sys.path.insert(0, "/root/reference/pyfiles")
+import model as ref_model            # noqa: E402
+import util as ref_util              # noqa: E402
+import util_notebook as ref_nb       # noqa: E402
+
+
+class LegacyAdam(torch.optim.Optimizer):
+    """torch==1.4.0 Adam arithmetic, parameters updated through .data (no version bump)."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.5, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    def step(self, closure=None):
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p.data)
+                    st["exp_avg_sq"] = torch.zeros_like(p.data)
+                st["step"] += 1
+                g = p.grad.data
+                st["exp_avg"].mul_(b1).add_(g, alpha=1 - b1)
+                st["exp_avg_sq"].mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = st["exp_avg_sq"].sqrt() / math.sqrt(1 - b2 ** st["step"]) + group["eps"]
+                p.data.addcdiv_(st["exp_avg"], denom, value=-group["lr"] / (1 - b1 ** st["step"]))
+
+
+def shapes_of(net):
+    return [[k, list(v.shape)] for k, v in net.state_dict().items()]
+
+
+def load_fill(net, seed):
+    sd = net.state_dict()
+    filled = {k: torch.from_numpy(oparams.fill_array(k, tuple(v.shape), seed)) for k, v in sd.items()}
+    net.load_state_dict(filled)
+    return net
+
+
+def pool8(t):
+    return torch.nn.functional.avg_pool2d(t, 8).detach().numpy()
+
+
+def build_nets(tier, seed=0):
+    if tier == "T":      # tiny widths, real 128x128 geometry
+        G = ref_model.SingleGenerator(3, 4, 2, 2, 1, "instance", num_con=12)
+        D = ref_model.SingleDiscriminator_solo_multi(3, 4, 2, 4, "instance", 4)
+        E = ref_model.Encoder(3, 8, 4, 4, "instance", 4, "cpu")
+    else:                # notebook configuration (05-train cell 13/20)
+        G = ref_model.SingleGenerator(3, 64, 2, 2, 6, "instance", num_con=12)
+        D = ref_model.SingleDiscriminator_solo_multi(3, 64, 2, 4, "instance", 4)
+        E = ref_model.Encoder(3, 8, 64, 4, "instance", 4, "cpu")
+    return load_fill(G, seed), load_fill(D, seed + 1), load_fill(E, seed + 2)
+
+
+def synthetic_batch(batch, size, n_class, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
+    src = torch.randint(0, n_class, (batch,), generator=g)
+    tgt = (src + torch.randint(1, n_class, (batch,), generator=g)) % n_class
+    return x, {"source": src, "target": tgt}
+
+
+LBD = {"class": 1.0, "cycle": 5.0, "idt": 5.0, "reg": 0.5, "idt_reg": 0.5, "KL": 0.0,
+       "batch_KL": 10.0, "corr_enc": 100.0, "hist": 100.0}
+
+
+def golden_shapes():
+    out = {}
+    for tier in ("T", "F"):
+        G, D, E = build_nets(tier)
+        out[tier] = {"G": shapes_of(G), "D": shapes_of(D), "E": shapes_of(E)}
+    out["D_original_64"] = shapes_of(ref_model.SingleDiscriminator_original_multi(3, 64, 2, 4, "instance"))
+    out["E_original_64"] = shapes_of(ref_model.Encoder_original(3, 8, 64, 4, "instance", 2, "cpu"))
+    out["G_cfg1"] = shapes_of(ref_model.SingleGenerator(3, 64, 2, 2, 6, "instance", num_con=10))
+    with open(os.path.join(HERE, "shapes.json"), "w") as f:
+        json.dump(out, f)
+
+
+def golden_modules():
+    """Tier-T module forward outputs + all parameter gradients of a fixed scalar."""
+    G, D, E = build_nets("T")
+    x, label = synthetic_batch(3, 128, 4, seed=11)
+    gen = torch.Generator().manual_seed(5)
+    z = torch.randn(3, 8, generator=gen)
+    c = torch.cat([ref_util.class_encode(label["target"], "cpu", np.eye(4)), z], 1)
+    out = {}
+    # G
+    y = G(x, c)
+    wy = torch.linspace(-1, 1, y.numel()).view_as(y)
+    (y * wy).sum().backward()
+    out["G_y_pool8"] = pool8(y)
+    out["G_y_sum"] = np.float64(y.double().sum())
+    out["G_y_abs"] = np.float64(y.double().abs().sum())
+    for k, p in G.named_parameters():
+        out["G_grad." + k] = p.grad.numpy().copy()
+    # D
+    xd = x.clone().requires_grad_(True)
+    (o1, o2), (c1, c2) = D(xd)
+    s = (o1 ** 2).sum() + (o2 * 0.5).sum() + (c1 * torch.arange(4.0)).sum() + (c2 ** 2).sum()
+    s.backward()
+    out.update(D_o1=o1.detach().numpy(), D_o2=o2.detach().numpy(), D_c1=c1.detach().numpy(), D_c2=c2.detach().numpy())
+    out["D_dx_pool8"] = pool8(xd.grad)
+    for k, p in D.named_parameters():
+        out["D_grad." + k] = p.grad.numpy().copy()
+    # E
+    xe = x.clone().requires_grad_(True)
+    torch.manual_seed(3)
+    code, mu, logvar, cls, _ = E(xe)
+    s = (mu * torch.linspace(0.5, 1.5, mu.numel()).view_as(mu)).sum() + (logvar ** 2).sum() + cls.sum() + code.sum()
+    s.backward()
+    torch.manual_seed(3)
+    eps = torch.FloatTensor(mu.size()).normal_()
+    out.update(E_code=code.detach().numpy(), E_mu=mu.detach().numpy(), E_logvar=logvar.detach().numpy(),
+               E_cls=cls.detach().numpy(), E_eps=eps.numpy())
+    out["E_dx_pool8"] = pool8(xe.grad)
+    for k, p in E.named_parameters():
+        out["E_grad." + k] = p.grad.numpy().copy()
+    out["x_seed"], out["z"] = np.int64(11), z.numpy()
+    np.savez_compressed(os.path.join(HERE, "modules_T.npz"), **out)
+
+
+def golden_losses():
+    out = {}
+    torch.manual_seed(0)
+    hi = ref_util.histogram_imitation("cpu")
+    out["hist_target_seed0"] = hi.target.detach().numpy()
+    torch.manual_seed(1234)
+    mu = torch.randn(32, 8)
+    mu2 = (1.5 * torch.sin(0.37 * torch.arange(256.0))).reshape(32, 8)
+    for name, m in (("randn1234", mu), ("sin", mu2)):
+        m = m.clone().requires_grad_(True)
+        n_batch = 32
+        var = torch.var(m, dim=0) * n_batch / (n_batch - 1)
+        mean = torch.mean(m, dim=0)
+        bkl = -0.5 * torch.sum(1 + torch.log(var) - mean ** 2 - var)
+        corr = ref_util.corrcoef_loss(m.T, "cpu")
+        hist = hi.loss(m)
+        gb, = torch.autograd.grad(bkl, m, retain_graph=True)
+        gc, = torch.autograd.grad(corr, m, retain_graph=True)
+        gh, = torch.autograd.grad(hist, m)
+        out[f"{name}_mu"] = m.detach().numpy()
+        out[f"{name}_vals"] = np.array([float(bkl), float(corr), float(hist)], dtype=np.float64)
+        out[f"{name}_dbkl"], out[f"{name}_dcorr"], out[f"{name}_dhist"] = gb.numpy(), gc.numpy(), gh.numpy()
+    # LSGAN / class-MSE known answers
+    g = torch.Generator().manual_seed(7)
+    o1, o2 = torch.randn(4, 1, 7, 7, generator=g), torch.randn(4, 1, 3, 3, generator=g)
+    q1 = torch.softmax(torch.randn(4, 4, generator=g), 1)
+    q2 = torch.softmax(torch.randn(4, 4, generator=g), 1)
+    lab = torch.tensor([0, 3, 1, 2])
+    mse = nn.MSELoss()
+    out["ls_o1"], out["ls_o2"], out["ls_q1"], out["ls_q2"], out["ls_lab"] = o1.numpy(), o2.numpy(), q1.numpy(), q2.numpy(), lab.numpy()
+    out["ls_vals"] = np.array([float(ref_util.get_loss_D([o1, o2], 1., mse, "cpu")),
+                               float(ref_util.get_loss_D([o1, o2], 0., mse, "cpu")),
+                               float(ref_util.get_domainloss_D([q1, q2], ref_util.class_encode(lab, "cpu", np.eye(4)), mse))])
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+
+
+def run_train(tier, batch, k, steps, seed, pretrained_e=False):
+    """Drive the reference SRGAN_training.train and record what it returns + final params."""
+    G, D, E = build_nets(tier)
+    optE = None
+    if pretrained_e:   # 05-train cell 22: only fcmean/fcvar are in optE (lr 1e-3), then melted
+        keys = [k_ for k_ in E.state_dict().keys() if not k_.startswith(("fcmean", "fcvar"))]
+        E.freeze_melt(keys, "freeze")
+        optE = LegacyAdam(filter(lambda p: p.requires_grad, E.parameters()), lr=1e-3, betas=(0.5, 0.999))
+        E.freeze_melt(keys, "melt")
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    sg = ref_nb.SRGAN_training([G, D, E], [LegacyAdam(G.parameters()), LegacyAdam(D.parameters()),
+                                           optE if optE is not None else LegacyAdam(E.parameters())],
+                               [nn.MSELoss(), nn.MSELoss()], dict(LBD), k, "cpu", np.eye(4), batch, "mu", 8)
+    sg.opt_sche_initialization()
+    size = 128
+    losses = []
+    for s in range(steps):
+        x, label = synthetic_batch(batch, size, 4, seed=100 + s)
+        errG, errD, errE = sg.train(x, label)
+        losses.append([float(errG), float(errD), float(errE)])
+    out = {"losses": np.array(losses, dtype=np.float64), "hist_target": sg.hi.target.detach().numpy()}
+    for name, net in (("G", sg.G), ("D", sg.D), ("E", sg.E)):
+        for k_, v in net.state_dict().items():
+            v = v.detach().double()
+            if tier == "T":
+                out[f"{name}.{k_}"] = v.float().numpy()
+            else:
+                out[f"{name}_ck.{k_}"] = np.array([float(v.sum()), float(v.norm())] + v.flatten()[:8].tolist())
+    return out
+
+
+def golden_train():
+    np.savez_compressed(os.path.join(HERE, "train_T_b4_k2.npz"), **run_train("T", 4, 2, 3, seed=0))
+    np.savez_compressed(os.path.join(HERE, "train_T_b4_k5.npz"), **run_train("T", 4, 5, 2, seed=0))
+    np.savez_compressed(os.path.join(HERE, "train_T_b4_k2_pretrainedE.npz"), **run_train("T", 4, 2, 2, seed=0, pretrained_e=True))
+    np.savez_compressed(os.path.join(HERE, "train_F_b2_k1.npz"), **run_train("F", 2, 1, 2, seed=0))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    golden_shapes()
+    golden_modules()
+    golden_losses()
+    golden_train()
+    print("golden fixtures written to", HERE)
