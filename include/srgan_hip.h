@@ -1,0 +1,148 @@
+/*
+ * srgan_hip.h -- C ABI of libsrgan_hip.so: the MI355X (gfx950) kernels behind the
+ * Style-Restricted GAN G+D+E train step.
+ *
+ * The reference (shinshoji01/Style-Restricted_GAN) has no FFI layer: its "operator API" is
+ * the set of torch.nn / torch.nn.functional calls made by pyfiles/model.py, pyfiles/util.py
+ * and pyfiles/util_notebook.py.  Each entry point below names the reference call site(s) it
+ * replaces.  The Python host (style-restricted_gan_amd/srgan_amd) binds these with ctypes and
+ * mirrors the reference's nn.Module / loss / trainer signatures on top of them.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to dense fp32 data unless stated otherwise;
+ *   - activations are NHWC ([N][H][W][C], C fastest); 2-D tensors are row-major;
+ *   - conv weights are read through explicit element strides (sO,sI,sH,sW) of the logical
+ *     [O][I][kh][kw] tensor, so PyTorch's OIHW parameters are consumed in place;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing syncs;
+ *   - `ws` / `ws_bytes`: caller-owned scratch, size from the matching *_workspace() query;
+ *   - return value: 0 on success, <0 invalid argument, >0 a hipError_t.  The text of the last
+ *     error of the calling thread is available from srgan_last_error().
+ */
+#ifndef SRGAN_HIP_H
+#define SRGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRGAN_ABI_VERSION 1
+
+enum { SRGAN_ACT_NONE = 0, SRGAN_ACT_RELU = 1, SRGAN_ACT_LRELU = 2 };
+enum { SRGAN_PAD_ZERO = 0, SRGAN_PAD_REFLECT = 1 };
+
+int srgan_abi_version(void);
+const char* srgan_last_error(void);
+
+/* Geometry of one convolution y[N,Ho,Wo,O] = conv(x[N,Hi,Wi,I], w[O,I,kh,kw]) (+bias). */
+typedef struct srgan_conv_desc {
+  int N, Hi, Wi, I;      /* input  */
+  int Ho, Wo, O;         /* output */
+  int kh, kw, stride, pad;
+  int pad_mode;          /* SRGAN_PAD_* (reflect: pyfiles/model.py:358,364,419,425) */
+  long long sO, sI, sH, sW; /* element strides of the logical [O][I][kh][kw] weight */
+} srgan_conv_desc;
+
+/* nn.Conv2d forward (pyfiles/model.py:191,193,212,215,232,262,269,302,309,328-331,358,364,
+ * 369,385,445) with optional bias and fused activation epilogue (nn.LeakyReLU model.py:263).
+ * Also the input-gradient of nn.ConvTranspose2d (model.py:227,230) when called with the
+ * transposed-conv weight viewed as [O=Cin_t][I=Cout_t]. */
+size_t srgan_conv2d_workspace(const srgan_conv_desc* d);
+int srgan_conv2d_fwd(const srgan_conv_desc* d, const float* x, const float* w, const float* bias,
+                     float* y, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+
+/* Gradient w.r.t. the conv input (autograd of the call sites above): dx[N,Hi,Wi,I].
+ * Also the FORWARD of nn.ConvTranspose2d (model.py:227,230).  Weights are read at call time. */
+int srgan_conv2d_dgrad(const srgan_conv_desc* d, const float* dy, const float* w, float* dx,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* Gradient w.r.t. the conv weight, written through (sO,sI,sH,sW) (overwrites, no accumulate);
+ * dbias[O] (may be NULL) = column sums of dy. */
+int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, const float* dy, float* dw,
+                       float* dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* Instance norm + per-(n,c) affine + activation (+ residual):
+ *   xh = (x - mean_nc) * rstd_nc ; y = act(xh * scale[n,c] + shift[n,c]) (+ res)
+ * F.instance_norm(eps=1e-5, biased var) at model.py:58-60 (CBIN), nn.InstanceNorm2d at
+ * model.py:178 (scale/shift NULL), nn.ReLU model.py:199,240,246, LeakyReLU(0.2) model.py:418,
+ * residual add model.py:201.  mean/rstd [N*C] are written for the backward. */
+size_t srgan_instnorm_workspace(int N, int HW, int C);
+int srgan_instnorm_fwd(const float* x, const float* scale, const float* shift, const float* res,
+                       float* y, float* mean, float* rstd, int N, int HW, int C, float eps,
+                       int act, float slope, void* ws, size_t ws_bytes, void* stream);
+/* Backward: dx, and (when scale!=NULL or wanted) dscale[n,c]=sum dy_act*xh, dshift[n,c]=sum dy_act.
+ * dres is dy itself (caller aliases it).  y_act_src: the forward's x (pre-norm) is re-normalised
+ * to rebuild the activation mask. */
+int srgan_instnorm_bwd(const float* x, const float* dy, const float* scale, const float* shift,
+                       const float* mean, const float* rstd, float* dx, float* dscale,
+                       float* dshift, int N, int HW, int C, int act, float slope,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* Central-biasing affine of _CBINorm.forward (model.py:54-67): t = tanh(c W^T + b);
+ * scale[n,ch] = gamma[ch]; shift[n,ch] = t*gamma + beta.  c:[N,num_con] W:[C,num_con]. */
+int srgan_cbin_affine_fwd(const float* c, const float* W, const float* b, const float* gamma,
+                          const float* beta, float* t, float* scale, float* shift,
+                          int N, int C, int num_con, void* stream);
+/* Backward of the above from dscale/dshift[N,C]: dgamma, dbeta, dW, db (overwritten), dc [N,num_con]. */
+int srgan_cbin_affine_bwd(const float* c, const float* W, const float* gamma, const float* t,
+                          const float* dscale, const float* dshift, float* dgamma, float* dbeta,
+                          float* dW, float* db, float* dc, int N, int C, int num_con,
+                          void* ws, size_t ws_bytes /* >= N*C floats */, void* stream);
+
+/* Pointwise: y = act(x) and dx = dy * act'(y) (mask from the OUTPUT sign, slope>0). tanh: model.py:248 */
+int srgan_act_fwd(const float* x, float* y, long long n, int act, float slope, void* stream);
+int srgan_act_bwd(const float* y, const float* dy, float* dx, long long n, int act, float slope, void* stream);
+int srgan_tanh_fwd(const float* x, float* y, long long n, void* stream);
+int srgan_tanh_bwd(const float* y, const float* dy, float* dx, long long n, void* stream);
+/* y = a + b (E block: cmp(...) + shortcut(x), model.py:436) */
+int srgan_add(const float* a, const float* b, float* y, long long n, void* stream);
+
+/* nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False)  model.py:286,324 */
+int srgan_avgpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int srgan_avgpool3s2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* nn.AvgPool2d(2,2) (floor)  model.py:365,368,426,429 */
+int srgan_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int srgan_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* LeakyReLU(slope) -> AdaptiveAvgPool2d(1)  (Encoder.last_layer, model.py:454,475-480) */
+int srgan_lrelu_gap_fwd(const float* x, float* y, int N, int HW, int C, float slope, void* stream);
+int srgan_lrelu_gap_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C, float slope, void* stream);
+
+/* nn.Linear: y[M,N] = x[M,K] W[N,K]^T + b  (model.py:455-457; small M) */
+int srgan_linear_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, void* stream);
+int srgan_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db,
+                     int M, int N, int K, void* stream);
+
+/* NCHW <-> NHWC repack at the module boundary. */
+int srgan_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);
+int srgan_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);
+
+/* ---- fused loss reductions (value + gradient in one launch) -------------------------------
+ * Each writes loss[0] (overwrite) and the gradient of `weight * loss` w.r.t. its input. */
+/* get_loss_D, util.py:457-462 with nn.MSELoss: one scale; loss = mean((o-target)^2)*weight */
+int srgan_mse_const(const float* o, long long n, float target, float weight, float* loss, float* d_o, void* stream);
+/* nn.Softmax(dim=1) + get_domainloss_D (util.py:464-468, model.py:333-346): z:[B,n_class] logits,
+ * label:[B] int64; q=softmax(z) is written to `q`; loss = mean((q-onehot)^2)*weight; dz via softmax Jacobian. */
+int srgan_softmax_mse(const float* z, const long long* label, int B, int n_class, float weight,
+                      float* q, float* loss, float* dz, void* stream);
+/* torch.mean(torch.abs(a-b)) util_notebook.py:625,639,676,686 ; da = weight*sign(a-b)/n, db = -da */
+size_t srgan_l1_workspace(long long n);
+int srgan_l1_mean(const float* a, const float* b, long long n, float weight, float* loss,
+                  float* da, float* db, void* ws, size_t ws_bytes, void* stream);
+/* batch-KL + correlation + histogram-imitation on mu[B,d] (util_notebook.py:644-662, util.py:470-553).
+ * vals[4] = (bKL, corr, hist, w_bkl*bKL + w_corr*corr + w_hist*hist); dmu = gradient of vals[3].
+ * hist_target: [bins] device floats.  d <= 16, bins <= 64, B <= 4096. */
+int srgan_latent_losses(const float* mu, int B, int d, float n_batch, const float* hist_target, int bins,
+                        float range_max, float sigma, float w_bkl, float w_corr, float w_hist,
+                        float* vals, float* dmu, void* stream);
+
+/* optim.Adam.step, torch 1.4 arithmetic (util_notebook.py:500-506) on flat buffers.
+ * step_count is the 1-based step number t.  Writes through raw pointers (no autograd version bump). */
+int srgan_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                    float beta2, float eps, int step_count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRGAN_HIP_H */

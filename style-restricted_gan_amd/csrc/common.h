@@ -1,0 +1,73 @@
+// Shared helpers for the gfx950 kernels of libsrgan_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "srgan_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace srgan {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+#define SRGAN_REQUIRE(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      srgan::set_error(__VA_ARGS__);        \
+      return -1;                            \
+    }                                       \
+  } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
+inline long long round_up(long long a, long long b) { return ceil_div(a, b) * b; }
+
+// 64-lane wavefront reductions (gfx950 wave = 64).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64). `red` must hold 16 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  if (act == SRGAN_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == SRGAN_ACT_LRELU) return v > 0.f ? v : v * slope;
+  return v;
+}
+// derivative from the (pre- or post-activation) sign; slope > 0 keeps signs equal
+__device__ __forceinline__ float act_grad(float v, int act, float slope) {
+  if (act == SRGAN_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+  if (act == SRGAN_ACT_LRELU) return v > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+}  // namespace srgan

@@ -1,0 +1,725 @@
+// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+//   out[m][n] = sum_k A[m][k] * B[n][k]
+//     m = (image, grid-y, grid-x)       rows of the destination (NHWC pixels)
+//     n = destination channel
+//     k = (tap-y, tap-x, source channel)  gathered on the fly from the NHWC source tensor
+//
+// One kernel serves three reference ops (see include/srgan_hip.h):
+//   mode 0  nn.Conv2d forward           src = x,  dst = y    in_y = a*stride + ty - pad
+//   mode 1  conv input-gradient and     src = dy, dst = dx   in_y = a + floor((py+pad)/s) - ty
+//           nn.ConvTranspose2d forward  (one launch z-slice per output parity phase (py,px);
+//                                        taps ky = (py+pad)%s + s*ty, zero-weighted if ky>=kh)
+// The weight operand is first repacked to [phase][Npad][Kpad] (K contiguous, zero padded) by
+// pack_weights_kernel so the main loop needs no masks on B.
+//
+// Tiling: 256 threads = 4 waves, block tile BM x BN x 32, each wave owns TM x TN MFMA tiles of
+// 32x32.  A and B tiles are staged global -> registers -> LDS (rows padded by one 16-B access
+// so the ds_read_b128 fragment reads are conflict-free); the next tile's global loads are in
+// flight while the current tile is multiplied.  Within a 32-deep K tile lane (r, h) feeds the
+// MFMA k-slots {8q+4h+e} so that A and B fragments come from single ds_read_b128's.
+#include <algorithm>
+#include "common.h"
+
+namespace srgan {
+
+struct IgemmParams {
+  const float* src;
+  const float* wp;    // packed weights [phases][Npad][Kpad]
+  const float* bias;  // [Cd] or null
+  float* dst;
+  int NB, Hs, Ws, Cs;  // source tensor
+  int Hg, Wg;          // destination grid per phase
+  int Hd, Wd, Cd;      // destination tensor
+  int mode, stride, pad;
+  int Ty, Tx;          // taps per phase
+  int K, Kpad, Npad;
+  int reflect;
+  int act;
+  float slope;
+  int M;               // NB*Hg*Wg
+  int m_tiles, n_tiles;
+};
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;
+
+template <int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  static_assert(WM * WN == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+  __shared__ int row_n[BM], row_y[BM], row_x[BM], row_o[BM];
+
+  const int tid = threadIdx.x;
+  const int mt = blockIdx.x % p.m_tiles, nt = blockIdx.x / p.m_tiles;
+  const int phase = blockIdx.y;
+  const int s = p.stride;
+  int py = 0, px = 0;
+  if (p.mode == 1) { py = phase / s; px = phase % s; }
+  const int sgn = p.mode == 0 ? 1 : -1;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  for (int r = tid; r < BM; r += 256) {
+    int m = m0 + r;
+    int n = 0, y0 = -(1 << 28), x0 = -(1 << 28), o = -1;
+    if (m < p.M) {
+      n = m / (p.Hg * p.Wg);
+      int rem = m - n * (p.Hg * p.Wg);
+      int a = rem / p.Wg, b = rem - a * p.Wg;
+      if (p.mode == 0) {
+        y0 = a * s - p.pad; x0 = b * s - p.pad;
+        o = (n * p.Hd + a) * p.Wd + b;
+      } else {
+        int oy = a * s + py, ox = b * s + px;
+        if (oy < p.Hd && ox < p.Wd) {
+          y0 = a + (py + p.pad) / s; x0 = b + (px + p.pad) / s;
+          o = (n * p.Hd + oy) * p.Wd + ox;
+        }
+      }
+    }
+    row_n[r] = n; row_y[r] = y0; row_x[r] = x0; row_o[r] = o;
+  }
+  __syncthreads();
+
+  const float* wp = p.wp + (size_t)phase * p.Npad * p.Kpad + (size_t)n0 * p.Kpad;
+  const int nk = p.Kpad / BK;
+
+  // staging registers
+  constexpr int A_VEC_IT = BM / 32;      // float4 per thread (VEC)
+  constexpr int A_SC_IT = BM / 8;        // scalars per thread (generic)
+  constexpr int B_IT = BN / 32;
+  f32x4 a_reg[VEC ? A_VEC_IT : 1];
+  float a_sc[VEC ? 1 : A_SC_IT];
+  f32x4 b_reg[B_IT];
+
+  auto src_index = [&](int r, int ty, int tx, bool& ok) -> size_t {
+    int y = row_y[r] + sgn * ty, x = row_x[r] + sgn * tx;
+    if (p.reflect) {
+      if (y < 0) y = -y;
+      if (y >= p.Hs) y = 2 * p.Hs - 2 - y;
+      if (x < 0) x = -x;
+      if (x >= p.Ws) x = 2 * p.Ws - 2 - x;
+    }
+    ok = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+    return ((size_t)(row_n[r] * p.Hs + y) * p.Ws + x) * p.Cs;
+  };
+
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+    if constexpr (VEC) {
+      const int t = k0 / p.Cs, c0 = k0 - t * p.Cs;
+      const int ty = t / p.Tx, tx = t - ty * p.Tx;
+      const int seg = tid & 7;
+#pragma unroll
+      for (int i = 0; i < A_VEC_IT; ++i) {
+        const int r = (tid >> 3) + 32 * i;
+        bool ok;
+        size_t off = src_index(r, ty, tx, ok);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.src + off + c0 + seg * 4);
+        a_reg[i] = v;
+      }
+    } else {
+      const int kk = tid & 31;
+      const int k = k0 + kk;
+      const bool kok = k < p.K;
+      const int t = kok ? k / p.Cs : 0;
+      const int c = k - t * p.Cs;
+      const int ty = t / p.Tx, tx = t - ty * p.Tx;
+#pragma unroll
+      for (int i = 0; i < A_SC_IT; ++i) {
+        const int r = (tid >> 5) + 8 * i;
+        bool ok;
+        size_t off = src_index(r, ty, tx, ok);
+        a_sc[i] = (ok && kok) ? p.src[off + c] : 0.f;
+      }
+    }
+    const int seg = tid & 7;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int r = (tid >> 3) + 32 * i;
+      b_reg[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)r * p.Kpad + k0 + seg * 4);
+    }
+  };
+
+  auto store_tiles = [&]() {
+    if constexpr (VEC) {
+      const int seg = tid & 7;
+#pragma unroll
+      for (int i = 0; i < A_VEC_IT; ++i) {
+        const int r = (tid >> 3) + 32 * i;
+        *reinterpret_cast<f32x4*>(&As[r * LDK + seg * 4]) = a_reg[i];
+      }
+    } else {
+      const int kk = tid & 31;
+#pragma unroll
+      for (int i = 0; i < A_SC_IT; ++i) {
+        const int r = (tid >> 5) + 8 * i;
+        As[r * LDK + kk] = a_sc[i];
+      }
+    }
+    const int seg = tid & 7;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int r = (tid >> 3) + 32 * i;
+      *reinterpret_cast<f32x4*>(&Bs[r * LDK + seg * 4]) = b_reg[i];
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tiles(0);
+  store_tiles();
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const f32x4*>(&As[(wm * TM * 32 + i * 32 + lr) * LDK + q * 8 + lh * 4]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn * TN * 32 + j * 32 + lr) * LDK + q * 8 + lh * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * TN * 32 + j * 32 + lr;
+    const bool nok = n < p.Cd;
+    const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int o = row_o[r];
+        if (nok && o >= 0) {
+          float v = acc[i][j][e] + bv;
+          v = apply_act(v, p.act, p.slope);
+          p.dst[(size_t)o * p.Cd + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- weight repack ------------------------------------------------------------------------
+// dst[phase][n][ (ty*Tx+tx)*Cs + c ], zero padded to [Npad][Kpad].
+//   mode 0: n = O index, c = I index, (ky,kx) = (ty,tx)
+//   mode 1: n = I index, c = O index, ky = (py+pad)%s + s*ty (zero if >= kh)
+struct PackParams {
+  const float* w;
+  float* dst;
+  long long sO, sI, sH, sW;
+  int O, I, kh, kw, mode, stride, pad, Ty, Tx, Cs, N, K, Kpad, Npad, phases;
+};
+
+__global__ void pack_weights_kernel(PackParams p) {
+  const long long total = (long long)p.phases * p.Npad * p.Kpad;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % p.Kpad);
+    const long long rest = idx / p.Kpad;
+    const int n = (int)(rest % p.Npad);
+    const int phase = (int)(rest / p.Npad);
+    float v = 0.f;
+    if (n < p.N && k < p.K) {
+      const int t = k / p.Cs, c = k - t * p.Cs;
+      const int ty = t / p.Tx, tx = t - ty * p.Tx;
+      if (p.mode == 0) {
+        v = p.w[n * p.sO + c * p.sI + ty * p.sH + tx * p.sW];
+      } else {
+        const int py = phase / p.stride, px = phase % p.stride;
+        const int ky = (py + p.pad) % p.stride + p.stride * ty;
+        const int kx = (px + p.pad) % p.stride + p.stride * tx;
+        if (ky < p.kh && kx < p.kw) v = p.w[c * p.sO + n * p.sI + ky * p.sH + kx * p.sW];
+      }
+    }
+    p.dst[idx] = v;
+  }
+}
+
+// ---- reflect-pad fold (dgrad of a reflect-padded conv) --------------------------------------
+// dxp: [N][H+2P][W+2P][C] gradient w.r.t. the padded image; dx[n][y][x][c] sums every padded
+// position that mirrors onto (y,x).  P = pad (1 in the reference).
+__global__ void reflect_fold_kernel(const float* dxp, float* dx, int N, int H, int W, int C, int P) {
+  const long long total = (long long)N * H * W * C;
+  const int Hp = H + 2 * P, Wp = W + 2 * P;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    long long r = idx / C;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    // candidate padded rows: y+P (direct), P-y (top mirror, needs 1<=y<=P), 2H-2-y+P (bottom)
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = y + P;
+    if (y >= 1 && y <= P) ys[ny++] = P - y;
+    if (y <= H - 2 && y >= H - 1 - P) ys[ny++] = 2 * H - 2 - y + P;
+    xs[nx++] = x + P;
+    if (x >= 1 && x <= P) xs[nx++] = P - x;
+    if (x <= W - 2 && x >= W - 1 - P) xs[nx++] = 2 * W - 2 - x + P;
+    float v = 0.f;
+    for (int i = 0; i < ny; ++i)
+      for (int j = 0; j < nx; ++j) v += dxp[((size_t)(n * Hp + ys[i]) * Wp + xs[j]) * C + c];
+    dx[idx] = v;
+  }
+}
+
+// ---- weight gradient ----------------------------------------------------------------------
+//   dW[co][nn] = sum_m dy[m][co] * X[m][nn],  nn = (ky*kw+kx)*Cs + ci, X gathered from x.
+// Block tile BMc (co) x BNn (nn) over a split of the m range; partial tiles go to
+// slab[split][co_pad][NNpad] and are summed by wgrad_reduce_kernel.
+struct WgradParams {
+  const float* x;
+  const float* dy;
+  float* slab;
+  int NB, Hi, Wi, Cs, Hg, Wg, Cd, stride, pad, kw, reflect;
+  int NN, NNpad, Cdpad, M, rows_per_split, co_tiles, nn_tiles;
+};
+
+template <int BMc, int BNn, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  constexpr int TM = BMc / (WM * 32), TN = BNn / (WN * 32);
+  __shared__ __attribute__((aligned(16))) float As[32 * BMc];
+  __shared__ __attribute__((aligned(16))) float Bs[32 * BNn];
+  __shared__ int row_n[32], row_y[32], row_x[32];
+
+  const int tid = threadIdx.x;
+  const int ct = blockIdx.x % p.co_tiles, nt = blockIdx.x / p.co_tiles;
+  const int split = blockIdx.y;
+  const int co0 = ct * BMc, nn0 = nt * BNn;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const bool active = wave < WM * WN;   // small tiles use fewer than 4 MFMA waves
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const bool cd_vec = (p.Cd & 3) == 0;
+
+  for (int mb = m_begin; mb < m_end; mb += 32) {
+    __syncthreads();  // previous tile fully consumed
+    if (tid < 32) {
+      const int m = mb + tid;
+      int n = 0, y0 = -(1 << 28), x0 = -(1 << 28);
+      if (m < m_end) {
+        n = m / (p.Hg * p.Wg);
+        int rem = m - n * (p.Hg * p.Wg);
+        int a = rem / p.Wg, b = rem - a * p.Wg;
+        y0 = a * p.stride - p.pad; x0 = b * p.stride - p.pad;
+      }
+      row_n[tid] = n; row_y[tid] = y0; row_x[tid] = x0;
+    }
+    // A' tile: dy rows (dense)
+    if (cd_vec) {
+      constexpr int PER_ROW = BMc / 4;
+      for (int idx = tid; idx < 32 * PER_ROW; idx += 256) {
+        const int r = idx / PER_ROW, c4 = idx - r * PER_ROW;
+        const int m = mb + r, co = co0 + c4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < m_end && co < p.Cd) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cd + co);
+        *reinterpret_cast<f32x4*>(&As[r * BMc + c4 * 4]) = v;
+      }
+    } else {
+      for (int idx = tid; idx < 32 * BMc; idx += 256) {
+        const int r = idx / BMc, c = idx - r * BMc;
+        const int m = mb + r, co = co0 + c;
+        As[idx] = (m < m_end && co < p.Cd) ? p.dy[(size_t)m * p.Cd + co] : 0.f;
+      }
+    }
+    __syncthreads();  // row table visible
+    if constexpr (VEC) {
+      const int t = nn0 / p.Cs, c0 = nn0 - t * p.Cs;
+      const int ty = t / p.kw, tx = t - ty * p.kw;
+      constexpr int PER_ROW = BNn / 4;
+      for (int idx = tid; idx < 32 * PER_ROW; idx += 256) {
+        const int r = idx / PER_ROW, c4 = idx - r * PER_ROW;
+        int y = row_y[r] + ty, x = row_x[r] + tx;
+        if (p.reflect) {
+          if (y < 0) y = -y;
+          if (y >= p.Hi) y = 2 * p.Hi - 2 - y;
+          if (x < 0) x = -x;
+          if (x >= p.Wi) x = 2 * p.Wi - 2 - x;
+        }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi && nn0 < p.NN)
+          v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(row_n[r] * p.Hi + y) * p.Wi + x) * p.Cs + c0 + c4 * 4);
+        *reinterpret_cast<f32x4*>(&Bs[r * BNn + c4 * 4]) = v;
+      }
+    } else {
+      for (int idx = tid; idx < 32 * BNn; idx += 256) {
+        const int r = idx / BNn, j = idx - r * BNn;
+        const int nn = nn0 + j;
+        float v = 0.f;
+        if (nn < p.NN) {
+          const int t = nn / p.Cs, c = nn - t * p.Cs;
+          const int ty = t / p.kw, tx = t - ty * p.kw;
+          int y = row_y[r] + ty, x = row_x[r] + tx;
+          if (p.reflect) {
+            if (y < 0) y = -y;
+            if (y >= p.Hi) y = 2 * p.Hi - 2 - y;
+            if (x < 0) x = -x;
+            if (x >= p.Wi) x = 2 * p.Wi - 2 - x;
+          }
+          if ((unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi)
+            v = p.x[((size_t)(row_n[r] * p.Hi + y) * p.Wi + x) * p.Cs + c];
+        }
+        Bs[idx] = v;
+      }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+    for (int kp = 0; kp < 16; ++kp) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[(2 * kp + lh) * BMc + wm * TM * 32 + i * 32 + lr];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * kp + lh) * BNn + wn * TN * 32 + j * 32 + lr];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    }
+  }
+
+  if (!active) return;
+  float* slab = p.slab + (size_t)split * p.Cdpad * p.NNpad;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nn = nn0 + wn * TN * 32 + j * 32 + lr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        slab[(size_t)co * p.NNpad + nn] = acc[i][j][e];
+      }
+  }
+}
+
+struct WgradReduceParams {
+  const float* slab;
+  float* dw;
+  long long sO, sI, sH, sW;
+  int O, I, kh, kw, splits, Cdpad, NNpad;
+};
+
+__global__ void wgrad_reduce_kernel(WgradReduceParams p) {
+  const long long total = (long long)p.O * p.kh * p.kw * p.I;
+  const size_t slab_stride = (size_t)p.Cdpad * p.NNpad;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % p.I);
+    long long r = idx / p.I;
+    const int kx = (int)(r % p.kw); r /= p.kw;
+    const int ky = (int)(r % p.kh);
+    const int o = (int)(r / p.kh);
+    const size_t off = (size_t)o * p.NNpad + (size_t)(ky * p.kw + kx) * p.I + i;
+    float v = 0.f;
+    for (int s = 0; s < p.splits; ++s) v += p.slab[s * slab_stride + off];
+    p.dw[o * p.sO + i * p.sI + ky * p.sH + kx * p.sW] = v;
+  }
+}
+
+// column sums of a dense [M][C] matrix -> out[C] (bias gradients); two-stage, deterministic.
+__global__ void colsum_partial_kernel(const float* a, float* part, int M, int C, int rows_per_block) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float s = 0.f;
+  for (int m = m0; m < m1; ++m) s += a[(size_t)m * C + c];
+  part[(size_t)blockIdx.y * C + c] = s;
+}
+__global__ void colsum_final_kernel(const float* part, float* out, int C, int nparts) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int i = 0; i < nparts; ++i) s += part[(size_t)i * C + c];
+  out[c] = s;
+}
+
+// ---- host side ----------------------------------------------------------------------------
+namespace {
+
+struct TileChoice { int BM, BN; };
+
+TileChoice choose_tile(long long M, int N) {
+  if (N <= 32) return {128, 32};
+  if (N <= 64) return {128, 64};
+  long long tiles = ceil_div(M, 128) * ceil_div(N, 128);
+  if (tiles < 256) return {64, 64};
+  return {128, 128};
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm(const IgemmParams& p, int phases, bool vec, hipStream_t st) {
+  dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)phases, 1);
+  if (vec)
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, p);
+  return check_launch("igemm_kernel");
+}
+
+int run_igemm(IgemmParams p, int phases, hipStream_t st) {
+  TileChoice tc = choose_tile(p.M, p.Cd);
+  p.m_tiles = (int)ceil_div(p.M, tc.BM);
+  p.n_tiles = (int)ceil_div(p.Cd, tc.BN);
+  const bool vec = (p.Cs % BK) == 0;
+  if (tc.BM == 128 && tc.BN == 128) return launch_igemm<128, 128, 2, 2>(p, phases, vec, st);
+  if (tc.BM == 128 && tc.BN == 64) return launch_igemm<128, 64, 2, 2>(p, phases, vec, st);
+  if (tc.BM == 128 && tc.BN == 32) return launch_igemm<128, 32, 4, 1>(p, phases, vec, st);
+  return launch_igemm<64, 64, 2, 2>(p, phases, vec, st);
+}
+
+int npad_for(long long M, int N) {
+  TileChoice tc = choose_tile(M, N);
+  return (int)round_up(N, tc.BN);
+}
+
+int validate(const srgan_conv_desc* d) {
+  SRGAN_REQUIRE(d != nullptr, "conv desc is null");
+  SRGAN_REQUIRE(d->N > 0 && d->Hi > 0 && d->Wi > 0 && d->I > 0 && d->O > 0 && d->kh > 0 && d->kw > 0,
+                "conv desc: non-positive dimension");
+  SRGAN_REQUIRE(d->stride >= 1 && d->pad >= 0, "conv desc: bad stride/pad");
+  const int ho = (d->Hi + 2 * d->pad - d->kh) / d->stride + 1;
+  const int wo = (d->Wi + 2 * d->pad - d->kw) / d->stride + 1;
+  SRGAN_REQUIRE(ho == d->Ho && wo == d->Wo, "conv desc: Ho/Wo (%d,%d) do not match geometry (%d,%d)", d->Ho, d->Wo, ho, wo);
+  SRGAN_REQUIRE(d->pad_mode == SRGAN_PAD_ZERO || d->pad_mode == SRGAN_PAD_REFLECT, "conv desc: bad pad_mode");
+  if (d->pad_mode == SRGAN_PAD_REFLECT)
+    SRGAN_REQUIRE(d->stride == 1 && d->pad < d->Hi && d->pad < d->Wi, "reflect padding needs stride 1 and pad < size");
+  SRGAN_REQUIRE((long long)d->N * d->Hi * d->Wi * (long long)d->I < (1LL << 31) &&
+                (long long)d->N * d->Ho * d->Wo * (long long)d->O < (1LL << 31), "tensor too large for 32-bit pixel indexing");
+  return 0;
+}
+
+struct WgradPlan { int BMc, BNn, splits, rows_per_split, Cdpad, NNpad, co_tiles, nn_tiles; bool vec; };
+
+WgradPlan plan_wgrad(const srgan_conv_desc* d) {
+  WgradPlan w;
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  const int NN = d->kh * d->kw * d->I;
+  w.BMc = d->O <= 32 ? 32 : (d->O <= 64 ? 64 : 128);
+  w.vec = (d->I % 32) == 0;
+  if (w.vec) w.BNn = (d->I % 128 == 0 && w.BMc <= 64) ? 128 : ((d->I % 64 == 0) ? 64 : 32);
+  else w.BNn = 64;
+  if (w.BMc == 128 && w.BNn > 64) w.BNn = 64;
+  // supported shapes: (128,64) (64,128) (64,64) (32,128) (32,64) (64,32) (32,32)
+  w.co_tiles = (int)ceil_div(d->O, w.BMc);
+  w.nn_tiles = (int)ceil_div(NN, w.BNn);
+  w.Cdpad = w.co_tiles * w.BMc;
+  w.NNpad = w.nn_tiles * w.BNn;
+  long long tiles = (long long)w.co_tiles * w.nn_tiles;
+  long long want = ceil_div(1024, tiles);                 // ~4 blocks per CU
+  long long max_splits = ceil_div(M, 256);                // at least 8 K-tiles per split
+  long long splits = want < 1 ? 1 : want;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  w.rows_per_split = (int)round_up(ceil_div(M, splits), 32);
+  w.splits = (int)ceil_div(M, w.rows_per_split);
+  return w;
+}
+
+size_t pack_bytes(const srgan_conv_desc* d) {
+  // fwd pack and dgrad pack upper bounds
+  const long long M_f = (long long)d->N * d->Ho * d->Wo;
+  const long long Kf = round_up((long long)d->kh * d->kw * d->I, BK);
+  const long long f = (long long)npad_for(M_f, d->O) * Kf;
+  const int s = d->stride;
+  const int Ty = (int)ceil_div(d->kh, s), Tx = (int)ceil_div(d->kw, s);
+  const long long Kd = round_up((long long)Ty * Tx * d->O, BK);
+  const long long g = (long long)s * s * round_up(d->I, 128) * Kd;
+  return (size_t)((f > g ? f : g) * sizeof(float));
+}
+
+}  // namespace
+}  // namespace srgan
+
+using namespace srgan;
+
+extern "C" size_t srgan_conv2d_workspace(const srgan_conv_desc* d) {
+  if (validate(d) != 0) return 0;
+  size_t bytes = pack_bytes(d);
+  // reflect dgrad: padded-gradient temp
+  if (d->pad_mode == SRGAN_PAD_REFLECT)
+    bytes += (size_t)d->N * (d->Hi + 2 * d->pad) * (d->Wi + 2 * d->pad) * d->I * sizeof(float);
+  WgradPlan w = plan_wgrad(d);
+  size_t wg = (size_t)w.splits * w.Cdpad * w.NNpad * sizeof(float);
+  size_t cs = (size_t)1024 * d->O * sizeof(float);
+  if (wg + cs > bytes) bytes = wg + cs;
+  return bytes + 4096;
+}
+
+extern "C" int srgan_conv2d_fwd(const srgan_conv_desc* d, const float* x, const float* w, const float* bias,
+                                float* y, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(x && w && y && ws, "conv2d_fwd: null pointer");
+  SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_fwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  IgemmParams p{};
+  p.src = x; p.bias = bias; p.dst = y;
+  p.NB = d->N; p.Hs = d->Hi; p.Ws = d->Wi; p.Cs = d->I;
+  p.Hg = d->Ho; p.Wg = d->Wo; p.Hd = d->Ho; p.Wd = d->Wo; p.Cd = d->O;
+  p.mode = 0; p.stride = d->stride; p.pad = d->pad; p.Ty = d->kh; p.Tx = d->kw;
+  p.K = d->kh * d->kw * d->I; p.Kpad = (int)round_up(p.K, BK);
+  p.M = d->N * d->Ho * d->Wo;
+  p.Npad = npad_for(p.M, d->O);
+  p.reflect = d->pad_mode == SRGAN_PAD_REFLECT;
+  p.act = act; p.slope = slope;
+  PackParams q{};
+  q.w = w; q.dst = (float*)ws; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
+  q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 0; q.stride = d->stride; q.pad = d->pad;
+  q.Ty = d->kh; q.Tx = d->kw; q.Cs = d->I; q.N = d->O; q.K = p.K; q.Kpad = p.Kpad; q.Npad = p.Npad; q.phases = 1;
+  long long total = (long long)q.Npad * q.Kpad;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
+  if (int e = check_launch("pack_weights_kernel")) return e;
+  p.wp = (const float*)ws;
+  return run_igemm(p, 1, st);
+}
+
+extern "C" int srgan_conv2d_dgrad(const srgan_conv_desc* d, const float* dy, const float* w, float* dx,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(dy && w && dx && ws, "conv2d_dgrad: null pointer");
+  SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_dgrad: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const bool reflect = d->pad_mode == SRGAN_PAD_REFLECT;
+  const int s = d->stride;
+  // reflect: gradient w.r.t. the padded image (a pad-0 conv over Hi+2P), then fold.
+  const int P = reflect ? d->pad : 0;
+  const int Hd = d->Hi + 2 * P, Wd = d->Wi + 2 * P;
+  const int pad_eff = reflect ? 0 : d->pad;
+  IgemmParams p{};
+  p.src = dy; p.bias = nullptr;
+  p.NB = d->N; p.Hs = d->Ho; p.Ws = d->Wo; p.Cs = d->O;
+  p.Hg = (int)ceil_div(Hd, s); p.Wg = (int)ceil_div(Wd, s);
+  p.Hd = Hd; p.Wd = Wd; p.Cd = d->I;
+  p.mode = 1; p.stride = s; p.pad = pad_eff;
+  p.Ty = (int)ceil_div(d->kh, s); p.Tx = (int)ceil_div(d->kw, s);
+  p.K = p.Ty * p.Tx * d->O; p.Kpad = (int)round_up(p.K, BK);
+  p.M = d->N * p.Hg * p.Wg;
+  p.Npad = npad_for(p.M, d->I);
+  p.reflect = 0; p.act = SRGAN_ACT_NONE; p.slope = 0.f;
+  const int phases = s * s;
+  float* packed = (float*)ws;
+  size_t packed_elems = (size_t)phases * p.Npad * p.Kpad;
+  float* padded = (float*)ws + round_up((long long)packed_elems, 64);
+  PackParams q{};
+  q.w = w; q.dst = packed; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
+  q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 1; q.stride = s; q.pad = pad_eff;
+  q.Ty = p.Ty; q.Tx = p.Tx; q.Cs = d->O; q.N = d->I; q.K = p.K; q.Kpad = p.Kpad; q.Npad = p.Npad; q.phases = phases;
+  long long total = (long long)packed_elems;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
+  if (int e = check_launch("pack_weights_kernel")) return e;
+  p.wp = packed;
+  p.dst = reflect ? padded : dx;
+  if (int e = run_igemm(p, phases, st)) return e;
+  if (reflect) {
+    long long n = (long long)d->N * d->Hi * d->Wi * d->I;
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 256), 8192)), dim3(256), 0, st,
+                       padded, dx, d->N, d->Hi, d->Wi, d->I, d->pad);
+    return check_launch("reflect_fold_kernel");
+  }
+  return 0;
+}
+
+namespace srgan {
+template <int BMc, int BNn, int WM, int WN>
+static int launch_wgrad(const WgradParams& p, const WgradPlan& w, hipStream_t st) {
+  dim3 grid((unsigned)(w.co_tiles * w.nn_tiles), (unsigned)w.splits, 1);
+  if (w.vec)
+    hipLaunchKernelGGL((wgrad_kernel<BMc, BNn, WM, WN, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<BMc, BNn, WM, WN, false>), grid, dim3(256), 0, st, p);
+  return check_launch("wgrad_kernel");
+}
+}  // namespace srgan
+
+extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, const float* dy, float* dw,
+                                  float* dbias, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(x && dy && dw && ws, "conv2d_wgrad: null pointer");
+  SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_wgrad: workspace too small");
+  hipStream_t st = as_stream(stream);
+  WgradPlan w = plan_wgrad(d);
+  WgradParams p{};
+  p.x = x; p.dy = dy; p.slab = (float*)ws;
+  p.NB = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cs = d->I; p.Hg = d->Ho; p.Wg = d->Wo; p.Cd = d->O;
+  p.stride = d->stride; p.pad = d->pad; p.kw = d->kw; p.reflect = d->pad_mode == SRGAN_PAD_REFLECT;
+  p.NN = d->kh * d->kw * d->I; p.NNpad = w.NNpad; p.Cdpad = w.Cdpad;
+  p.M = d->N * d->Ho * d->Wo; p.rows_per_split = w.rows_per_split;
+  p.co_tiles = w.co_tiles; p.nn_tiles = w.nn_tiles;
+  int e = -1;
+  if (w.BMc == 128 && w.BNn == 64) e = launch_wgrad<128, 64, 2, 2>(p, w, st);
+  else if (w.BMc == 64 && w.BNn == 128) e = launch_wgrad<64, 128, 2, 2>(p, w, st);
+  else if (w.BMc == 64 && w.BNn == 64) e = launch_wgrad<64, 64, 2, 2>(p, w, st);
+  else if (w.BMc == 64 && w.BNn == 32) e = launch_wgrad<64, 32, 2, 1>(p, w, st);
+  else if (w.BMc == 32 && w.BNn == 128) e = launch_wgrad<32, 128, 1, 4>(p, w, st);
+  else if (w.BMc == 32 && w.BNn == 64) e = launch_wgrad<32, 64, 1, 2>(p, w, st);
+  else if (w.BMc == 32 && w.BNn == 32) e = launch_wgrad<32, 32, 1, 1>(p, w, st);
+  else if (w.BMc == 128 && w.BNn == 32) e = launch_wgrad<128, 32, 4, 1>(p, w, st);
+  else { set_error("wgrad: unsupported tile %dx%d", w.BMc, w.BNn); return -1; }
+  if (e) return e;
+  WgradReduceParams r{};
+  r.slab = (const float*)ws; r.dw = dw; r.sO = d->sO; r.sI = d->sI; r.sH = d->sH; r.sW = d->sW;
+  r.O = d->O; r.I = d->I; r.kh = d->kh; r.kw = d->kw; r.splits = w.splits; r.Cdpad = w.Cdpad; r.NNpad = w.NNpad;
+  long long total = (long long)d->O * d->kh * d->kw * d->I;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, r);
+  if (int e2 = check_launch("wgrad_reduce_kernel")) return e2;
+  if (dbias) {
+    float* part = (float*)ws + (size_t)w.splits * w.Cdpad * w.NNpad;
+    const int M = p.M;
+    int nparts = (int)std::min<long long>(1024, ceil_div(M, 64));
+    int rpb = (int)ceil_div(M, nparts);
+    nparts = (int)ceil_div(M, rpb);
+    dim3 g1((unsigned)ceil_div(d->O, 64), (unsigned)nparts);
+    hipLaunchKernelGGL(colsum_partial_kernel, g1, dim3(64), 0, st, dy, part, M, d->O, rpb);
+    if (int e3 = check_launch("colsum_partial_kernel")) return e3;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(d->O, 64)), dim3(64), 0, st, (const float*)part, dbias, d->O, nparts);
+    return check_launch("colsum_final_kernel");
+  }
+  return 0;
+}

@@ -1,0 +1,266 @@
+// Fused loss reductions of the SRGAN train step: every kernel produces the loss value AND the
+// gradient w.r.t. its input in one launch (wavefront-shuffle reductions, 64-lane waves).
+//
+//   mse_const       get_loss_D  (pyfiles/util.py:457-462, nn.MSELoss against a constant)
+//   softmax_mse     nn.Softmax(dim=1) + get_domainloss_D (model.py:333-346, util.py:464-468)
+//   l1_mean         torch.mean(torch.abs(a-b)) (util_notebook.py:625,639,676,686)
+//   latent_losses   batch-KL (util_notebook.py:644-650), correlation (util.py:470-517),
+//                   histogram imitation (util.py:521-553); closed forms: SURVEY.md Appendix F.2-F.4
+#include <algorithm>
+#include <cmath>
+#include "common.h"
+
+namespace srgan {
+
+__global__ __launch_bounds__(256) void mse_const_kernel(const float* o, long long n, float target, float weight,
+                                                        float* loss, float* d_o) {
+  __shared__ float red[16];
+  float s = 0.f;
+  const float gscale = 2.f * weight / (float)n;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float d = o[i] - target;
+    s += d * d;
+    if (d_o) d_o[i] = gscale * d;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) loss[0] = weight * s / (float)n;
+}
+
+__global__ __launch_bounds__(256) void softmax_mse_kernel(const float* z, const long long* label, int B, int nc,
+                                                          float weight, float* q, float* loss, float* dz) {
+  __shared__ float red[16];
+  float s = 0.f;
+  const float gscale = 2.f * weight / (float)(B * nc);
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float zz[16], qq[16];
+    float mx = -INFINITY;
+    for (int j = 0; j < nc; ++j) { zz[j] = z[b * nc + j]; mx = fmaxf(mx, zz[j]); }
+    float den = 0.f;
+    for (int j = 0; j < nc; ++j) { qq[j] = expf(zz[j] - mx); den += qq[j]; }
+    const int lab = (int)label[b];
+    float dot = 0.f;
+    float dq[16];
+    for (int j = 0; j < nc; ++j) {
+      qq[j] /= den;
+      const float d = qq[j] - (j == lab ? 1.f : 0.f);
+      s += d * d;
+      dq[j] = gscale * d;
+      dot += qq[j] * dq[j];
+    }
+    for (int j = 0; j < nc; ++j) {
+      if (q) q[b * nc + j] = qq[j];
+      if (dz) dz[b * nc + j] = qq[j] * (dq[j] - dot);
+    }
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) loss[0] = weight * s / (float)(B * nc);
+}
+
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* a, const float* b, long long n, float gscale,
+                                                         float* part, float* da, float* db) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    s += fabsf(d);
+    const float g = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
+    if (da) da[i] = g;
+    if (db) db[i] = -g;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void l1_final_kernel(const float* part, int nparts, float scale, float* loss) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) loss[0] = s * scale;
+}
+
+// ---- latent losses: one workgroup, mu staged in LDS ---------------------------------------
+constexpr int LAT_MAX_D = 16, LAT_MAX_BINS = 64, LAT_MAX_ELEMS = 16384;
+
+__global__ __launch_bounds__(256) void latent_losses_kernel(const float* mu_g, int B, int d, float n_batch,
+                                                            const float* target, int bins, float range_max, float sigma,
+                                                            float w_bkl, float w_corr, float w_hist, float* vals,
+                                                            float* dmu) {
+  extern __shared__ float smem[];
+  float* mu = smem;                        // [B][d]
+  float* mean = mu + B * d;                // [d]
+  float* var_u = mean + LAT_MAX_D;         // [d] unbiased variance
+  float* cov = var_u + LAT_MAX_D;          // [d][d]
+  float* dC = cov + LAT_MAX_D * LAT_MAX_D; // [d][d] dL/dC (symmetrised use)
+  float* h = dC + LAT_MAX_D * LAT_MAX_D;   // [d][bins]
+  float* dh = h + LAT_MAX_D * LAT_MAX_BINS;// [d][bins]
+  float* scal = dh + LAT_MAX_D * LAT_MAX_BINS;  // misc scalars: [0]=bkl [1]=corr [2]=hist, [8+j]=S_j
+  const int tid = threadIdx.x, nt = blockDim.x;
+
+  for (int i = tid; i < B * d; i += nt) mu[i] = mu_g[i];
+  if (tid < 32) scal[tid] = 0.f;
+  __syncthreads();
+  // means
+  if (tid < d) {
+    float s = 0.f;
+    for (int i = 0; i < B; ++i) s += mu[i * d + tid];
+    mean[tid] = s / (float)B;
+  }
+  __syncthreads();
+  // covariance (unnormalised by B-1 applied here)
+  for (int p = tid; p < d * d; p += nt) {
+    const int a = p / d, b = p - a * d;
+    float s = 0.f;
+    for (int i = 0; i < B; ++i) s += (mu[i * d + a] - mean[a]) * (mu[i * d + b] - mean[b]);
+    cov[a * LAT_MAX_D + b] = s / (float)(B - 1);
+  }
+  __syncthreads();
+  if (tid < d) var_u[tid] = cov[tid * LAT_MAX_D + tid];
+  __syncthreads();
+  const float sfac = n_batch / (n_batch - 1.f);
+  // batch-KL value
+  if (tid == 0) {
+    float L = 0.f;
+    for (int j = 0; j < d; ++j) {
+      const float v = sfac * var_u[j];
+      L += 1.f + logf(v) - mean[j] * mean[j] - v;
+    }
+    scal[0] = -0.5f * L;
+  }
+  // correlation: R, G = sign(R - I)/(d(d-1)) off-diagonal (0 where clamp active), dL/dC
+  if (tid == 64) {
+    float R[LAT_MAX_D][LAT_MAX_D], G[LAT_MAX_D][LAT_MAX_D], sd[LAT_MAX_D];
+    const float norm = 1.f / (float)(d * (d - 1));
+    for (int a = 0; a < d; ++a) sd[a] = sqrtf(var_u[a]);
+    float L = 0.f;
+    for (int a = 0; a < d; ++a)
+      for (int b = 0; b < d; ++b) {
+        float r = cov[a * LAT_MAX_D + b] / sd[b] / sd[a];
+        const bool clamped = r > 1.f || r < -1.f;
+        r = fminf(1.f, fmaxf(-1.f, r));
+        R[a][b] = r;
+        const float e = r - (a == b ? 1.f : 0.f);
+        L += fabsf(e);
+        float g = e > 0.f ? norm : (e < 0.f ? -norm : 0.f);
+        if (clamped || a == b) g = 0.f;   // diagonal is identically 1: analytic derivative 0
+        G[a][b] = g;
+      }
+    scal[1] = L * norm;
+    for (int a = 0; a < d; ++a) {
+      float rs = 0.f, cs = 0.f;
+      for (int b = 0; b < d; ++b) { rs += G[a][b] * R[a][b]; cs += G[b][a] * R[b][a]; }
+      for (int b = 0; b < d; ++b) {
+        float v = G[a][b] / (sd[a] * sd[b]);
+        if (a == b) v -= (rs + cs) / (2.f * var_u[a]);
+        dC[a * LAT_MAX_D + b] = v;
+      }
+    }
+  }
+  // histograms h[j][k]
+  const float delta = 2.f * range_max / (float)bins;
+  const float knorm = delta / (sigma * 2.5066282746310002f);
+  const float inv2s2 = 0.5f / (sigma * sigma);
+  for (int p = tid; p < d * bins; p += nt) {
+    const int j = p / bins, k = p - j * bins;
+    const float ck = -range_max + delta * ((float)k + 0.5f);
+    float s = 0.f;
+    for (int i = 0; i < B; ++i) {
+      const float dd = mu[i * d + j] - ck;
+      s += expf(-dd * dd * inv2s2);
+    }
+    h[j * LAT_MAX_BINS + k] = s * knorm;
+  }
+  __syncthreads();
+  // per-dim normaliser, KL value and dL/dh
+  if (tid < d) {
+    const int j = tid;
+    float S = 0.f;
+    for (int k = 0; k < bins; ++k) S += h[j * LAT_MAX_BINS + k];
+    float L = 0.f, corr = 0.f;
+    for (int k = 0; k < bins; ++k) {
+      const float p = h[j * LAT_MAX_BINS + k] / S + 1e-8f;
+      const float t = target[k];
+      L += t * (logf(t) - logf(p));
+      corr += t * h[j * LAT_MAX_BINS + k] / (p * S * S);
+    }
+    for (int k = 0; k < bins; ++k) {
+      const float p = h[j * LAT_MAX_BINS + k] / S + 1e-8f;
+      dh[j * LAT_MAX_BINS + k] = -target[k] / (p * S) + corr;
+    }
+    scal[8 + j] = L;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float L = 0.f;
+    for (int j = 0; j < d; ++j) L += scal[8 + j];
+    vals[0] = scal[0]; vals[1] = scal[1]; vals[2] = L;
+    vals[3] = w_bkl * scal[0] + w_corr * scal[1] + w_hist * L;
+  }
+  if (!dmu) return;
+  // gradient per element
+  for (int p = tid; p < B * d; p += nt) {
+    const int i = p / d, j = p - i * d;
+    const float x = mu[p];
+    // batch-KL: m_j/B - (1/v_j - 1) * s * (x - m_j)/(B-1)
+    const float v = sfac * var_u[j];
+    const float gb = mean[j] / (float)B - (1.f / v - 1.f) * sfac * (x - mean[j]) / (float)(B - 1);
+    // correlation: dL/dxm_{j,i} = sum_b (dC[j][b] + dC[b][j]) xm_{b,i} / (B-1); the row mean of this
+    // over i is zero (sum_i xm = 0), so the mean-removal Jacobian changes nothing.
+    float gc = 0.f;
+    for (int b = 0; b < d; ++b) gc += (dC[j * LAT_MAX_D + b] + dC[b * LAT_MAX_D + j]) * (mu[i * d + b] - mean[b]);
+    gc /= (float)(B - 1);
+    // histogram: sum_k dh_k * (-kappa_ki * d_ki / sigma^2)
+    float gh = 0.f;
+    for (int k = 0; k < bins; ++k) {
+      const float ck = -range_max + delta * ((float)k + 0.5f);
+      const float dd = x - ck;
+      gh += dh[j * LAT_MAX_BINS + k] * (-knorm * expf(-dd * dd * inv2s2) * dd / (sigma * sigma));
+    }
+    dmu[p] = w_bkl * gb + w_corr * gc + w_hist * gh;
+  }
+}
+
+}  // namespace srgan
+
+using namespace srgan;
+
+extern "C" int srgan_mse_const(const float* o, long long n, float target, float weight, float* loss, float* d_o, void* stream) {
+  SRGAN_REQUIRE(o && loss && n > 0, "mse_const: bad argument");
+  hipLaunchKernelGGL(mse_const_kernel, dim3(1), dim3(256), 0, as_stream(stream), o, n, target, weight, loss, d_o);
+  return check_launch("mse_const_kernel");
+}
+
+extern "C" int srgan_softmax_mse(const float* z, const long long* label, int B, int n_class, float weight, float* q,
+                                 float* loss, float* dz, void* stream) {
+  SRGAN_REQUIRE(z && label && loss && B > 0 && n_class > 0 && n_class <= 16, "softmax_mse: bad argument (n_class<=16)");
+  hipLaunchKernelGGL(softmax_mse_kernel, dim3(1), dim3(256), 0, as_stream(stream), z, label, B, n_class, weight, q, loss, dz);
+  return check_launch("softmax_mse_kernel");
+}
+
+extern "C" size_t srgan_l1_workspace(long long n) {
+  (void)n;
+  return 1024 * sizeof(float);
+}
+
+extern "C" int srgan_l1_mean(const float* a, const float* b, long long n, float weight, float* loss, float* da, float* db,
+                             void* ws, size_t ws_bytes, void* stream) {
+  SRGAN_REQUIRE(a && b && loss && n > 0, "l1_mean: bad argument");
+  SRGAN_REQUIRE(ws && ws_bytes >= 1024 * sizeof(float), "l1_mean: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int blocks = (int)std::max<long long>(1, std::min<long long>(1024, ceil_div(n, 256 * 8)));
+  float* part = (float*)ws;
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, st, a, b, n, weight / (float)n, part, da, db);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, st, (const float*)part, blocks, weight / (float)n, loss);
+  return check_launch("l1_mean");
+}
+
+extern "C" int srgan_latent_losses(const float* mu, int B, int d, float n_batch, const float* hist_target, int bins,
+                                   float range_max, float sigma, float w_bkl, float w_corr, float w_hist, float* vals,
+                                   float* dmu, void* stream) {
+  SRGAN_REQUIRE(mu && hist_target && vals, "latent_losses: null pointer");
+  SRGAN_REQUIRE(B >= 2 && d >= 2 && d <= LAT_MAX_D && bins >= 1 && bins <= LAT_MAX_BINS && (long long)B * d <= LAT_MAX_ELEMS,
+                "latent_losses: need 2<=B, 2<=d<=16, bins<=64, B*d<=16384");
+  const size_t shmem = ((size_t)B * d + 2 * LAT_MAX_D + 2 * LAT_MAX_D * LAT_MAX_D + 2 * LAT_MAX_D * LAT_MAX_BINS + 64) * sizeof(float);
+  hipLaunchKernelGGL(latent_losses_kernel, dim3(1), dim3(256), shmem, as_stream(stream), mu, B, d, n_batch, hist_target, bins,
+                     range_max, sigma, w_bkl, w_corr, w_hist, vals, dmu);
+  return check_launch("latent_losses_kernel");
+}

@@ -1,0 +1,301 @@
+// Small HBM-bound kernels of the train step: activations, pools, layout repacks, Linear heads,
+// fused Adam.  NHWC fp32.  Reference call sites are listed in include/srgan_hip.h.
+#include <algorithm>
+#include <cmath>
+#include "common.h"
+
+namespace srgan {
+
+static inline unsigned grid_for(long long n, int per_thread = 1) {
+  long long b = ceil_div(ceil_div(n, per_thread), 256);
+  return (unsigned)std::max<long long>(1, std::min<long long>(b, 8192));
+}
+
+#define GRID_STRIDE(i, n) \
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+__global__ void act_fwd_kernel(const float* x, float* y, long long n, int act, float slope) {
+  GRID_STRIDE(i, n) y[i] = apply_act(x[i], act, slope);
+}
+__global__ void act_bwd_kernel(const float* y, const float* dy, float* dx, long long n, int act, float slope) {
+  GRID_STRIDE(i, n) dx[i] = dy[i] * act_grad(y[i], act, slope);
+}
+__global__ void tanh_fwd_kernel(const float* x, float* y, long long n) {
+  GRID_STRIDE(i, n) y[i] = tanhf(x[i]);
+}
+__global__ void tanh_bwd_kernel(const float* y, const float* dy, float* dx, long long n) {
+  GRID_STRIDE(i, n) { const float t = y[i]; dx[i] = dy[i] * (1.f - t * t); }
+}
+__global__ void add_kernel(const float* a, const float* b, float* y, long long n) {
+  GRID_STRIDE(i, n) y[i] = a[i] + b[i];
+}
+
+// AvgPool2d(3, s2, p1, count_include_pad=False): Ho = (H+2-3)/2+1
+__global__ void avgpool3s2_fwd_kernel(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo) {
+  const long long total = (long long)N * Ho * Wo * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float s = 0.f;
+    int cnt = 0;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = oy * 2 + dy;
+      if ((unsigned)yy >= (unsigned)H) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int xx = ox * 2 + dx;
+        if ((unsigned)xx >= (unsigned)W) continue;
+        s += x[((size_t)(n * H + yy) * W + xx) * C + c];
+        ++cnt;
+      }
+    }
+    y[i] = s / (float)cnt;
+  }
+}
+__device__ __forceinline__ int valid3(int o, int L) {  // taps of window o that fall inside [0,L)
+  int c = 0;
+  for (int d = -1; d <= 1; ++d) c += ((unsigned)(o * 2 + d) < (unsigned)L);
+  return c;
+}
+__global__ void avgpool3s2_bwd_kernel(const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo) {
+  const long long total = (long long)N * H * W * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    float s = 0.f;
+    // windows oy with |2*oy - y| <= 1
+    for (int oy = (y - 1 + 1) / 2 - 1; oy <= (y + 1) / 2; ++oy) {
+      if (oy < 0 || oy >= Ho || abs(2 * oy - y) > 1) continue;
+      const int cy = valid3(oy, H);
+      for (int ox = (x - 1 + 1) / 2 - 1; ox <= (x + 1) / 2; ++ox) {
+        if (ox < 0 || ox >= Wo || abs(2 * ox - x) > 1) continue;
+        const int cx = valid3(ox, W);
+        s += dy[((size_t)(n * Ho + oy) * Wo + ox) * C + c] / (float)(cy * cx);
+      }
+    }
+    dx[i] = s;
+  }
+}
+
+__global__ void avgpool2_fwd_kernel(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo) {
+  const long long total = (long long)N * Ho * Wo * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const size_t b = ((size_t)(n * H + oy * 2) * W + ox * 2) * C + c;
+    y[i] = 0.25f * (x[b] + x[b + C] + x[b + (size_t)W * C] + x[b + (size_t)W * C + C]);
+  }
+}
+__global__ void avgpool2_bwd_kernel(const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo) {
+  const long long total = (long long)N * H * W * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    const int oy = y >> 1, ox = x >> 1;
+    dx[i] = (oy < Ho && ox < Wo) ? 0.25f * dy[((size_t)(n * Ho + oy) * Wo + ox) * C + c] : 0.f;
+  }
+}
+
+__global__ void lrelu_gap_fwd_kernel(const float* x, float* y, int N, int HW, int C, float slope) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * C) return;
+  const int n = idx / C, c = idx - n * C;
+  float s = 0.f;
+  for (int r = 0; r < HW; ++r) {
+    const float v = x[((size_t)n * HW + r) * C + c];
+    s += v > 0.f ? v : v * slope;
+  }
+  y[idx] = s / (float)HW;
+}
+__global__ void lrelu_gap_bwd_kernel(const float* x, const float* dy, float* dx, int N, int HW, int C, float slope) {
+  const long long total = (long long)N * HW * C;
+  const float inv = 1.f / (float)HW;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    const int n = (int)(i / ((long long)HW * C));
+    dx[i] = dy[n * C + c] * inv * (x[i] > 0.f ? 1.f : slope);
+  }
+}
+
+// Linear heads: one wave per output element (M, N small; K = 1024)
+__global__ void linear_fwd_kernel(const float* x, const float* W, const float* b, float* y, int M, int N, int K) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= M * N) return;
+  const int m = wave / N, n = wave - m * N;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += x[(size_t)m * K + k] * W[(size_t)n * K + k];
+  s = wave_sum(s);
+  if (lane == 0) y[wave] = s + (b ? b[n] : 0.f);
+}
+__global__ void linear_bwd_dx_kernel(const float* W, const float* dy, float* dx, int M, int N, int K) {
+  const long long total = (long long)M * K;
+  GRID_STRIDE(i, total) {
+    const int k = (int)(i % K), m = (int)(i / K);
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dy[m * N + n] * W[(size_t)n * K + k];
+    dx[i] = s;
+  }
+}
+__global__ void linear_bwd_dw_kernel(const float* x, const float* dy, float* dW, float* db, int M, int N, int K) {
+  const long long total = (long long)N * K;
+  GRID_STRIDE(i, total) {
+    const int k = (int)(i % K), n = (int)(i / K);
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dy[m * N + n] * x[(size_t)m * K + k];
+    dW[i] = s;
+    if (k == 0 && db) {
+      float t = 0.f;
+      for (int m = 0; m < M; ++m) t += dy[m * N + n];
+      db[n] = t;
+    }
+  }
+}
+
+// layout repack through a 32x33 LDS tile: [N][C][P] <-> [N][P][C], P = H*W
+__global__ void transpose_cp_kernel(const float* x, float* y, int rows, int cols) {
+  // x: [n][rows][cols] -> y: [n][cols][rows]
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const float* xp = x + (size_t)n * rows * cols;
+  float* yp = y + (size_t)n * rows * cols;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    if (r < rows && c < cols) tile[j][tx] = xp[(size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (r < rows && c < cols) yp[(size_t)c * rows + r] = tile[tx][j];
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float step_size, float beta1, float beta2, float eps,
+                            float inv_sqrt_bc2) {
+  GRID_STRIDE(i, n) {
+    const float gi = g[i];
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  }
+}
+
+}  // namespace srgan
+
+using namespace srgan;
+
+#define LAUNCH1D(kernel, n, st, ...)                                                        \
+  do {                                                                                      \
+    hipLaunchKernelGGL(kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(st), __VA_ARGS__); \
+    return check_launch(#kernel);                                                           \
+  } while (0)
+
+extern "C" int srgan_act_fwd(const float* x, float* y, long long n, int act, float slope, void* stream) {
+  SRGAN_REQUIRE(x && y && n >= 0, "act_fwd: bad argument");
+  if (n == 0) return 0;
+  LAUNCH1D(act_fwd_kernel, n, stream, x, y, n, act, slope);
+}
+extern "C" int srgan_act_bwd(const float* y, const float* dy, float* dx, long long n, int act, float slope, void* stream) {
+  SRGAN_REQUIRE(y && dy && dx && n >= 0, "act_bwd: bad argument");
+  if (n == 0) return 0;
+  LAUNCH1D(act_bwd_kernel, n, stream, y, dy, dx, n, act, slope);
+}
+extern "C" int srgan_tanh_fwd(const float* x, float* y, long long n, void* stream) {
+  SRGAN_REQUIRE(x && y && n >= 0, "tanh_fwd: bad argument");
+  if (n == 0) return 0;
+  LAUNCH1D(tanh_fwd_kernel, n, stream, x, y, n);
+}
+extern "C" int srgan_tanh_bwd(const float* y, const float* dy, float* dx, long long n, void* stream) {
+  SRGAN_REQUIRE(y && dy && dx && n >= 0, "tanh_bwd: bad argument");
+  if (n == 0) return 0;
+  LAUNCH1D(tanh_bwd_kernel, n, stream, y, dy, dx, n);
+}
+extern "C" int srgan_add(const float* a, const float* b, float* y, long long n, void* stream) {
+  SRGAN_REQUIRE(a && b && y && n >= 0, "add: bad argument");
+  if (n == 0) return 0;
+  LAUNCH1D(add_kernel, n, stream, a, b, y, n);
+}
+
+extern "C" int srgan_avgpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  SRGAN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "avgpool3s2_fwd: bad argument");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  LAUNCH1D(avgpool3s2_fwd_kernel, (long long)N * Ho * Wo * C, stream, x, y, N, H, W, C, Ho, Wo);
+}
+extern "C" int srgan_avgpool3s2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+  SRGAN_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "avgpool3s2_bwd: bad argument");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  LAUNCH1D(avgpool3s2_bwd_kernel, (long long)N * H * W * C, stream, dy, dx, N, H, W, C, Ho, Wo);
+}
+extern "C" int srgan_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  SRGAN_REQUIRE(x && y && N > 0 && H > 1 && W > 1 && C > 0, "avgpool2_fwd: bad argument");
+  LAUNCH1D(avgpool2_fwd_kernel, (long long)N * (H / 2) * (W / 2) * C, stream, x, y, N, H, W, C, H / 2, W / 2);
+}
+extern "C" int srgan_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+  SRGAN_REQUIRE(dy && dx && N > 0 && H > 1 && W > 1 && C > 0, "avgpool2_bwd: bad argument");
+  LAUNCH1D(avgpool2_bwd_kernel, (long long)N * H * W * C, stream, dy, dx, N, H, W, C, H / 2, W / 2);
+}
+extern "C" int srgan_lrelu_gap_fwd(const float* x, float* y, int N, int HW, int C, float slope, void* stream) {
+  SRGAN_REQUIRE(x && y && N > 0 && HW > 0 && C > 0, "lrelu_gap_fwd: bad argument");
+  LAUNCH1D(lrelu_gap_fwd_kernel, (long long)N * C, stream, x, y, N, HW, C, slope);
+}
+extern "C" int srgan_lrelu_gap_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C, float slope, void* stream) {
+  SRGAN_REQUIRE(x && dy && dx && N > 0 && HW > 0 && C > 0, "lrelu_gap_bwd: bad argument");
+  LAUNCH1D(lrelu_gap_bwd_kernel, (long long)N * HW * C, stream, x, dy, dx, N, HW, C, slope);
+}
+
+extern "C" int srgan_linear_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, void* stream) {
+  SRGAN_REQUIRE(x && W && y && M > 0 && N > 0 && K > 0, "linear_fwd: bad argument");
+  const long long threads = (long long)M * N * 64;
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, as_stream(stream), x, W, b, y, M, N, K);
+  return check_launch("linear_fwd_kernel");
+}
+extern "C" int srgan_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db,
+                                int M, int N, int K, void* stream) {
+  SRGAN_REQUIRE(x && W && dy && M > 0 && N > 0 && K > 0, "linear_bwd: bad argument");
+  hipStream_t st = as_stream(stream);
+  if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(grid_for((long long)M * K)), dim3(256), 0, st, W, dy, dx, M, N, K);
+  if (dW) hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(grid_for((long long)N * K)), dim3(256), 0, st, x, dy, dW, db, M, N, K);
+  return check_launch("linear_bwd");
+}
+
+extern "C" int srgan_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+  SRGAN_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad argument");
+  const int P = H * W;  // [N][C][P] -> [N][P][C]
+  dim3 g((P + 31) / 32, (C + 31) / 32, N);
+  hipLaunchKernelGGL(transpose_cp_kernel, g, dim3(256), 0, as_stream(stream), x, y, C, P);
+  return check_launch("transpose_cp_kernel");
+}
+extern "C" int srgan_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+  SRGAN_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad argument");
+  const int P = H * W;  // [N][P][C] -> [N][C][P]
+  dim3 g((C + 31) / 32, (P + 31) / 32, N);
+  hipLaunchKernelGGL(transpose_cp_kernel, g, dim3(256), 0, as_stream(stream), x, y, P, C);
+  return check_launch("transpose_cp_kernel");
+}
+
+extern "C" int srgan_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                               float beta2, float eps, int step_count, void* stream) {
+  SRGAN_REQUIRE(p && g && m && v && n >= 0 && step_count >= 1, "adam_step: bad argument");
+  if (n == 0) return 0;
+  // torch 1.4: p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+  const double bc1 = 1.0 - std::pow((double)beta1, step_count);
+  const double bc2 = 1.0 - std::pow((double)beta2, step_count);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
+  LAUNCH1D(adam_kernel, n, stream, p, g, m, v, n, step_size, beta1, beta2, eps, inv_sqrt_bc2);
+}

@@ -1,0 +1,91 @@
+"""ctypes binding of libsrgan_hip.so (C ABI declared in include/srgan_hip.h).
+
+There is NO fallback: if the library is missing or an entry point fails, the error is raised.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrgan_hip.so")
+
+
+class ConvDesc(ctypes.Structure):
+    """struct srgan_conv_desc"""
+    _fields_ = [("N", c_int), ("Hi", c_int), ("Wi", c_int), ("I", c_int),
+                ("Ho", c_int), ("Wo", c_int), ("O", c_int),
+                ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad", c_int),
+                ("pad_mode", c_int),
+                ("sO", c_longlong), ("sI", c_longlong), ("sH", c_longlong), ("sW", c_longlong)]
+
+
+P = c_void_p
+_DESC = POINTER(ConvDesc)
+
+# name -> (restype, argtypes); must list EVERY symbol include/srgan_hip.h declares
+SIGNATURES = {
+    "srgan_abi_version": (c_int, []),
+    "srgan_last_error": (ctypes.c_char_p, []),
+    "srgan_conv2d_workspace": (c_size_t, [_DESC]),
+    "srgan_conv2d_fwd": (c_int, [_DESC, P, P, P, P, c_int, c_float, P, c_size_t, P]),
+    "srgan_conv2d_dgrad": (c_int, [_DESC, P, P, P, P, c_size_t, P]),
+    "srgan_conv2d_wgrad": (c_int, [_DESC, P, P, P, P, P, c_size_t, P]),
+    "srgan_instnorm_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "srgan_instnorm_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_float, P, c_size_t, P]),
+    "srgan_instnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P]),
+    "srgan_cbin_affine_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "srgan_cbin_affine_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
+    "srgan_act_fwd": (c_int, [P, P, c_longlong, c_int, c_float, P]),
+    "srgan_act_bwd": (c_int, [P, P, P, c_longlong, c_int, c_float, P]),
+    "srgan_tanh_fwd": (c_int, [P, P, c_longlong, P]),
+    "srgan_tanh_bwd": (c_int, [P, P, P, c_longlong, P]),
+    "srgan_add": (c_int, [P, P, P, c_longlong, P]),
+    "srgan_avgpool3s2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srgan_avgpool3s2_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srgan_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srgan_avgpool2_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srgan_lrelu_gap_fwd": (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
+    "srgan_lrelu_gap_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),
+    "srgan_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "srgan_linear_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "srgan_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srgan_nhwc_to_nchw": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srgan_mse_const": (c_int, [P, c_longlong, c_float, c_float, P, P, P]),
+    "srgan_softmax_mse": (c_int, [P, P, c_int, c_int, c_float, P, P, P, P]),
+    "srgan_l1_workspace": (c_size_t, [c_longlong]),
+    "srgan_l1_mean": (c_int, [P, P, c_longlong, c_float, P, P, P, P, c_size_t, P]),
+    "srgan_latent_losses": (c_int, [P, c_int, c_int, c_float, P, c_int, c_float, c_float, c_float, c_float, c_float, P, P, P]),
+    "srgan_adam_step": (c_int, [P, P, P, P, c_longlong, c_float, c_float, c_float, c_float, c_int, P]),
+}
+
+_lib = None
+
+
+class SrganHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SrganHipError(
+            f"{LIB_PATH} not found: build it with `make -C style-restricted_gan_amd/csrc` "
+            "(or __graft_entry__.build()). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.srgan_abi_version() != 1:
+        raise SrganHipError("libsrgan_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().srgan_last_error().decode(errors="replace")
+        raise SrganHipError(f"{what} failed (code {code}): {msg}")

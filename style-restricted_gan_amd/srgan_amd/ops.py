@@ -1,0 +1,591 @@
+"""torch.autograd.Function wrappers over the C ABI of libsrgan_hip.so.
+
+PyTorch is used for device memory, streams and the autograd graph only; every forward and
+backward computation below is a hand-written gfx950 kernel reached through ctypes.
+
+Layout: 4-D activations are *NHWC-dense* tensors with logical NCHW shape (what PyTorch calls
+channels_last), so they interoperate with callers written against the reference's NCHW API.
+
+Stale-graph semantics: convolution / transposed-convolution weights
+are kept on the autograd context by reference and read when backward RUNS (torch 1.4 behaviour
+the reference's train step relies on, util_notebook.py:664-690); activations, norm statistics
+and the CBIN gamma copy are the forward-time values.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import ConvDesc
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+PAD_ZERO, PAD_REFLECT = 0, 1
+
+_workspaces = {}
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise _lib.SrganHipError(f"{what}: tensor is on {t.device}; srgan_amd runs on the MI355X HIP path only "
+                                 "(no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise _lib.SrganHipError(f"{what}: expected float32, got {t.dtype}")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def workspace(device, nbytes):
+    """Cached scratch buffer (per device); grown on demand, reused in stream order."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes * 1.25), 1 << 22), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def nhwc_empty(n, c, h, w, device):
+    return torch.empty((n, h, w, c), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+
+
+def is_nhwc_dense(t):
+    return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def to_nhwc(t):
+    """Return an NHWC-dense tensor with the same logical NCHW shape/values (HIP repack kernel)."""
+    if t.dim() != 4:
+        raise ValueError('expected 4D input (got {}D input)'.format(t.dim()))
+    _require_gpu(t, "to_nhwc")
+    if is_nhwc_dense(t):
+        return t
+    t = t.contiguous()
+    n, c, h, w = t.shape
+    out = nhwc_empty(n, c, h, w, t.device)
+    _lib.check(_lib.load().srgan_nchw_to_nhwc(_ptr(t), _ptr(out), n, c, h, w, _stream()), "nchw_to_nhwc")
+    return out
+
+
+def to_nchw(t):
+    """NCHW-contiguous copy of an NHWC-dense tensor (HIP repack kernel)."""
+    _require_gpu(t, "to_nchw")
+    if t.is_contiguous():
+        return t
+    t = to_nhwc(t)
+    n, c, h, w = t.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=t.device)
+    _lib.check(_lib.load().srgan_nhwc_to_nchw(_ptr(t), _ptr(out), n, c, h, w, _stream()), "nhwc_to_nchw")
+    return out
+
+
+def _dense2d(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------
+def _conv_desc(n, hi, wi, i, ho, wo, o, kh, kw, stride, pad, pad_mode, weight):
+    so, si, sh, sw = weight.stride()
+    return ConvDesc(n, hi, wi, i, ho, wo, o, kh, kw, stride, pad, pad_mode, so, si, sh, sw)
+
+
+def _conv_ws(desc, device):
+    lib = _lib.load()
+    nbytes = lib.srgan_conv2d_workspace(ctypes.byref(desc))
+    if nbytes == 0:
+        raise _lib.SrganHipError("conv2d: " + lib.srgan_last_error().decode())
+    return workspace(device, nbytes), nbytes
+
+
+def _run_conv_fwd(desc, x, weight, bias, y, act, slope):
+    ws, nb = _conv_ws(desc, x.device)
+    _lib.check(_lib.load().srgan_conv2d_fwd(ctypes.byref(desc), _ptr(x), _ptr(weight), _ptr(bias), _ptr(y), act,
+                                            float(slope), _ptr(ws), nb, _stream()), "conv2d_fwd")
+
+
+def _run_conv_dgrad(desc, dy, weight, dx):
+    ws, nb = _conv_ws(desc, dy.device)
+    _lib.check(_lib.load().srgan_conv2d_dgrad(ctypes.byref(desc), _ptr(dy), _ptr(weight), _ptr(dx), _ptr(ws), nb,
+                                              _stream()), "conv2d_dgrad")
+
+
+def _run_conv_wgrad(desc, x, dy, dw, dbias):
+    ws, nb = _conv_ws(desc, x.device)
+    _lib.check(_lib.load().srgan_conv2d_wgrad(ctypes.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias), _ptr(ws),
+                                              nb, _stream()), "conv2d_wgrad")
+
+
+def _act_bwd(y, gy, act, slope):
+    g = torch.empty_like(gy)
+    _lib.check(_lib.load().srgan_act_bwd(_ptr(y), _ptr(gy), _ptr(g), gy.numel(), act, float(slope), _stream()), "act_bwd")
+    return g
+
+
+class _Conv2dFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, pad_mode, act, slope):
+        x = to_nhwc(x)
+        _require_gpu(weight, "conv2d weight")
+        n, i, hi, wi = x.shape
+        o, i2, kh, kw = weight.shape
+        if i != i2:
+            raise _lib.SrganHipError(f"conv2d: input has {i} channels, weight expects {i2}")
+        ho = (hi + 2 * pad - kh) // stride + 1
+        wo = (wi + 2 * pad - kw) // stride + 1
+        desc = _conv_desc(n, hi, wi, i, ho, wo, o, kh, kw, stride, pad, pad_mode, weight)
+        y = nhwc_empty(n, o, ho, wo, x.device)
+        _run_conv_fwd(desc, x, weight, bias, y, act, slope)
+        ctx.desc, ctx.act, ctx.slope = desc, act, slope
+        ctx.weight = weight            # by reference: read at backward time (torch 1.4 semantics)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y = ctx.saved_tensors
+        gy = to_nhwc(gy)
+        if ctx.act != ACT_NONE:
+            gy = _act_bwd(y, gy, ctx.act, ctx.slope)
+        weight = ctx.weight
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _run_conv_dgrad(ctx.desc, gy, weight, dx)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
+            desc = ConvDesc.from_buffer_copy(ctx.desc)
+            desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
+            if ctx.has_bias:
+                db = torch.empty(weight.shape[0], dtype=torch.float32, device=weight.device)
+            _run_conv_wgrad(desc, x, gy, dw, db)
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0):
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, pad_mode, act, slope)
+
+
+class _ConvTranspose2dFn(Function):
+    """y = conv_transpose2d(x, w[Cin,Cout,kh,kw]): the input-gradient kernel of the conv C whose
+    weight is w viewed as [O=Cin][I=Cout]; backward = C forward (dx) and C's weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        x = to_nhwc(x)
+        _require_gpu(weight, "conv_transpose2d weight")
+        n, ci, hi, wi = x.shape
+        ci2, co, kh, kw = weight.shape
+        if ci != ci2:
+            raise _lib.SrganHipError(f"conv_transpose2d: input has {ci} channels, weight expects {ci2}")
+        ho = (hi - 1) * stride - 2 * pad + kh
+        wo = (wi - 1) * stride - 2 * pad + kw
+        # conv C: input = y-space [n,co,ho,wo], output = x-space [n,ci,hi,wi]
+        desc = _conv_desc(n, ho, wo, co, hi, wi, ci, kh, kw, stride, pad, PAD_ZERO, weight)
+        y = nhwc_empty(n, co, ho, wo, x.device)
+        _run_conv_dgrad(desc, x, weight, y)
+        ctx.desc, ctx.weight = desc, weight
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = to_nhwc(gy)
+        weight = ctx.weight
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _run_conv_fwd(ctx.desc, gy, weight, None, dx, ACT_NONE, 0.0)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
+            desc = ConvDesc.from_buffer_copy(ctx.desc)
+            desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
+            _run_conv_wgrad(desc, gy, x, dw, None)
+        return dx, dw, None, None
+
+
+def conv_transpose2d(x, weight, stride=2, padding=1):
+    return _ConvTranspose2dFn.apply(x, weight, stride, padding)
+
+
+# ------------------------------------------------------------------------------------------
+# instance norm (+affine, activation, residual) and the CBIN affine
+# ------------------------------------------------------------------------------------------
+class _InstNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift, res, act, slope, eps):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        lib = _lib.load()
+        if res is not None:
+            res = to_nhwc(res)
+        y = torch.empty_like(x)
+        mean = torch.empty(n * c, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        nb = lib.srgan_instnorm_workspace(n, h * w, c)
+        ws = workspace(x.device, nb)
+        _lib.check(lib.srgan_instnorm_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y), _ptr(mean), _ptr(rstd),
+                                          n, h * w, c, float(eps), act, float(slope), _ptr(ws), nb, _stream()),
+                   "instnorm_fwd")
+        ctx.act, ctx.slope, ctx.has_res = act, slope, res is not None
+        ctx.save_for_backward(x, scale, shift, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, scale, shift, mean, rstd = ctx.saved_tensors
+        gy = to_nhwc(gy)
+        n, c, h, w = x.shape
+        lib = _lib.load()
+        dx = torch.empty_like(x)
+        dscale = torch.empty(n, c, dtype=torch.float32, device=x.device)
+        dshift = torch.empty_like(dscale)
+        nb = lib.srgan_instnorm_workspace(n, h * w, c)
+        ws = workspace(x.device, nb)
+        _lib.check(lib.srgan_instnorm_bwd(_ptr(x), _ptr(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                          _ptr(dscale), _ptr(dshift), n, h * w, c, ctx.act, float(ctx.slope), _ptr(ws), nb,
+                                          _stream()), "instnorm_bwd")
+        has_aff = scale is not None
+        return (dx, dscale if has_aff else None, dshift if has_aff else None, gy if ctx.has_res else None,
+                None, None, None)
+
+
+def instance_norm_act(x, scale=None, shift=None, res=None, act=ACT_NONE, slope=0.0, eps=1e-5):
+    """act((x - mean)/sqrt(var+eps) * scale[n,c] + shift[n,c]) (+ res)."""
+    return _InstNormFn.apply(x, scale, shift, res, act, slope, eps)
+
+
+class _CbinAffineFn(Function):
+    @staticmethod
+    def forward(ctx, c, W, b, gamma, beta):
+        _require_gpu(c, "cbin condition vector")
+        c = _dense2d(c)
+        n, nc = c.shape
+        ch = W.shape[0]
+        t = torch.empty(n, ch, dtype=torch.float32, device=c.device)
+        scale = torch.empty_like(t)
+        shift = torch.empty_like(t)
+        _lib.check(_lib.load().srgan_cbin_affine_fwd(_ptr(c), _ptr(W), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(t),
+                                                     _ptr(scale), _ptr(shift), n, ch, nc, _stream()), "cbin_affine_fwd")
+        ctx.W = W                      # Linear weight: by reference (read at backward time)
+        ctx.save_for_backward(c, t, scale)
+        return scale, shift
+
+    @staticmethod
+    def backward(ctx, dscale, dshift):
+        c, t, scale = ctx.saved_tensors
+        W = ctx.W
+        n, nc = c.shape
+        ch = W.shape[0]
+        dev = c.device
+        if dscale is None:
+            dscale = torch.zeros(n, ch, dtype=torch.float32, device=dev)
+        if dshift is None:
+            dshift = torch.zeros(n, ch, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(ch, dtype=torch.float32, device=dev)
+        dbeta = torch.empty_like(dgamma)
+        dW = torch.empty(ch, nc, dtype=torch.float32, device=dev)
+        db = torch.empty_like(dgamma)
+        dc = torch.empty(n, nc, dtype=torch.float32, device=dev)
+        ws = workspace(dev, n * ch * 4)
+        # gamma as seen by the forward = row 0 of the saved scale (the reference multiplies by a
+        # repeat()-copy of gamma made at forward time, model.py:64)
+        _lib.check(_lib.load().srgan_cbin_affine_bwd(_ptr(c), _ptr(W), _ptr(scale), _ptr(t), _ptr(_dense2d(dscale)),
+                                                     _ptr(_dense2d(dshift)), _ptr(dgamma), _ptr(dbeta), _ptr(dW), _ptr(db),
+                                                     _ptr(dc), n, ch, nc, _ptr(ws), n * ch * 4, _stream()),
+                   "cbin_affine_bwd")
+        return dc, dW, db, dgamma, dbeta
+
+
+def cbin_affine(c, W, b, gamma, beta):
+    """-> (scale[N,C], shift[N,C]) with scale = gamma, shift = tanh(c W^T + b)*gamma + beta."""
+    return _CbinAffineFn.apply(c, W, b, gamma, beta)
+
+
+# ------------------------------------------------------------------------------------------
+# pointwise / pools / heads
+# ------------------------------------------------------------------------------------------
+class _TanhFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x, "tanh")
+        x = to_nhwc(x) if x.dim() == 4 else x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(_lib.load().srgan_tanh_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), "tanh_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        if y.dim() == 4:
+            gy = to_nhwc(gy)
+        dx = torch.empty_like(y)
+        _lib.check(_lib.load().srgan_tanh_bwd(_ptr(y), _ptr(gy), _ptr(dx), y.numel(), _stream()), "tanh_bwd")
+        return dx
+
+
+def tanh(x):
+    return _TanhFn.apply(x)
+
+
+class _ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        _require_gpu(x, "activation")
+        x = to_nhwc(x) if x.dim() == 4 else x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(_lib.load().srgan_act_fwd(_ptr(x), _ptr(y), x.numel(), act, float(slope), _stream()), "act_fwd")
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        if y.dim() == 4:
+            gy = to_nhwc(gy)
+        return _act_bwd(y, gy, ctx.act, ctx.slope), None, None
+
+
+def activation(x, act, slope=0.0):
+    return _ActFn.apply(x, act, slope)
+
+
+class _AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = to_nhwc(a), to_nhwc(b)
+        y = torch.empty_like(a)
+        _lib.check(_lib.load().srgan_add(_ptr(a), _ptr(b), _ptr(y), a.numel(), _stream()), "add")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy, gy
+
+
+def add(a, b):
+    return _AddFn.apply(a, b)
+
+
+def _pool_fn(fwd_name, bwd_name, out_hw):
+    class _Pool(Function):
+        @staticmethod
+        def forward(ctx, x):
+            x = to_nhwc(x)
+            n, c, h, w = x.shape
+            ho, wo = out_hw(h, w)
+            y = nhwc_empty(n, c, ho, wo, x.device)
+            _lib.check(getattr(_lib.load(), fwd_name)(_ptr(x), _ptr(y), n, h, w, c, _stream()), fwd_name)
+            ctx.shape = (n, c, h, w)
+            return y
+
+        @staticmethod
+        def backward(ctx, gy):
+            n, c, h, w = ctx.shape
+            gy = to_nhwc(gy)
+            dx = nhwc_empty(n, c, h, w, gy.device)
+            _lib.check(getattr(_lib.load(), bwd_name)(_ptr(gy), _ptr(dx), n, h, w, c, _stream()), bwd_name)
+            return dx
+    return _Pool
+
+
+_AvgPool3s2 = _pool_fn("srgan_avgpool3s2_fwd", "srgan_avgpool3s2_bwd", lambda h, w: ((h - 1) // 2 + 1, (w - 1) // 2 + 1))
+_AvgPool2 = _pool_fn("srgan_avgpool2_fwd", "srgan_avgpool2_bwd", lambda h, w: (h // 2, w // 2))
+
+
+def avgpool3s2(x):
+    """AvgPool2d(3, stride=2, padding=1, count_include_pad=False)."""
+    return _AvgPool3s2.apply(x)
+
+
+def avgpool2(x):
+    """AvgPool2d(2, 2)."""
+    return _AvgPool2.apply(x)
+
+
+class _LreluGapFn(Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = torch.empty(n, c, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().srgan_lrelu_gap_fwd(_ptr(x), _ptr(y), n, h * w, c, float(slope), _stream()), "lrelu_gap_fwd")
+        ctx.slope = slope
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        _lib.check(_lib.load().srgan_lrelu_gap_bwd(_ptr(x), _ptr(_dense2d(gy)), _ptr(dx), n, h * w, c, float(ctx.slope),
+                                                   _stream()), "lrelu_gap_bwd")
+        return dx, None
+
+
+def lrelu_global_avgpool(x, slope):
+    """LeakyReLU(slope) followed by AdaptiveAvgPool2d(1), flattened to [N, C]."""
+    return _LreluGapFn.apply(x, slope)
+
+
+class _LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, W, b):
+        _require_gpu(x, "linear")
+        x = _dense2d(x)
+        m, k = x.shape
+        n = W.shape[0]
+        y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().srgan_linear_fwd(_ptr(x), _ptr(W), _ptr(b), _ptr(y), m, n, k, _stream()), "linear_fwd")
+        ctx.W, ctx.has_bias = W, b is not None
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        W = ctx.W
+        m, k = x.shape
+        n = W.shape[0]
+        gy = _dense2d(gy)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dW = torch.empty(n, k, dtype=torch.float32, device=x.device) if need_w else None
+        db = torch.empty(n, dtype=torch.float32, device=x.device) if (need_w and ctx.has_bias) else None
+        _lib.check(_lib.load().srgan_linear_bwd(_ptr(x), _ptr(W), _ptr(gy), _ptr(dx), _ptr(dW), _ptr(db), m, n, k, _stream()),
+                   "linear_bwd")
+        return dx, dW, db
+
+
+def linear(x, W, b=None):
+    return _LinearFn.apply(x, W, b)
+
+
+# ------------------------------------------------------------------------------------------
+# fused losses (value + gradient in one launch)
+# ------------------------------------------------------------------------------------------
+class _MseConstFn(Function):
+    @staticmethod
+    def forward(ctx, o, target, weight):
+        _require_gpu(o, "mse_const")
+        o = o if (o.is_contiguous() or is_nhwc_dense(o)) else o.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=o.device)
+        d_o = torch.empty_like(o)
+        _lib.check(_lib.load().srgan_mse_const(_ptr(o), o.numel(), float(target), float(weight), _ptr(loss), _ptr(d_o),
+                                               _stream()), "mse_const")
+        ctx.save_for_backward(d_o)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_o,) = ctx.saved_tensors
+        return d_o * g, None, None
+
+
+def mse_const(o, target, weight=1.0):
+    """weight * mean((o - target)^2)."""
+    return _MseConstFn.apply(o, target, weight)
+
+
+class _SoftmaxMseFn(Function):
+    @staticmethod
+    def forward(ctx, z, label, weight):
+        _require_gpu(z, "softmax_mse")
+        z = _dense2d(z)
+        b, nc = z.shape
+        label = label.to(device=z.device, dtype=torch.int64).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=z.device)
+        q = torch.empty_like(z)
+        dz = torch.empty_like(z)
+        _lib.check(_lib.load().srgan_softmax_mse(_ptr(z), _ptr(label), b, nc, float(weight), _ptr(q), _ptr(loss), _ptr(dz),
+                                                 _stream()), "softmax_mse")
+        ctx.save_for_backward(dz)
+        ctx.mark_non_differentiable(q)
+        return loss, q
+
+    @staticmethod
+    def backward(ctx, g, _gq):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None, None
+
+
+def softmax_mse(z, label, weight=1.0):
+    """-> (weight * mean((softmax(z) - onehot(label))^2), softmax(z))."""
+    return _SoftmaxMseFn.apply(z, label, weight)
+
+
+class _L1MeanFn(Function):
+    @staticmethod
+    def forward(ctx, a, b, weight):
+        _require_gpu(a, "l1_mean")
+        if a.dim() == 4:
+            a, b = to_nhwc(a), to_nhwc(b)
+        else:
+            a, b = a.contiguous(), b.contiguous()
+        lib = _lib.load()
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        da = torch.empty_like(a) if need_a else None
+        db = torch.empty_like(b) if need_b else None
+        nb = lib.srgan_l1_workspace(a.numel())
+        ws = workspace(a.device, nb)
+        _lib.check(lib.srgan_l1_mean(_ptr(a), _ptr(b), a.numel(), float(weight), _ptr(loss), _ptr(da), _ptr(db), _ptr(ws),
+                                     nb, _stream()), "l1_mean")
+        ctx.save_for_backward(da, db)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        da, db = ctx.saved_tensors
+        return (da * g if da is not None else None, db * g if db is not None else None, None)
+
+
+def l1_mean(a, b, weight=1.0):
+    """weight * mean(|a - b|)."""
+    return _L1MeanFn.apply(a, b, weight)
+
+
+class _LatentLossFn(Function):
+    @staticmethod
+    def forward(ctx, mu, n_batch, target, bins, range_max, sigma, w_bkl, w_corr, w_hist):
+        _require_gpu(mu, "latent_losses")
+        mu = _dense2d(mu)
+        b, d = mu.shape
+        vals = torch.empty(4, dtype=torch.float32, device=mu.device)
+        dmu = torch.empty_like(mu)
+        _lib.check(_lib.load().srgan_latent_losses(_ptr(mu), b, d, float(n_batch), _ptr(target), bins, float(range_max),
+                                                   float(sigma), float(w_bkl), float(w_corr), float(w_hist), _ptr(vals),
+                                                   _ptr(dmu), _stream()), "latent_losses")
+        ctx.save_for_backward(dmu)
+        total, parts = vals[3], vals[:3]
+        ctx.mark_non_differentiable(parts)
+        return total, parts
+
+    @staticmethod
+    def backward(ctx, g, _gp):
+        (dmu,) = ctx.saved_tensors
+        return (dmu * g,) + (None,) * 8
+
+
+def latent_losses(mu, n_batch, hist_target, w_bkl, w_corr, w_hist, bins=50, range_max=10.0, sigma=0.2):
+    """-> (w_bkl*bKL + w_corr*corr + w_hist*hist, tensor([bKL, corr, hist]))."""
+    return _LatentLossFn.apply(mu, n_batch, hist_target, bins, range_max, sigma, w_bkl, w_corr, w_hist)
+
+
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
+    """In-place torch-1.4 Adam on dense buffers, through raw pointers (no autograd version bump)."""
+    _require_gpu(p, "adam")
+    _lib.check(_lib.load().srgan_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
+                                           float(beta2), float(eps), int(step), _stream()), "adam_step")

@@ -1,0 +1,301 @@
+"""GPU: every HIP op of libsrgan_hip.so (through the C ABI / ctypes) against a PyTorch-CPU fp32/fp64
+restatement of the same op.  Tolerance: 2e-5 relative to the tensor's max magnitude for fp32 kernels
+(exact-fp32 MFMA, different summation order), stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from srgan_amd import ops as _ops
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def close(a, b, rtol=2e-5, atol=1e-6):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(float(b.abs().max()), 1e-30)
+    err = float((a - b).abs().max())
+    assert err <= atol + rtol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+CONV_CASES = [
+    # N, I, H, W, O, k, s, p, reflect, bias
+    (2, 3, 20, 20, 8, 7, 1, 3, False, False),     # G first layer shape class (Cin=3)
+    (2, 64, 16, 16, 128, 4, 2, 1, False, False),  # k4 s2 down conv (vector path)
+    (2, 32, 12, 12, 64, 3, 1, 1, False, False),   # 3x3 residual conv class
+    (1, 256, 8, 8, 256, 3, 1, 1, False, False),   # exact G res conv channels
+    (2, 64, 14, 14, 3, 7, 1, 3, False, False),    # G last layer (Cout=3)
+    (2, 3, 32, 32, 64, 4, 2, 1, False, False),    # D first layer
+    (3, 128, 8, 8, 1, 4, 1, 1, False, True),      # D last_layer (Cout=1, bias)
+    (3, 64, 8, 8, 4, 8, 1, 0, False, True),       # D classification head (valid 8x8)
+    (2, 3, 33, 33, 16, 7, 2, 1, False, True),     # E first layer (k7 s2 p1, odd sizes)
+    (2, 32, 9, 9, 64, 3, 1, 1, True, False),      # E reflect conv (vector path)
+    (2, 4, 7, 7, 8, 3, 1, 1, True, False),        # reflect, generic-channel path
+    (2, 8, 3, 3, 16, 3, 1, 1, True, False),       # reflect on a 3x3 map (both mirrors hit row 1)
+    (2, 32, 6, 6, 64, 1, 1, 0, False, True),      # 1x1 shortcut with bias
+    (1, 16, 10, 10, 32, 4, 2, 1, False, False),   # generic channels, stride 2
+    (2, 160, 6, 6, 96, 3, 1, 1, False, False),    # non power-of-two channels (vector path, N mask)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(ops, case):
+    n, i, h, w, o, k, s, p, reflect, has_bias = case
+    x = rnd(n, i, h, w, seed=1).requires_grad_(True)
+    wt = (rnd(o, i, k, k, seed=2) / np.sqrt(i * k * k)).requires_grad_(True)
+    b = (rnd(o, seed=3) * 0.1).requires_grad_(True) if has_bias else None
+    if reflect:
+        yr = F.conv2d(F.pad(x, (p, p, p, p), mode="reflect"), wt, b, s, 0)
+    else:
+        yr = F.conv2d(x, wt, b, s, p)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+
+    xd = x.detach().cuda().requires_grad_(True)
+    wd = wt.detach().cuda().requires_grad_(True)
+    bd = b.detach().cuda().requires_grad_(True) if has_bias else None
+    y = ops.conv2d(xd, wd, bd, s, p, ops.PAD_REFLECT if reflect else ops.PAD_ZERO)
+    assert ops.is_nhwc_dense(y)
+    y.backward(gy.cuda())
+    close(y, yr)
+    close(xd.grad, x.grad)
+    close(wd.grad, wt.grad, 5e-5)
+    if has_bias:
+        close(bd.grad, b.grad, 5e-5)
+
+
+def test_conv2d_fused_leaky_relu(ops):
+    x = rnd(2, 32, 10, 10, seed=1).requires_grad_(True)
+    wt = (rnd(64, 32, 4, 4, seed=2) / 20).requires_grad_(True)
+    yr = F.leaky_relu(F.conv2d(x, wt, None, 2, 1), 0.01)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+    xd, wd = x.detach().cuda().requires_grad_(True), wt.detach().cuda().requires_grad_(True)
+    y = ops.conv2d(xd, wd, None, 2, 1, ops.PAD_ZERO, ops.ACT_LRELU, 0.01)
+    y.backward(gy.cuda())
+    close(y, yr)
+    close(xd.grad, x.grad)
+    close(wd.grad, wt.grad, 5e-5)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 8, 8, 32), (2, 8, 5, 5, 4), (1, 256, 4, 4, 128)])
+def test_conv_transpose2d(ops, case):
+    n, ci, h, w, co = case
+    x = rnd(n, ci, h, w, seed=1).requires_grad_(True)
+    wt = (rnd(ci, co, 4, 4, seed=2) / np.sqrt(ci * 4)).requires_grad_(True)
+    yr = F.conv_transpose2d(x, wt, None, 2, 1)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+    xd, wd = x.detach().cuda().requires_grad_(True), wt.detach().cuda().requires_grad_(True)
+    y = ops.conv_transpose2d(xd, wd, 2, 1)
+    y.backward(gy.cuda())
+    close(y, yr)
+    close(xd.grad, x.grad)
+    close(wd.grad, wt.grad, 5e-5)
+
+
+def test_conv_weight_read_at_backward_time(ops):
+    """torch-1.4 stale-graph semantics: dgrad uses the weights as they are when backward runs."""
+    x = rnd(1, 32, 6, 6, seed=1).cuda().requires_grad_(True)
+    w = (rnd(32, 32, 3, 3, seed=2) / 17).cuda().requires_grad_(True)
+    y = ops.conv2d(x, w, None, 1, 1)
+    w_new = rnd(32, 32, 3, 3, seed=9) / 17
+    w.data.copy_(w_new.cuda())            # what the fused Adam does through raw pointers
+    gy = rnd(*y.shape, seed=3)
+    y.backward(gy.cuda())
+    ref = torch.nn.grad.conv2d_input(x.shape, w_new, gy, 1, 1)
+    close(x.grad, ref)
+
+
+@pytest.mark.parametrize("shape,act", [((2, 16, 9, 9), 1), ((3, 64, 16, 16), 0), ((2, 8, 31, 31), 2), ((2, 6, 5, 5), 1)])
+@pytest.mark.parametrize("affine", [False, True])
+def test_instance_norm_act(ops, shape, act, affine):
+    n, c, h, w = shape
+    x = (rnd(*shape, seed=1) * 2 + 0.5).requires_grad_(True)
+    res = rnd(*shape, seed=5).requires_grad_(True)
+    sc = (1 + 0.3 * rnd(n, c, seed=2)).requires_grad_(True) if affine else None
+    sh = (0.5 * rnd(n, c, seed=3)).requires_grad_(True) if affine else None
+    xh = F.instance_norm(x, eps=1e-5)
+    z = xh * sc[:, :, None, None] + sh[:, :, None, None] if affine else xh
+    z = {0: z, 1: torch.relu(z), 2: F.leaky_relu(z, 0.2)}[act]
+    yr = z + res
+    gy = rnd(*shape, seed=4)
+    yr.backward(gy)
+    xd = x.detach().cuda().requires_grad_(True)
+    rd = res.detach().cuda().requires_grad_(True)
+    scd = sc.detach().cuda().requires_grad_(True) if affine else None
+    shd = sh.detach().cuda().requires_grad_(True) if affine else None
+    y = ops.instance_norm_act(xd, scd, shd, rd, act, 0.2)
+    y.backward(gy.cuda())
+    close(y, yr, 2e-5)
+    close(xd.grad, x.grad, 1e-4)
+    close(rd.grad, res.grad)
+    if affine:
+        close(scd.grad, sc.grad, 1e-4)
+        close(shd.grad, sh.grad, 1e-4)
+
+
+def test_cbin_affine(ops):
+    n, ch, nc = 5, 24, 12
+    c = rnd(n, nc, seed=1).requires_grad_(True)
+    W = (rnd(ch, nc, seed=2) * 0.3).requires_grad_(True)
+    b = (rnd(ch, seed=3) * 0.1).requires_grad_(True)
+    gam = (1 + 0.2 * rnd(ch, seed=4)).requires_grad_(True)
+    bet = (0.1 * rnd(ch, seed=5)).requires_grad_(True)
+    t = torch.tanh(F.linear(c, W, b))
+    scale_r = gam[None, :].expand(n, ch)
+    shift_r = t * gam + bet
+    g1, g2 = rnd(n, ch, seed=6), rnd(n, ch, seed=7)
+    ((scale_r * g1).sum() + (shift_r * g2).sum()).backward()
+    dev = [v.detach().cuda().requires_grad_(True) for v in (c, W, b, gam, bet)]
+    scale, shift = ops.cbin_affine(*dev)
+    ((scale * g1.cuda()).sum() + (shift * g2.cuda()).sum()).backward()
+    close(scale, scale_r)
+    close(shift, shift_r)
+    for d, r in zip(dev, (c, W, b, gam, bet)):
+        close(d.grad, r.grad, 5e-5)
+
+
+def test_pools_and_heads(ops):
+    x = rnd(2, 8, 13, 13, seed=1).requires_grad_(True)
+    gy = None
+    for name, ref in (("avgpool3s2", lambda t: F.avg_pool2d(t, 3, 2, 1, count_include_pad=False)),
+                      ("avgpool2", lambda t: F.avg_pool2d(t, 2, 2))):
+        x.grad = None
+        yr = ref(x)
+        gy = rnd(*yr.shape, seed=2)
+        yr.backward(gy)
+        xd = x.detach().cuda().requires_grad_(True)
+        y = getattr(ops, name)(xd)
+        y.backward(gy.cuda())
+        close(y, yr)
+        close(xd.grad, x.grad)
+    # even sizes too (the D input is 128x128)
+    x2 = rnd(1, 3, 16, 16, seed=3)
+    close(ops.avgpool3s2(x2.cuda()), F.avg_pool2d(x2, 3, 2, 1, count_include_pad=False))
+    # LeakyReLU + global average pool
+    x.grad = None
+    yr = F.leaky_relu(x, 0.2).mean(dim=(2, 3))
+    g = rnd(*yr.shape, seed=4)
+    yr.backward(g)
+    xd = x.detach().cuda().requires_grad_(True)
+    y = ops.lrelu_global_avgpool(xd, 0.2)
+    y.backward(g.cuda())
+    close(y, yr)
+    close(xd.grad, x.grad)
+    # linear
+    a = rnd(6, 1024, seed=5).requires_grad_(True)
+    W = (rnd(8, 1024, seed=6) / 32).requires_grad_(True)
+    b = rnd(8, seed=7).requires_grad_(True)
+    yr = F.linear(a, W, b)
+    g = rnd(*yr.shape, seed=8)
+    yr.backward(g)
+    dev = [v.detach().cuda().requires_grad_(True) for v in (a, W, b)]
+    y = ops.linear(*dev)
+    y.backward(g.cuda())
+    close(y, yr)
+    for d, r in zip(dev, (a, W, b)):
+        close(d.grad, r.grad, 5e-5)
+    # tanh / activation / add
+    t = rnd(2, 3, 8, 8, seed=9).requires_grad_(True)
+    yr = torch.tanh(t)
+    g = rnd(*yr.shape, seed=10)
+    yr.backward(g)
+    td = t.detach().cuda().requires_grad_(True)
+    y = ops.tanh(td)
+    y.backward(g.cuda())
+    close(y, yr)
+    close(td.grad, t.grad)
+    u, v = rnd(2, 4, 5, 5, seed=11), rnd(2, 4, 5, 5, seed=12)
+    close(ops.add(u.cuda(), v.cuda()), u + v)
+    close(ops.activation(u.cuda(), ops.ACT_LRELU, 0.2), F.leaky_relu(u, 0.2))
+
+
+def test_layout_round_trip(ops):
+    x = rnd(3, 5, 7, 9, seed=1)
+    xd = ops.to_nhwc(x.cuda())
+    assert ops.is_nhwc_dense(xd)
+    close(xd, x, 0, 0)
+    close(ops.to_nchw(xd), x, 0, 0)
+    assert ops.to_nchw(xd).is_contiguous()
+    with pytest.raises(ValueError, match="expected 4D input"):
+        ops.to_nhwc(torch.zeros(3, 4).cuda())
+
+
+def test_losses(ops, golden_dir):
+    import os
+    gold = np.load(os.path.join(golden_dir, "losses.npz"))
+    # LSGAN / class MSE against the reference's own numbers
+    o1, o2 = torch.from_numpy(gold["ls_o1"]), torch.from_numpy(gold["ls_o2"])
+    for tgt, idx in ((1.0, 0), (0.0, 1)):
+        v = ops.mse_const(o1.cuda(), tgt, 0.5) + ops.mse_const(o2.cuda(), tgt, 0.5)
+        assert abs(float(v) - gold["ls_vals"][idx]) < 1e-5 * max(1, abs(gold["ls_vals"][idx]))
+    od = o1.cuda().requires_grad_(True)
+    ops.mse_const(od, 1.0, 0.5).backward()
+    close(od.grad, 0.5 * 2 * (o1 - 1.0) / o1.numel())
+    # softmax + MSE: logits whose softmax is the golden q
+    z = torch.from_numpy(gold["ls_q1"]).log().requires_grad_(True)
+    lab = torch.from_numpy(gold["ls_lab"])
+    q = torch.softmax(z, 1)
+    lr = ((q - F.one_hot(lab, 4).float()) ** 2).mean() * 0.7
+    lr.backward()
+    zd = z.detach().cuda().requires_grad_(True)
+    l, qd = ops.softmax_mse(zd, lab, 0.7)
+    l.backward()
+    close(l, lr, 1e-5)
+    close(qd, q, 1e-5)
+    close(zd.grad, z.grad, 1e-4)
+    # L1
+    a, b = rnd(2, 3, 16, 16, seed=1).requires_grad_(True), rnd(2, 3, 16, 16, seed=2).requires_grad_(True)
+    lr = (a - b).abs().mean() * 5.0
+    lr.backward()
+    ad, bd = a.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    l = ops.l1_mean(ad, bd, 5.0)
+    l.backward()
+    close(l, lr, 1e-5)
+    close(ad.grad, a.grad)
+    close(bd.grad, b.grad)
+    # latent losses vs the reference's values and autograd gradients
+    tgt = torch.from_numpy(gold["hist_target_seed0"]).cuda()
+    for name in ("randn1234", "sin"):
+        mu = torch.from_numpy(gold[f"{name}_mu"]).cuda().requires_grad_(True)
+        total, parts = ops.latent_losses(mu, 32, tgt, 10.0, 100.0, 100.0)
+        total.backward()
+        ref = gold[f"{name}_vals"]
+        np.testing.assert_allclose(parts.cpu().numpy(), ref, rtol=2e-4)
+        assert abs(float(total) - (10 * ref[0] + 100 * ref[1] + 100 * ref[2])) < 2e-4 * abs(float(total))
+        gref = 10 * gold[f"{name}_dbkl"] + 100 * gold[f"{name}_dcorr"] + 100 * gold[f"{name}_dhist"]
+        close(mu.grad, torch.from_numpy(gref), 5e-4)
+
+
+def test_adam_matches_torch14_math(ops):
+    from oracle.trainer import Adam14
+    p = rnd(1000, seed=1)
+    ref = p.clone().requires_grad_(True)
+    opt = Adam14([ref], lr=1e-3)
+    pd = p.cuda()
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    for step in range(1, 4):
+        g = rnd(1000, seed=10 + step)
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam_step_(pd, g.cuda(), m, v, 1e-3, 0.5, 0.999, 1e-8, step)
+    close(pd, ref, 1e-6)
+
+
+def test_no_cpu_fallback(ops):
+    from srgan_amd._lib import SrganHipError
+    with pytest.raises(SrganHipError):
+        ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))
