@@ -135,7 +135,16 @@ int srgan_l1_mean(const float* a, const float* b, long long n, float weight, flo
  * hist_target: [bins] device floats.  d <= 16, bins <= 64, B <= 4096. */
 int srgan_latent_losses(const float* mu, int B, int d, float n_batch, const float* hist_target, int bins,
                         float range_max, float sigma, float w_bkl, float w_corr, float w_hist,
-                        float* vals, float* dmu, void* stream);
+                        float* vals, float* dmu, float* corr_out /* [d*d] Pearson matrix or NULL */, void* stream);
+/* generic nn.MSELoss(a, b) * weight with both gradients (get_domainloss_D on probabilities, util.py:464-468) */
+int srgan_mse_pair(const float* a, const float* b, long long n, float weight, float* loss, float* da, float* db,
+                   void* stream);
+/* GaussianHistogram.forward (util.py:521-537) of a 1-D sample x[n] -> h[bins], and its vector-Jacobian product */
+size_t srgan_soft_histogram_workspace(long long n, int bins);
+int srgan_soft_histogram_fwd(const float* x, long long n, int bins, float lo, float hi, float sigma, float* h,
+                             void* ws, size_t ws_bytes, void* stream);
+int srgan_soft_histogram_bwd(const float* x, const float* g, long long n, int bins, float lo, float hi, float sigma,
+                             float* dx, void* stream);
 
 /* optim.Adam.step, torch 1.4 arithmetic (util_notebook.py:500-506) on flat buffers.
  * step_count is the 1-based step number t.  Writes through raw pointers (no autograd version bump). */

@@ -78,13 +78,68 @@ __global__ void l1_final_kernel(const float* part, int nparts, float scale, floa
   if (threadIdx.x == 0) loss[0] = s * scale;
 }
 
+// mean((a-b)^2) * weight between two tensors (generic nn.MSELoss(a, b)); single block (small inputs)
+__global__ __launch_bounds__(256) void mse_pair_kernel(const float* a, const float* b, long long n, float weight,
+                                                       float* loss, float* da, float* db) {
+  __shared__ float red[16];
+  float s = 0.f;
+  const float gscale = 2.f * weight / (float)n;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float d = a[i] - b[i];
+    s += d * d;
+    if (da) da[i] = gscale * d;
+    if (db) db[i] = -gscale * d;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) loss[0] = weight * s / (float)n;
+}
+
+// GaussianHistogram.forward (util.py:532-537) for a long 1-D sample: part[block][bin], then summed.
+__global__ __launch_bounds__(256) void soft_hist_partial_kernel(const float* x, long long n, int bins, float lo,
+                                                                float delta, float sigma, float* part) {
+  __shared__ float red[16];
+  const float knorm = delta / (sigma * 2.5066282746310002f);
+  const float inv2s2 = 0.5f / (sigma * sigma);
+  for (int k = 0; k < bins; ++k) {
+    const float ck = lo + delta * ((float)k + 0.5f);
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+      const float d = x[i] - ck;
+      s += expf(-d * d * inv2s2);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * bins + k] = s * knorm;
+  }
+}
+__global__ void soft_hist_final_kernel(const float* part, int nparts, int bins, float* h) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= bins) return;
+  float s = 0.f;
+  for (int i = 0; i < nparts; ++i) s += part[(size_t)i * bins + k];
+  h[k] = s;
+}
+// dx_i = sum_k g_k * dh_k/dx_i
+__global__ void soft_hist_bwd_kernel(const float* x, const float* g, long long n, int bins, float lo, float delta,
+                                     float sigma, float* dx) {
+  const float knorm = delta / (sigma * 2.5066282746310002f);
+  const float inv2s2 = 0.5f / (sigma * sigma), invs2 = 1.f / (sigma * sigma);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < bins; ++k) {
+      const float d = x[i] - (lo + delta * ((float)k + 0.5f));
+      s += g[k] * (-knorm * expf(-d * d * inv2s2) * d * invs2);
+    }
+    dx[i] = s;
+  }
+}
+
 // ---- latent losses: one workgroup, mu staged in LDS ---------------------------------------
 constexpr int LAT_MAX_D = 16, LAT_MAX_BINS = 64, LAT_MAX_ELEMS = 16384;
 
 __global__ __launch_bounds__(256) void latent_losses_kernel(const float* mu_g, int B, int d, float n_batch,
                                                             const float* target, int bins, float range_max, float sigma,
                                                             float w_bkl, float w_corr, float w_hist, float* vals,
-                                                            float* dmu) {
+                                                            float* dmu, float* corr_out) {
   extern __shared__ float smem[];
   float* mu = smem;                        // [B][d]
   float* mean = mu + B * d;                // [d]
@@ -138,6 +193,7 @@ __global__ __launch_bounds__(256) void latent_losses_kernel(const float* mu_g, i
         const bool clamped = r > 1.f || r < -1.f;
         r = fminf(1.f, fmaxf(-1.f, r));
         R[a][b] = r;
+        if (corr_out) corr_out[a * d + b] = r;
         const float e = r - (a == b ? 1.f : 0.f);
         L += fabsf(e);
         float g = e > 0.f ? norm : (e < 0.f ? -norm : 0.f);
@@ -255,12 +311,45 @@ extern "C" int srgan_l1_mean(const float* a, const float* b, long long n, float 
 
 extern "C" int srgan_latent_losses(const float* mu, int B, int d, float n_batch, const float* hist_target, int bins,
                                    float range_max, float sigma, float w_bkl, float w_corr, float w_hist, float* vals,
-                                   float* dmu, void* stream) {
+                                   float* dmu, float* corr_out, void* stream) {
   SRGAN_REQUIRE(mu && hist_target && vals, "latent_losses: null pointer");
   SRGAN_REQUIRE(B >= 2 && d >= 2 && d <= LAT_MAX_D && bins >= 1 && bins <= LAT_MAX_BINS && (long long)B * d <= LAT_MAX_ELEMS,
                 "latent_losses: need 2<=B, 2<=d<=16, bins<=64, B*d<=16384");
   const size_t shmem = ((size_t)B * d + 2 * LAT_MAX_D + 2 * LAT_MAX_D * LAT_MAX_D + 2 * LAT_MAX_D * LAT_MAX_BINS + 64) * sizeof(float);
   hipLaunchKernelGGL(latent_losses_kernel, dim3(1), dim3(256), shmem, as_stream(stream), mu, B, d, n_batch, hist_target, bins,
-                     range_max, sigma, w_bkl, w_corr, w_hist, vals, dmu);
+                     range_max, sigma, w_bkl, w_corr, w_hist, vals, dmu, corr_out);
   return check_launch("latent_losses_kernel");
+}
+
+extern "C" int srgan_mse_pair(const float* a, const float* b, long long n, float weight, float* loss, float* da, float* db,
+                              void* stream) {
+  SRGAN_REQUIRE(a && b && loss && n > 0, "mse_pair: bad argument");
+  hipLaunchKernelGGL(mse_pair_kernel, dim3(1), dim3(256), 0, as_stream(stream), a, b, n, weight, loss, da, db);
+  return check_launch("mse_pair_kernel");
+}
+
+extern "C" size_t srgan_soft_histogram_workspace(long long n, int bins) {
+  (void)n;
+  return (size_t)256 * bins * sizeof(float);
+}
+
+extern "C" int srgan_soft_histogram_fwd(const float* x, long long n, int bins, float lo, float hi, float sigma, float* h,
+                                        void* ws, size_t ws_bytes, void* stream) {
+  SRGAN_REQUIRE(x && h && n > 0 && bins > 0 && hi > lo && sigma > 0.f, "soft_histogram_fwd: bad argument");
+  SRGAN_REQUIRE(ws && ws_bytes >= (size_t)256 * bins * sizeof(float), "soft_histogram_fwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int blocks = (int)std::max<long long>(1, std::min<long long>(256, ceil_div(n, 256)));
+  const float delta = (hi - lo) / (float)bins;
+  hipLaunchKernelGGL(soft_hist_partial_kernel, dim3(blocks), dim3(256), 0, st, x, n, bins, lo, delta, sigma, (float*)ws);
+  hipLaunchKernelGGL(soft_hist_final_kernel, dim3((bins + 63) / 64), dim3(64), 0, st, (const float*)ws, blocks, bins, h);
+  return check_launch("soft_histogram_fwd");
+}
+
+extern "C" int srgan_soft_histogram_bwd(const float* x, const float* g, long long n, int bins, float lo, float hi, float sigma,
+                                        float* dx, void* stream) {
+  SRGAN_REQUIRE(x && g && dx && n > 0 && bins > 0 && hi > lo && sigma > 0.f, "soft_histogram_bwd: bad argument");
+  const float delta = (hi - lo) / (float)bins;
+  const int blocks = (int)std::max<long long>(1, std::min<long long>(1024, ceil_div(n, 256)));
+  hipLaunchKernelGGL(soft_hist_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, g, n, bins, lo, delta, sigma, dx);
+  return check_launch("soft_histogram_bwd");
 }

@@ -1,0 +1,485 @@
+"""nn.Module surface of the reference's ``pyfiles/model.py`` over the gfx950 HIP kernels.
+
+Same class names, constructor signatures, forward signatures / return structures and
+``state_dict()`` keys, shapes and dtypes as the reference, so that
+``05-train_Style-Restricted_GAN.ipynb``'s construction code and ``.pth`` checkpoints carry over.
+torch.nn containers (nn.Conv2d, nn.Linear, ...) are used only as PARAMETER HOLDERS -- this keeps the
+key names and PyTorch's default initialisation (the reference's ``weights_init`` is a no-op,
+util.py:193-203) -- every ``forward`` below dispatches to hand-written kernels via ``srgan_amd.ops``.
+Modules are built in the reference's construction order so that a given ``torch.manual_seed``
+yields the same initial weights.
+
+4-D activations returned by these modules are NHWC-dense tensors with logical NCHW shape.
+"""
+import functools
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, PAD_REFLECT, PAD_ZERO
+
+__all__ = ["CBINorm2d", "get_norm_layer", "SingleResidualBlock", "SingleGenerator",
+           "SingleDiscriminator_original", "SingleDiscriminator_original_multi", "SingleDiscriminator_solo",
+           "SingleDiscriminator_solo_multi", "BasicBlock", "Encoder_original", "BasicBlock_classification",
+           "Encoder", "Encoder_classifier", "MinMax"]
+
+D_SLOPE = 0.01   # nn.LeakyReLU() default in the discriminators   (model.py:263,303)
+E_SLOPE = 0.2    # nn.LeakyReLU(0.2) in the encoders               (model.py:357,418,454)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter holders with HIP forwards
+# ------------------------------------------------------------------------------------------------
+class _Conv2d(nn.Conv2d):
+    """nn.Conv2d parameters; forward = implicit-GEMM MFMA kernel (optionally fused LeakyReLU)."""
+
+    def forward(self, x, act=ACT_NONE, slope=0.0):
+        mode = PAD_REFLECT if self.padding_mode == "reflect" else PAD_ZERO
+        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], mode, act, slope)
+
+
+class _ConvTranspose2d(nn.ConvTranspose2d):
+    def forward(self, x):
+        return ops.conv_transpose2d(x, self.weight, self.stride[0], self.padding[0])
+
+
+class _Linear(nn.Linear):
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class _LeakyReLU(nn.Module):
+    """Parameter-free slot that keeps the reference's Sequential indices (convs at 0,2,4,...)."""
+
+    def __init__(self, slope=0.01):
+        super().__init__()
+        self.negative_slope = slope
+
+    def forward(self, x):
+        return ops.activation(x, ACT_LRELU, self.negative_slope)
+
+
+class _Tanh(nn.Module):
+    def forward(self, x):
+        return ops.tanh(x)
+
+
+class _Softmax(nn.Module):
+    """nn.Softmax() placeholder of classification_layer{1,2}: the softmax itself is fused into the
+    head/loss kernels; called stand-alone it normalises over dim 1 like the reference's implicit dim."""
+
+    def forward(self, x):
+        z = x.reshape(x.shape[0], -1)
+        _, q = ops.softmax_mse(z, torch.zeros(z.shape[0], dtype=torch.int64, device=z.device), 0.0)
+        return q.view_as(x)
+
+
+class _InstanceNorm2d(nn.Module):
+    """nn.InstanceNorm2d(affine=False, track_running_stats=False): no parameters, no buffers."""
+
+    def __init__(self, num_features, affine=False):
+        super().__init__()
+        if affine:
+            raise NotImplementedError("InstanceNorm2d(affine=True) is not used by the reference")
+        self.num_features = num_features
+
+    def forward(self, x, act=ACT_NONE, slope=0.0):
+        return ops.instance_norm_act(x, None, None, None, act, slope)
+
+
+class _AvgPool3s2(nn.Module):
+    def forward(self, x):
+        return ops.avgpool3s2(x)
+
+
+class _AvgPool2(nn.Module):
+    def forward(self, x):
+        return ops.avgpool2(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# central-biasing instance norm        (reference: _CBINorm / CBINorm2d, model.py:12-73)
+# ------------------------------------------------------------------------------------------------
+class CBINorm2d(nn.Module):
+    def __init__(self, num_features, num_con=8, eps=1e-5, momentum=0.1, affine=False, track_running_stats=False):
+        super().__init__()
+        if track_running_stats:
+            raise NotImplementedError("CBINorm2d(track_running_stats=True) is not used by the reference")
+        self.num_features, self.num_con, self.eps, self.momentum = num_features, num_con, eps, momentum
+        self.affine, self.track_running_stats = affine, track_running_stats
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+        self.ConBias = nn.Sequential(_Linear(num_con, num_features), _Tanh())
+
+    def _check_input_dim(self, input):
+        if input.dim() != 4:
+            raise ValueError('expected 4D input (got {}D input)'.format(input.dim()))
+
+    def forward(self, input, ConInfor, act=ACT_NONE, slope=0.0, res=None):
+        """(IN(x) + tanh(Linear(c))) * weight + bias, with optional fused activation / residual."""
+        self._check_input_dim(input)
+        lin = self.ConBias[0]
+        if self.affine:
+            gamma, beta = self.weight, self.bias
+        else:
+            gamma = torch.ones(self.num_features, device=input.device)
+            beta = torch.zeros(self.num_features, device=input.device)
+        scale, shift = ops.cbin_affine(ConInfor, lin.weight, lin.bias, gamma, beta)
+        return ops.instance_norm_act(input, scale, shift, res, act, slope, self.eps)
+
+
+def get_norm_layer(layer_type='instance', num_con=2):
+    """(norm_layer, c_norm_layer) factories, as model.py:173-182."""
+    if layer_type == 'instance':
+        norm_layer = functools.partial(_InstanceNorm2d, affine=False)
+        c_norm_layer = functools.partial(CBINorm2d, affine=True, num_con=num_con)
+    elif layer_type == 'batch':
+        # dead code in the reference (CBBNorm2d._load_from_state_dict references an undefined name,
+        # model.py:163; no notebook passes norm_type="batch") -- out of scope, SURVEY.md section 2 row 1
+        raise NotImplementedError('normalization layer [batch] is out of scope of the MI355X path')
+    else:
+        raise NotImplementedError('normalization layer [%s] is not found' % layer_type)
+    return norm_layer, c_norm_layer
+
+
+# ------------------------------------------------------------------------------------------------
+# Generator                              (reference: model.py:188-249)
+# ------------------------------------------------------------------------------------------------
+class SingleResidualBlock(nn.Module):
+    def __init__(self, nch, c_norm_layer):
+        super().__init__()
+        self.c1 = _Conv2d(nch, nch, kernel_size=3, stride=1, padding=1, bias=False)
+        self.cn1 = c_norm_layer(nch)
+        self.c2 = _Conv2d(nch, nch, kernel_size=3, stride=1, padding=1, bias=False)
+        self.cn2 = c_norm_layer(nch)
+
+    def forward(self, x):
+        data, con = x[0], x[1]
+        h = self.cn1(self.c1(data), con, ACT_RELU)
+        return self.cn2(self.c2(h), con, ACT_NONE, 0.0, data), con
+
+
+class SingleGenerator(nn.Module):
+    def __init__(self, nch_in, nch, reduce=2, num_cls=3, res_num=6, norm_type="instance", num_con=2, nch_out=None):
+        super().__init__()
+        if nch_out is None:
+            nch_out = nch_in
+        norm_layer, c_norm_layer = get_norm_layer(layer_type=norm_type, num_con=num_con)
+        self.num_cls = num_cls
+        k, s, p = 2 * reduce, reduce, int(reduce / 2)
+
+        convs = [_Conv2d(nch_in, nch, kernel_size=7, stride=1, padding=3, bias=False)]
+        cnorms = [c_norm_layer(nch)]
+        for i in range(num_cls):
+            convs.append(_Conv2d(nch * 2 ** i, nch * 2 ** (i + 1), kernel_size=k, stride=s, padding=p, bias=False))
+            cnorms.append(c_norm_layer(nch * 2 ** (i + 1)))
+        self.down_convs = nn.ModuleList(convs)
+        self.down_cnorms = nn.ModuleList(cnorms)
+
+        self.resBlocks = nn.Sequential(*[SingleResidualBlock(nch * 2 ** num_cls, c_norm_layer) for _ in range(res_num)])
+
+        ups = [_ConvTranspose2d(nch * 2 ** num_cls, nch * 2 ** (num_cls - 1), kernel_size=k, stride=s, padding=p, bias=False)]
+        norms = [norm_layer(nch * 2 ** (num_cls - 1))]
+        for i in range(1, num_cls)[::-1]:
+            ups.append(_ConvTranspose2d(nch * 2 ** i, nch * 2 ** (i - 1), kernel_size=k, stride=s, padding=p, bias=False))
+            norms.append(norm_layer(nch * 2 ** (i - 1)))
+        ups.append(_Conv2d(nch, nch_out, kernel_size=7, stride=1, padding=3, bias=False))
+        self.up_convs = nn.ModuleList(ups)
+        self.up_norms = nn.ModuleList(norms)
+
+    def forward(self, x, c):
+        for i in range(self.num_cls + 1):
+            x = self.down_cnorms[i](self.down_convs[i](x), c, ACT_RELU)
+        x = self.resBlocks([x, c])[0]
+        for i in range(self.num_cls):
+            x = self.up_norms[i](self.up_convs[i](x), ACT_RELU)
+        return ops.tanh(self.up_convs[-1](x))
+
+
+# ------------------------------------------------------------------------------------------------
+# Discriminators                        (reference: model.py:255-346)
+# ------------------------------------------------------------------------------------------------
+def _d_trunk_layers(nch_in, nch, reduce, num_cls):
+    layers = [_Conv2d(nch_in, nch, kernel_size=4, stride=2, padding=1, bias=False), _LeakyReLU(D_SLOPE)]
+    dim_in = nch
+    for _ in range(1, num_cls):
+        dim_out = min(dim_in * 2, nch * 8)
+        layers.append(_Conv2d(dim_in, dim_out, kernel_size=2 * reduce, stride=reduce, padding=int(reduce / 2), bias=False))
+        layers.append(_LeakyReLU(D_SLOPE))
+        dim_in = dim_out
+    return layers, dim_in
+
+
+def _run_trunk(seq, x):
+    """conv + LeakyReLU pairs run as one fused kernel each; a trailing bias conv runs plain."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        if i + 1 < len(mods) and isinstance(mods[i + 1], _LeakyReLU):
+            x = mods[i](x, ACT_LRELU, mods[i + 1].negative_slope)
+            i += 2
+        else:
+            x = mods[i](x)
+            i += 1
+    return x
+
+
+class SingleDiscriminator_original(nn.Module):
+    def __init__(self, nch_in, nch, reduce=2, num_cls=3, norm_type="instance", num_con=2):
+        super().__init__()
+        self.num_cls = num_cls
+        layers, dim_in = _d_trunk_layers(nch_in, nch, reduce, num_cls)
+        layers.append(_Conv2d(dim_in, 1, kernel_size=4, stride=1, padding=1, bias=True))
+        self.down_convs = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return _run_trunk(self.down_convs, x)
+
+
+class SingleDiscriminator_original_multi(nn.Module):
+    def __init__(self, nch_in, nch, reduce=2, num_cls=3, norm_type="instance", num_con=2):
+        super().__init__()
+        self.discriminator1 = SingleDiscriminator_original(nch_in, nch, reduce, num_cls, norm_type, num_con)
+        self.down = _AvgPool3s2()
+        self.discriminator2 = SingleDiscriminator_original(nch_in, nch // 2, reduce, num_cls, norm_type, num_con)
+
+    def forward(self, x):
+        return [self.discriminator1(x), self.discriminator2(self.down(x))]
+
+
+class SingleDiscriminator_solo(nn.Module):
+    def __init__(self, nch_in, nch, reduce=2, num_cls=3, norm_type="instance", num_con=2):
+        super().__init__()
+        self.num_cls = num_cls
+        layers, _ = _d_trunk_layers(nch_in, nch, reduce, num_cls)
+        self.down_convs = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return _run_trunk(self.down_convs, x)
+
+
+class SingleDiscriminator_solo_multi(nn.Module):
+    def __init__(self, nch_in, nch, reduce=2, num_cls=3, norm_type="instance", n_class=4):
+        super().__init__()
+        self.n_class = n_class
+        self.discriminator1 = SingleDiscriminator_solo(nch_in, nch, reduce, num_cls, norm_type, None)
+        self.down = _AvgPool3s2()
+        self.discriminator2 = SingleDiscriminator_solo(nch_in, nch // 2, reduce, num_cls, norm_type, None)
+        dim_in = min(nch * 2 ** num_cls, nch * 8)
+        self.last_layer1 = _Conv2d(dim_in, 1, kernel_size=4, stride=1, padding=1, bias=True)
+        self.last_layer2 = _Conv2d(dim_in // 2, 1, kernel_size=4, stride=1, padding=1, bias=True)
+        self.classification_layer1 = nn.Sequential(_Conv2d(dim_in, n_class, kernel_size=8, stride=1, padding=0, bias=True), _Softmax())
+        self.classification_layer2 = nn.Sequential(_Conv2d(dim_in // 2, n_class, kernel_size=4, stride=1, padding=0, bias=True), _Softmax())
+
+    def forward_logits(self, x):
+        """-> ([out1, out2], [logits1, logits2]); logits are [B, n_class] pre-softmax (used by the
+        fused softmax+MSE loss kernel in the trainer)."""
+        d1 = self.discriminator1(x)
+        d2 = self.discriminator2(self.down(x))
+        o1, o2 = self.last_layer1(d1), self.last_layer2(d2)
+        z1 = self.classification_layer1[0](d1).reshape(-1, self.n_class)
+        z2 = self.classification_layer2[0](d2).reshape(-1, self.n_class)
+        return [o1, o2], [z1, z2]
+
+    def forward(self, x):
+        outs, logits = self.forward_logits(x)
+        return outs, [_softmax_rows(z) for z in logits]
+
+
+class _SoftmaxRowsFn(torch.autograd.Function):
+    """Row softmax with its Jacobian-vector product, both through the fused softmax kernel."""
+
+    @staticmethod
+    def forward(ctx, z):
+        _, q = ops.softmax_mse(z, torch.zeros(z.shape[0], dtype=torch.int64, device=z.device), 0.0)
+        ctx.save_for_backward(q)
+        return q
+
+    @staticmethod
+    def backward(ctx, gq):
+        (q,) = ctx.saved_tensors
+        return q * (gq - (q * gq).sum(dim=1, keepdim=True))
+
+
+def _softmax_rows(z):
+    return _SoftmaxRowsFn.apply(z)
+
+
+# ------------------------------------------------------------------------------------------------
+# Encoders                               (reference: model.py:352-507)
+# ------------------------------------------------------------------------------------------------
+class BasicBlock_classification(nn.Module):
+    def __init__(self, nch_in, nch_out, norm_layer):
+        super().__init__()
+        self.norm1 = norm_layer(nch_in)
+        self.nl1 = _LeakyReLU(E_SLOPE)
+        self.conv1 = _Conv2d(nch_in, nch_in, kernel_size=3, stride=1, padding=1, bias=False, padding_mode="reflect")
+        self.norm2 = norm_layer(nch_in)
+        self.nl2 = _LeakyReLU(E_SLOPE)
+        self.cmp = nn.Sequential(
+            _Conv2d(nch_in, nch_out, kernel_size=3, stride=1, padding=1, bias=False, padding_mode="reflect"),
+            _AvgPool2())
+        self.shortcut = nn.Sequential(
+            _AvgPool2(),
+            _Conv2d(nch_in, nch_out, kernel_size=1, stride=1, padding=0, bias=True))
+
+    def forward(self, input):
+        x = input
+        h = self.conv1(self.norm1(x, ACT_LRELU, self.nl1.negative_slope))
+        h = self.cmp(self.norm2(h, ACT_LRELU, self.nl2.negative_slope))
+        return ops.add(h, self.shortcut(x))
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, nch_in, nch_out, c_norm_layer=None):
+        super().__init__()
+        self.cnorm1 = c_norm_layer(nch_in)
+        self.nl1 = _LeakyReLU(E_SLOPE)
+        self.conv1 = _Conv2d(nch_in, nch_in, kernel_size=3, stride=1, padding=1, bias=False, padding_mode="reflect")
+        self.cnorm2 = c_norm_layer(nch_in)
+        self.nl2 = _LeakyReLU(E_SLOPE)
+        self.cmp = nn.Sequential(
+            _Conv2d(nch_in, nch_out, kernel_size=3, stride=1, padding=1, bias=False, padding_mode="reflect"),
+            _AvgPool2())
+        self.shortcut = nn.Sequential(
+            _AvgPool2(),
+            _Conv2d(nch_in, nch_out, kernel_size=1, stride=1, padding=0, bias=True))
+
+    def forward(self, input):
+        x, d = input
+        h = self.conv1(self.cnorm1(x, d, ACT_LRELU, self.nl1.negative_slope))
+        h = self.cmp(self.cnorm2(h, d, ACT_LRELU, self.nl2.negative_slope))
+        return [ops.add(h, self.shortcut(x)), d]
+
+
+def _cpu_normal_like(t):
+    """Noise from the CPU default generator, then moved -- the reference's reparametrize does
+    ``torch.FloatTensor(size).normal_().to(device)`` (model.py:461), so seeds reproduce."""
+    return torch.FloatTensor(t.size()).normal_().to(t.device)
+
+
+class _ReparamFn(torch.autograd.Function):
+    """eps * exp(logvar/2) + mu on [B, ndim] (tiny; kept on-device, fused value+grads)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        std = torch.exp(0.5 * logvar)
+        ctx.save_for_backward(eps, std)
+        return eps * std + mu
+
+    @staticmethod
+    def backward(ctx, g):
+        eps, std = ctx.saved_tensors
+        return g, g * eps * std * 0.5, None
+
+
+class _EncoderBase(nn.Module):
+    def reparametrize(self, mu, logvar):
+        return _ReparamFn.apply(mu, logvar, _cpu_normal_like(mu))
+
+
+class Encoder_original(_EncoderBase):
+    def __init__(self, nch_in, nch_out, nch=64, num_cls=3, norm_type="instance", num_con=2, device="cpu"):
+        super().__init__()
+        _, c_norm_layer = get_norm_layer(layer_type=norm_type, num_con=num_con)
+        self.num_cls, self.device = num_cls, device
+        self.first_layer = _Conv2d(nch_in, nch, kernel_size=7, stride=2, padding=1, bias=True)
+        blocks, in_nch = [], nch
+        for _ in range(num_cls):
+            blocks.append(BasicBlock(in_nch, in_nch * 2, c_norm_layer))
+            in_nch *= 2
+        self.layers = nn.Sequential(*blocks)
+        self.last_layer = nn.Sequential(_LeakyReLU(E_SLOPE), nn.AdaptiveAvgPool2d(1))
+        self.fcmean = _Linear(in_nch, nch_out)
+        self.fcvar = _Linear(in_nch, nch_out)
+
+    def forward(self, x, c):
+        h = self.layers([self.first_layer(x), c])[0]
+        feat = ops.lrelu_global_avgpool(h, self.last_layer[0].negative_slope)
+        mu, logvar = self.fcmean(feat), self.fcvar(feat)
+        return self.reparametrize(mu, logvar), mu, logvar
+
+
+class Encoder(_EncoderBase):
+    def __init__(self, nch_in, nch_out, nch=64, num_cls=3, norm_type="instance", num_con=2, device="cpu"):
+        super().__init__()
+        norm_layer, _ = get_norm_layer(layer_type=norm_type, num_con=num_con)
+        self.num_cls, self.device = num_cls, device
+        self.first_layer = _Conv2d(nch_in, nch, kernel_size=7, stride=2, padding=1, bias=True)
+        blocks, in_nch = [], nch
+        for _ in range(num_cls):
+            blocks.append(BasicBlock_classification(in_nch, in_nch * 2, norm_layer))
+            in_nch *= 2
+        self.layers = nn.Sequential(*blocks)
+        self.last_layer = nn.Sequential(_LeakyReLU(E_SLOPE), nn.AdaptiveAvgPool2d(1))
+        self.fcmean = _Linear(in_nch, nch_out)
+        self.fcvar = _Linear(in_nch, nch_out)
+        self.fcclass = _Linear(in_nch, num_con)
+
+    def freeze_melt(self, classifier_layers, mode="freeze"):
+        """Toggle requires_grad of the parameters whose state_dict key is listed (model.py:465-472)."""
+        keys = list(self.state_dict().keys())
+        for i, param in enumerate(self.parameters()):
+            if keys[i] in classifier_layers:
+                if mode == "freeze":
+                    param.requires_grad = False
+                elif mode == "melt":
+                    param.requires_grad = True
+
+    def features(self, x):
+        h = self.layers(self.first_layer(x))
+        return ops.lrelu_global_avgpool(h, self.last_layer[0].negative_slope)
+
+    def forward(self, x):
+        feat = self.features(x)
+        mu, logvar = self.fcmean(feat), self.fcvar(feat)
+        c_code = self.reparametrize(mu, logvar)
+        class_output = self.fcclass(feat)
+        return c_code, mu, logvar, class_output, None
+
+
+class Encoder_classifier(nn.Module):
+    """Pre-training twin of Encoder (keys = Encoder's minus fcmean/fcvar); softmax class output."""
+
+    def __init__(self, nch_in, nch_out, nch=64, num_cls=3, norm_type="instance", num_con=2):
+        super().__init__()
+        norm_layer, _ = get_norm_layer(layer_type=norm_type, num_con=num_con)
+        self.num_cls = num_cls
+        self.first_layer = _Conv2d(nch_in, nch, kernel_size=7, stride=2, padding=1, bias=True)
+        blocks, in_nch = [], nch
+        for _ in range(num_cls):
+            blocks.append(BasicBlock_classification(in_nch, in_nch * 2, norm_layer))
+            in_nch *= 2
+        self.layers = nn.Sequential(*blocks)
+        self.last_layer = nn.Sequential(_LeakyReLU(E_SLOPE), nn.AdaptiveAvgPool2d(1))
+        self.fcclass = _Linear(in_nch, num_con)
+
+    def forward(self, x):
+        h = self.layers(self.first_layer(x))
+        feat = ops.lrelu_global_avgpool(h, self.last_layer[0].negative_slope)
+        return _softmax_rows(self.fcclass(feat))
+
+
+class MinMax(object):
+    """Per-image min-max scaling to [0,1] or [-1,1] (reference util.py:107-155; the notebooks import it
+    from ``model``).  Host-side data-pipeline transform, not part of the GPU hot path."""
+
+    def __init__(self, mean0=True):
+        self.mean0 = mean0
+
+    def __call__(self, img):
+        x = img.detach().cpu().numpy() if torch.is_tensor(img) else np.asarray(img)
+        lo, hi = x.min(), x.max()
+        out = (x - lo) / (hi - lo + 1e-8)
+        if self.mean0:
+            out = out * 2 - 1
+        return torch.Tensor(out)
+
+    def __repr__(self):
+        return self.__class__.__name__

@@ -23,6 +23,9 @@ ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 PAD_ZERO, PAD_REFLECT = 0, 1
 
 _workspaces = {}
+import os as _os
+_DEBUG_FRESH_WS = bool(_os.environ.get('SRGAN_DEBUG_FRESH_WS'))
+_DEBUG_CLONE = bool(_os.environ.get('SRGAN_DEBUG_CLONE'))
 
 
 def _require_gpu(t, what):
@@ -44,6 +47,8 @@ def _ptr(t):
 def workspace(device, nbytes):
     """Cached scratch buffer (per device); grown on demand, reused in stream order."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    if _DEBUG_FRESH_WS:
+        return torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes * 1.25), 1 << 22), dtype=torch.uint8, device=device)
@@ -255,7 +260,7 @@ class _InstNormFn(Function):
                                           _ptr(dscale), _ptr(dshift), n, h * w, c, ctx.act, float(ctx.slope), _ptr(ws), nb,
                                           _stream()), "instnorm_bwd")
         has_aff = scale is not None
-        return (dx, dscale if has_aff else None, dshift if has_aff else None, gy if ctx.has_res else None,
+        return (dx, dscale if has_aff else None, dshift if has_aff else None, (gy.clone() if _DEBUG_CLONE else gy) if ctx.has_res else None,
                 None, None, None)
 
 
@@ -565,23 +570,78 @@ class _LatentLossFn(Function):
         b, d = mu.shape
         vals = torch.empty(4, dtype=torch.float32, device=mu.device)
         dmu = torch.empty_like(mu)
+        corr = torch.empty(d, d, dtype=torch.float32, device=mu.device)
         _lib.check(_lib.load().srgan_latent_losses(_ptr(mu), b, d, float(n_batch), _ptr(target), bins, float(range_max),
                                                    float(sigma), float(w_bkl), float(w_corr), float(w_hist), _ptr(vals),
-                                                   _ptr(dmu), _stream()), "latent_losses")
+                                                   _ptr(dmu), _ptr(corr), _stream()), "latent_losses")
         ctx.save_for_backward(dmu)
         total, parts = vals[3], vals[:3]
-        ctx.mark_non_differentiable(parts)
-        return total, parts
+        ctx.mark_non_differentiable(parts, corr)
+        return total, parts, corr
 
     @staticmethod
-    def backward(ctx, g, _gp):
+    def backward(ctx, g, _gp, _gc):
         (dmu,) = ctx.saved_tensors
         return (dmu * g,) + (None,) * 8
 
 
 def latent_losses(mu, n_batch, hist_target, w_bkl, w_corr, w_hist, bins=50, range_max=10.0, sigma=0.2):
-    """-> (w_bkl*bKL + w_corr*corr + w_hist*hist, tensor([bKL, corr, hist]))."""
+    """-> (w_bkl*bKL + w_corr*corr + w_hist*hist, tensor([bKL, corr, hist]), Pearson matrix [d,d])."""
     return _LatentLossFn.apply(mu, n_batch, hist_target, bins, range_max, sigma, w_bkl, w_corr, w_hist)
+
+
+class _MsePairFn(Function):
+    @staticmethod
+    def forward(ctx, a, b, weight):
+        _require_gpu(a, "mse_pair")
+        a, b = a.contiguous(), b.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        _lib.check(_lib.load().srgan_mse_pair(_ptr(a), _ptr(b), a.numel(), float(weight), _ptr(loss), _ptr(da), _ptr(db),
+                                              _stream()), "mse_pair")
+        ctx.save_for_backward(da, db)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        da, db = ctx.saved_tensors
+        return (da * g if da is not None else None, db * g if db is not None else None, None)
+
+
+def mse_pair(a, b, weight=1.0):
+    """weight * mean((a - b)^2) for two small tensors of equal shape."""
+    return _MsePairFn.apply(a, b, weight)
+
+
+class _SoftHistFn(Function):
+    @staticmethod
+    def forward(ctx, x, bins, lo, hi, sigma):
+        _require_gpu(x, "soft_histogram")
+        x = x.contiguous()
+        lib = _lib.load()
+        h = torch.empty(bins, dtype=torch.float32, device=x.device)
+        nb = lib.srgan_soft_histogram_workspace(x.numel(), bins)
+        ws = workspace(x.device, nb)
+        _lib.check(lib.srgan_soft_histogram_fwd(_ptr(x), x.numel(), bins, float(lo), float(hi), float(sigma), _ptr(h),
+                                                _ptr(ws), nb, _stream()), "soft_histogram_fwd")
+        ctx.cfg = (bins, lo, hi, sigma)
+        ctx.save_for_backward(x)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        bins, lo, hi, sigma = ctx.cfg
+        dx = torch.empty_like(x)
+        _lib.check(_lib.load().srgan_soft_histogram_bwd(_ptr(x), _ptr(g.contiguous()), x.numel(), bins, float(lo), float(hi),
+                                                        float(sigma), _ptr(dx), _stream()), "soft_histogram_bwd")
+        return dx, None, None, None, None
+
+
+def soft_histogram(x, bins, lo, hi, sigma):
+    """Gaussian-kernel soft histogram of a 1-D sample (differentiable)."""
+    return _SoftHistFn.apply(x, bins, lo, hi, sigma)
 
 
 def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):

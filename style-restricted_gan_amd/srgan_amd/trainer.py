@@ -1,0 +1,329 @@
+"""``SRGAN_training``: the Style-Restricted GAN train step on the MI355X HIP path.
+
+Same constructor / method signatures and return values as the reference class
+(pyfiles/util_notebook.py:419-734); ``sg.train(source_image, label)`` drops into the loop of
+``05-train_Style-Restricted_GAN.ipynb``.  What differs is HOW the step is executed:
+
+* every network op and loss is a hand-written gfx950 kernel (``srgan_amd.ops``);
+* result-preserving work savings of SURVEY.md Appendix B.2: the G forwards of the first k-1
+  D-updates record no graph; D's weight gradients are not computed in phase 1 and E's not in
+  phase 2 (they are discarded by the reference's ``zero_grad`` calls); the encoder trunk runs once
+  for the two phase-1 ``E(source)`` calls; errG and errE are back-propagated in one pass;
+* under ``torch.distributed`` (one process per GPU) gradients are averaged with bucketed RCCL
+  all-reduce (``srgan_amd.dp``) and the batch-statistics losses see the all-gathered mu.
+
+Semantics kept on purpose: stale ``target_image`` graph re-used after
+``optG.step()`` with weights read at backward time; the no-op "unrolled" restore of D; corr/hist
+nested under batch_KL; the n/(n-1) double correction with the constructor's batch size; errE returned
+is the reporting sum; CPU-generator RNG order (k x randn, then normal_ x2, then normal_ x3).
+"""
+import contextlib
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from . import dp, ops
+from .losses import class_encode, get_domainloss_D, get_loss_D, histogram_imitation
+from .model import _cpu_normal_like
+from .optim import Adam
+
+__all__ = ["SRGAN_training"]
+
+
+@contextlib.contextmanager
+def _frozen(params):
+    """Temporarily mark parameters as not requiring grad (skips their weight-gradient kernels)."""
+    flags = [(p, p.requires_grad) for p in params]
+    for p, _ in flags:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p, f in flags:
+            p.requires_grad_(f)
+
+
+class SRGAN_training():
+    """
+    net            : [G, D, E] nn.Modules          opt : [optG, optD, optE] (None -> fused HIP Adam)
+    criterion      : [criterion, criterion_class]   (nn.MSELoss in every reference notebook)
+    lbd            : dict of loss weights: class, cycle, idt, reg, idt_reg, KL, batch_KL, corr_enc, hist
+    unrolled_k     : number of D updates per G/E update
+    device         : "cuda" / torch.device           ref_label : np.array (class_num, dim), usually one-hot
+    batch_size     : GLOBAL batch size (n of the batch-KL correction)
+    encoded_feature: "latent" or "mu"                ndim : style-code dimension
+    """
+
+    def __init__(self, net, opt, criterion, lbd, unrolled_k, device, ref_label,
+                 batch_size=64, encoded_feature="latent", ndim=8):
+        self.G, self.D, self.E = net[0].to(device), net[1].to(device), net[2].to(device)
+        self.optG, self.optD, self.optE = opt[0], opt[1], opt[2]
+        self.scheG, self.scheD, self.scheE = None, None, None
+        self.criterion, self.criterion_class = criterion
+        self.lbd = lbd
+        self.k = unrolled_k
+        self.device = device
+        self.ref_label = ref_label
+        self.n_batch = batch_size
+        self.encoded_feature = encoded_feature
+        self.ndim = ndim
+        self.source_image = None
+        self.target_image = None
+        self.recon_image = None
+        self.label = None
+        self.c_rand = None
+        self.enc_info = None
+        self.target_cenc = None
+        if lbd["hist"] > 0:
+            self.hi = histogram_imitation(device)
+        self.loss_terms = {}           # last step's individual loss values (device scalars)
+        self._reducers = {}
+        ref = np.asarray(ref_label)
+        self._ref_is_onehot = ref.ndim == 2 and ref.shape[0] == ref.shape[1] and np.array_equal(ref, np.eye(ref.shape[0]))
+
+    # ------------------------------------------------------------------------------------------
+    def opt_sche_initialization(self, lr=[0.0001, 0.0001, 0.0001]):
+        """Create the missing optimisers (Adam lr, betas=(0.5,0.999)) and ExponentialLR(gamma=0.95)
+        schedulers for G, D, E   (util_notebook.py:484-508)."""
+        lr_G, lr_D, lr_E = lr
+        if self.optG is None:
+            self.optG = Adam(self.G.parameters(), lr=lr_G, betas=(0.5, 0.999))
+        self.scheG = optim.lr_scheduler.ExponentialLR(self.optG, gamma=0.95)
+        if self.optD is None:
+            self.optD = Adam(self.D.parameters(), lr=lr_D, betas=(0.5, 0.999))
+        self.scheD = optim.lr_scheduler.ExponentialLR(self.optD, gamma=0.95)
+        if self.optE is None:
+            self.optE = Adam(self.E.parameters(), lr=lr_E, betas=(0.5, 0.999))
+        self.scheE = optim.lr_scheduler.ExponentialLR(self.optE, gamma=0.95)
+        return
+
+    # ------------------------------------------------------------------------------------------
+    # helpers
+    def _cached(self, kind, which, make):
+        """Per-label-tensor cache (labels are fixed during a step; class_encode forces a host sync)."""
+        cache = self.__dict__.setdefault("_label_cache", {})
+        lab = self.label[which]
+        hit = cache.get((kind, which))
+        if hit is None or hit[0] is not lab:
+            hit = cache[(kind, which)] = (lab, make(lab))
+        return hit[1]
+
+    def _onehot(self, which):
+        return self._cached("onehot", which, lambda lab: class_encode(lab, self.device, self.ref_label))
+
+    def _label_dev(self, which):
+        return self._cached("index", which,
+                            lambda lab: torch.as_tensor(lab).to(device=self.device, dtype=torch.int64))
+
+    @staticmethod
+    def _opt_params(opt):
+        return [p for g in opt.param_groups for p in g["params"]]
+
+    def _reduce_start(self, name, opt):
+        if not dp.is_distributed():
+            return None
+        red = self._reducers.get(name)
+        if red is None:
+            red = self._reducers[name] = dp.GradReducer(self._opt_params(opt))
+        red.start()
+        return red
+
+    def _encode(self, image, feat=None):
+        """E(image) -> 5-list; with a precomputed trunk feature only the heads (+ a fresh noise draw) run."""
+        E = dp.unwrap(self.E)
+        if feat is not None and hasattr(E, "features"):
+            mu, logvar = E.fcmean(feat), E.fcvar(feat)
+            return [E.reparametrize(mu, logvar), mu, logvar, E.fcclass(feat), None]
+        return list(self.E(image))
+
+    def _d_losses(self, image, gan_target, class_which, want_class):
+        """LSGAN (+ class MSE) of D(image) through the fused head/loss kernels."""
+        D = dp.unwrap(self.D)
+        if hasattr(D, "forward_logits") and self._ref_is_onehot:
+            outs, logits = D.forward_logits(image)
+            gan = get_loss_D(outs, gan_target, self.criterion, self.device)
+            cls = None
+            if want_class:
+                lab = self._label_dev(class_which)
+                w = 1.0 / len(logits)
+                cls = 0.0
+                for z in logits:
+                    cls = cls + ops.softmax_mse(z, lab, w)[0]
+            return gan, cls
+        outs, probs = self.D(image)
+        gan = get_loss_D(outs, gan_target, self.criterion, self.device)
+        cls = get_domainloss_D(probs, self._onehot(class_which), self.criterion_class) if want_class else None
+        return gan, cls
+
+    # ------------------------------------------------------------------------------------------
+    def G_transformation(self, target_label, source_image, encoder=False, ref_image=None, _enc_info=None):
+        """Translate ``source_image`` to ``target_label`` with a style code from E(ref_image) (encoder=True) or
+        N(0, I) noise drawn on the CPU default generator   (util_notebook.py:510-561).
+        Returns (image, info): info = [latent, mu, logvar, class_output, None] or the random latent."""
+        if encoder:
+            info = _enc_info if _enc_info is not None else self._encode(ref_image)
+            latent, mu = info[0], info[1]
+            if self.encoded_feature == "latent":
+                latent_vector = latent
+            elif self.encoded_feature == "mu":
+                latent_vector = mu
+        else:
+            latent_vector = torch.randn(source_image.shape[0], self.ndim).to(self.device)
+            info = latent_vector
+        if isinstance(target_label, str):
+            class_vector = self._onehot(target_label)
+        else:
+            class_vector = class_encode(target_label, self.device, self.ref_label)
+        class_vector = torch.cat([class_vector, latent_vector], 1)
+        target_image = self.G(source_image, class_vector)
+        return target_image, info
+
+    # ------------------------------------------------------------------------------------------
+    def update_D(self, _fake=None, _next_fake=None):
+        """One discriminator update (util_notebook.py:563-594); returns errD.
+        ``_fake`` / ``_next_fake`` let UnrolledUpdate hand in a pre-computed translation and overlap the next
+        one with this update's gradient all-reduce."""
+        self.D.zero_grad()
+        if _fake is None:
+            self.target_image, self.c_rand = self.G_transformation("target", self.source_image, False)
+        else:
+            self.target_image, self.c_rand = _fake
+
+        errD_real, errD_class = self._d_losses(self.source_image, 1., "source", True)
+        errD_fake, _ = self._d_losses(self.target_image.detach(), 0., None, False)
+        errD = errD_real + errD_class * self.lbd["class"] + errD_fake
+        errD.backward()
+        red = self._reduce_start("D", self.optD)
+        nxt = _next_fake() if _next_fake is not None else None      # overlaps the all-reduce
+        if red is not None:
+            red.finish()
+        self.optD.step()
+        self.loss_terms.update(errD_real=errD_real.detach(), errD_class=errD_class.detach(), errD_fake=errD_fake.detach())
+        if _next_fake is not None:
+            return errD, nxt
+        return errD
+
+    # ------------------------------------------------------------------------------------------
+    def update_GandE(self):
+        """Generator + encoder update in two phases (util_notebook.py:596-694); returns [errG, errE_output]."""
+        L = self.lbd
+        self.G.zero_grad()
+        self.E.zero_grad()
+        E = dp.unwrap(self.E)
+        src = self.source_image
+        ws = dp.world_size()
+
+        # ---------------- phase 1: G and E ----------------
+        optE_ids = {id(p) for p in self._opt_params(self.optE)}
+        e_unused = [p for p in self.E.parameters() if p.requires_grad and id(p) not in optE_ids]
+        with _frozen(e_unused):
+            feat = E.features(src) if hasattr(E, "features") else None
+            source_enc_info = self._encode(src, feat)
+            recon_image, _ = self.G_transformation("source", self.target_image, True, src, _enc_info=source_enc_info)
+            with _frozen(list(self.D.parameters())):       # D's weight grads would be discarded
+                errG_dis, errG_class = self._d_losses(self.target_image, 1., "target", True)
+            errG_cycle = ops.l1_mean(src, recon_image, 1.0)
+            errG = errG_dis + errG_class * L["class"] + errG_cycle * L["cycle"]
+            errE = 0
+            errE_output = errG_cycle * L["cycle"]
+            terms = dict(errG_dis=errG_dis, errG_class=errG_class, errG_cycle=errG_cycle)
+
+            _, mu, logvar, _, _ = source_enc_info
+            if L["KL"] > 0:
+                errE_KL = -0.5 * torch.sum(1 + logvar - mu ** 2 - logvar.exp())
+                errE = errE + errE_KL * L["KL"]
+                errE_output = errE_output + errE_KL * L["KL"]
+                terms["errE_KL"] = errE_KL
+
+            if L["idt"] > 0:
+                # the reference calls E(source) a second time: same weights, same input -> same mu; only the
+                # reparametrisation noise is drawn again (keeps the CPU RNG sequence identical)
+                idt_info = self._encode(src, feat) if feat is not None else None
+                identity_image, _ = self.G_transformation("source", src, True, src, _enc_info=idt_info)
+                errG_idt = ops.l1_mean(src, identity_image, 1.0)
+                errG = errG + errG_idt * L["idt"]
+                errE_output = errE_output + errG_idt * L["idt"]
+                terms["errG_idt"] = errG_idt
+
+            if L["batch_KL"] > 0:
+                w_corr = L["corr_enc"] if L["corr_enc"] > 0 else 0.0
+                w_hist = L["hist"] if L["hist"] > 0 else 0.0
+                target = self.hi.target if w_hist > 0 else torch.full((50,), 0.02, device=mu.device)
+                mu_all = dp.all_gather_rows(mu)
+                total, parts, _ = ops.latent_losses(mu_all, self.n_batch, target, L["batch_KL"], w_corr, w_hist)
+                # every rank evaluates the global-batch loss; its local rows' gradient must be SUMMED over ranks
+                # while the all-reduce averages -> pre-scale by the world size
+                errE = errE + (total * ws if ws > 1 else total)
+                errE_output = errE_output + total
+                terms.update(errE_bKL=parts[0], errE_corr=parts[1], errE_hist=parts[2])
+
+            total_p1 = errG + errE if torch.is_tensor(errE) else errG
+            total_p1.backward(retain_graph=True)         # target_image's graph is needed again in phase 2
+        redG = self._reduce_start("G", self.optG)
+        redE = self._reduce_start("E", self.optE)
+        if redG is not None:
+            redG.finish()
+            redE.finish()
+        self.optG.step()
+        self.optE.step()
+
+        # ---------------- phase 2: G only ----------------
+        self.G.zero_grad()
+        self.E.zero_grad()
+        with _frozen(list(self.E.parameters())):           # only optG steps: E's weight grads are discarded
+            _, target_cenc, _, _, _ = self._encode(self.target_image)
+            errG_reg = ops.l1_mean(self.c_rand, target_cenc, 1.0)
+            errG_ex = errG_reg * L["reg"]
+            terms["errG_reg"] = errG_reg
+            if L["idt_reg"] * L["idt"] > 0:
+                with torch.no_grad():                       # its gradient only reaches E's parameters
+                    info = self._encode(src)
+                idt_random_image, info = self.G_transformation("source", src, True, src, _enc_info=info)
+                source_c_rand = info[1]
+                _, idt_cenc_rand, _, _, _ = self._encode(idt_random_image)
+                errG_idt_reg = ops.l1_mean(source_c_rand, idt_cenc_rand, 1.0)
+                errG_ex = errG_ex + errG_idt_reg * (L["idt_reg"] * (L["idt"] / L["cycle"]))
+                terms["errG_idt_reg"] = errG_idt_reg
+            errG_ex.backward()
+        redG = self._reduce_start("G", self.optG)
+        if redG is not None:
+            redG.finish()
+        self.optG.step()
+
+        self.recon_image = recon_image.detach()
+        self.loss_terms.update({k: v.detach() for k, v in terms.items()})
+        errG = errG.detach() + errG_ex.detach()
+        return [errG, errE_output.detach()]
+
+    # ------------------------------------------------------------------------------------------
+    def UnrolledUpdate(self):
+        """k discriminator updates then one G/E update (util_notebook.py:696-728).  The reference then
+        "restores" D from ``paramD = self.D.state_dict()``, which aliases the live tensors -- a no-op that
+        is not replayed here.  Returns [errorG, errorD(first iteration), errorE]."""
+        errorD = None
+
+        def make_fake(keep_graph):
+            if keep_graph:
+                return self.G_transformation("target", self.source_image, False)
+            with torch.no_grad():               # only the last translation's graph is ever back-propagated
+                return self.G_transformation("target", self.source_image, False)
+
+        fake = make_fake(self.k == 1)
+        for i in range(self.k):
+            if i + 1 < self.k:
+                errD, fake = self.update_D(_fake=fake, _next_fake=lambda i=i: make_fake(i + 2 == self.k))
+            else:
+                errD = self.update_D(_fake=fake)
+            if i == 0:
+                errorD = errD.detach()
+        errorG, errorE = self.update_GandE()
+        return [errorG, errorD, errorE]
+
+    def train(self, source_image, label):
+        self.source_image = ops.to_nhwc(source_image)
+        self.label = label
+        self.loss_terms = {}
+        error = self.UnrolledUpdate()
+        return error

@@ -111,6 +111,13 @@ def golden_shapes():
     out["D_original_64"] = shapes_of(ref_model.SingleDiscriminator_original_multi(3, 64, 2, 4, "instance"))
     out["E_original_64"] = shapes_of(ref_model.Encoder_original(3, 8, 64, 4, "instance", 2, "cpu"))
     out["G_cfg1"] = shapes_of(ref_model.SingleGenerator(3, 64, 2, 2, 6, "instance", num_con=10))
+    # PyTorch default init under a fixed seed (weights_init is a no-op): per-key [sum, |sum|] checksums
+    torch.manual_seed(7)
+    nets = dict(G=ref_model.SingleGenerator(3, 8, 2, 2, 2, "instance", num_con=12),
+                D=ref_model.SingleDiscriminator_solo_multi(3, 8, 2, 4, "instance", 4),
+                E=ref_model.Encoder(3, 8, 8, 4, "instance", 4, "cpu"))
+    out["init_seed7"] = {n: [[k, float(v.double().sum()), float(v.double().abs().sum())] for k, v in net.state_dict().items()]
+                         for n, net in nets.items()}
     with open(os.path.join(HERE, "shapes.json"), "w") as f:
         json.dump(out, f)
 

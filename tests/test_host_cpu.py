@@ -1,0 +1,125 @@
+"""CPU: host-side logic of srgan_amd that needs no GPU -- module tree / state_dict layout / default
+init parity with the reference, error behaviour, host helpers, optimiser plumbing."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import params
+from srgan_amd import dp, losses, model
+from srgan_amd._lib import SrganHipError
+
+
+def shapes_of(net):
+    return [[k, list(v.shape)] for k, v in net.state_dict().items()]
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "shapes.json")))
+    G = model.SingleGenerator(3, 64, 2, 2, 6, "instance", num_con=12)
+    D = model.SingleDiscriminator_solo_multi(3, 64, 2, 4, "instance", 4)
+    E = model.Encoder(3, 8, 64, 4, "instance", 4, "cpu")
+    assert shapes_of(G) == ref["F"]["G"] and len(ref["F"]["G"]) == 78
+    assert shapes_of(D) == ref["F"]["D"] and len(ref["F"]["D"]) == 16
+    assert shapes_of(E) == ref["F"]["E"] and len(ref["F"]["E"]) == 24
+    assert shapes_of(model.SingleDiscriminator_original_multi(3, 64, 2, 4, "instance")) == ref["D_original_64"]
+    assert shapes_of(model.Encoder_original(3, 8, 64, 4, "instance", 2, "cpu")) == ref["E_original_64"]
+    assert shapes_of(model.SingleGenerator(3, 64, 2, 2, 6, "instance", num_con=10)) == ref["G_cfg1"]
+    assert all(v.dtype == torch.float32 for v in G.state_dict().values())
+    # Encoder_classifier keys = Encoder keys minus fcmean/fcvar (used by freeze_melt in 05-train cell 22)
+    C = model.Encoder_classifier(3, 8, 64, 4, "instance", 4)
+    assert list(C.state_dict().keys()) == [k for k in E.state_dict().keys() if not k.startswith(("fcmean", "fcvar"))]
+
+
+def test_default_init_equals_reference_under_seed(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "shapes.json")))["init_seed7"]
+    torch.manual_seed(7)
+    nets = dict(G=model.SingleGenerator(3, 8, 2, 2, 2, "instance", num_con=12),
+                D=model.SingleDiscriminator_solo_multi(3, 8, 2, 4, "instance", 4),
+                E=model.Encoder(3, 8, 8, 4, "instance", 4, "cpu"))
+    for name, net in nets.items():
+        net.apply(losses.weights_init)          # no-op, as in the reference
+        got = [[k, float(v.double().sum()), float(v.double().abs().sum())] for k, v in net.state_dict().items()]
+        for (k1, s1, a1), (k2, s2, a2) in zip(got, ref[name]):
+            assert k1 == k2
+            assert abs(s1 - s2) < 1e-9 and abs(a1 - a2) < 1e-9, (name, k1)
+
+
+def test_freeze_melt_pretrained_encoder_recipe():
+    E = model.Encoder(3, 8, 8, 4, "instance", 4, "cpu")
+    C = model.Encoder_classifier(3, 8, 8, 4, "instance", 4)
+    keys = list(C.state_dict().keys())
+    E.freeze_melt(keys, "freeze")
+    trainable = [k for k, p in E.named_parameters() if p.requires_grad]
+    assert trainable == ["fcmean.weight", "fcmean.bias", "fcvar.weight", "fcvar.bias"]
+    assert sum(p.numel() for p in E.parameters() if p.requires_grad) == 2 * (8 * 128 + 8)
+    E.freeze_melt(keys, "melt")
+    assert all(p.requires_grad for p in E.parameters())
+    missing = E.load_state_dict(C.state_dict(), strict=False)
+    assert sorted(missing.missing_keys) == ["fcmean.bias", "fcmean.weight", "fcvar.bias", "fcvar.weight"]
+
+
+def test_error_behaviour():
+    with pytest.raises(NotImplementedError, match=r"normalization layer \[foo\] is not found"):
+        model.get_norm_layer("foo")
+    cb = model.CBINorm2d(8, num_con=4, affine=True)
+    with pytest.raises(ValueError, match=r"expected 4D input \(got 3D input\)"):
+        cb(torch.zeros(2, 8, 5), torch.zeros(2, 4))
+    with pytest.raises(SrganHipError, match="no CPU fallback"):
+        model.SingleGenerator(3, 4, 2, 2, 1, "instance", num_con=12)(torch.zeros(1, 3, 16, 16), torch.zeros(1, 12))
+    with pytest.raises(NotImplementedError, match="MSELoss"):
+        losses.get_loss_D([torch.zeros(1)], 1.0, nn.L1Loss())
+
+
+def test_class_encode_and_get_target():
+    lab = torch.tensor([2, 0, 3, 1])
+    oh = losses.class_encode(lab, "cpu", np.eye(4))
+    assert oh.dtype == torch.float32 and oh.tolist() == np.eye(4)[[2, 0, 3, 1]].tolist()
+    ref = np.array([[1.0, 0.5], [0.0, 2.0], [3.0, 3.0]])
+    assert losses.class_encode(torch.tensor([2, 1]), "cpu", ref).tolist() == [[3.0, 3.0], [0.0, 2.0]]
+    np.random.seed(0)
+    t = losses.get_target(lab, (0, 1, 2, 3))
+    assert t.shape == (4, 3)
+    for row, src in zip(t, lab.tolist()):
+        assert sorted(row.tolist()) == sorted(set(range(4)) - {src})
+    assert losses.get_target(lab, (0, 1, 2, 3), whole=True, shuffle=False).tolist() == [[0, 1, 2, 3]] * 4
+    assert losses.get_target(lab, (0, 1, 2, 3), shuffle=False)[0].tolist() == [0, 1, 3]
+
+
+def test_minmax_transform():
+    x = torch.tensor([[0.0, 5.0], [10.0, 2.5]])
+    y = model.MinMax(True)(x)
+    assert float(y.min()) == pytest.approx(-1.0) and float(y.max()) == pytest.approx(1.0, abs=1e-6)
+    assert float(model.MinMax(False)(x).min()) == 0.0
+
+
+def test_dataparallel_wrapper_exposes_module():
+    net = model.SingleDiscriminator_solo_multi(3, 4, 2, 4, "instance", 4)
+    w = dp.DataParallel(net, [0, 1, 2, 3])
+    assert w.module is net and dp.unwrap(w) is net and dp.unwrap(net) is net
+    assert w.n_class == 4                                  # attribute pass-through
+    assert list(w.module.state_dict().keys()) == list(net.state_dict().keys())
+
+
+def test_trainer_signature_and_optimiser_setup():
+    import inspect
+    from srgan_amd.trainer import SRGAN_training
+    sig = inspect.signature(SRGAN_training.__init__)
+    assert list(sig.parameters)[1:] == ["net", "opt", "criterion", "lbd", "unrolled_k", "device", "ref_label",
+                                        "batch_size", "encoded_feature", "ndim"]
+    assert sig.parameters["batch_size"].default == 64 and sig.parameters["encoded_feature"].default == "latent"
+    for m in ("opt_sche_initialization", "G_transformation", "update_D", "update_GandE", "UnrolledUpdate", "train"):
+        assert callable(getattr(SRGAN_training, m))
+    G = model.SingleGenerator(3, 4, 2, 2, 1, "instance", num_con=12)
+    D = model.SingleDiscriminator_solo_multi(3, 4, 2, 4, "instance", 4)
+    E = model.Encoder(3, 8, 4, 4, "instance", 4, "cpu")
+    lbd = {"class": 1, "cycle": 5, "idt": 5, "reg": .5, "idt_reg": .5, "KL": 0, "batch_KL": 10, "corr_enc": 100, "hist": 0}
+    sg = SRGAN_training([G, D, E], [None, None, None], [nn.MSELoss(), nn.MSELoss()], lbd, 5, "cpu", np.eye(4), 32, "mu", 8)
+    sg.opt_sche_initialization()
+    for opt in (sg.optG, sg.optD, sg.optE):
+        assert opt.param_groups[0]["lr"] == 1e-4 and opt.param_groups[0]["betas"] == (0.5, 0.999)
+    sg.scheG.step()
+    assert sg.optG.param_groups[0]["lr"] == pytest.approx(0.95e-4)

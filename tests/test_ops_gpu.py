@@ -271,13 +271,37 @@ def test_losses(ops, golden_dir):
     tgt = torch.from_numpy(gold["hist_target_seed0"]).cuda()
     for name in ("randn1234", "sin"):
         mu = torch.from_numpy(gold[f"{name}_mu"]).cuda().requires_grad_(True)
-        total, parts = ops.latent_losses(mu, 32, tgt, 10.0, 100.0, 100.0)
+        total, parts, corr = ops.latent_losses(mu, 32, tgt, 10.0, 100.0, 100.0)
         total.backward()
         ref = gold[f"{name}_vals"]
         np.testing.assert_allclose(parts.cpu().numpy(), ref, rtol=2e-4)
         assert abs(float(total) - (10 * ref[0] + 100 * ref[1] + 100 * ref[2])) < 2e-4 * abs(float(total))
         gref = 10 * gold[f"{name}_dbkl"] + 100 * gold[f"{name}_dcorr"] + 100 * gold[f"{name}_dhist"]
         close(mu.grad, torch.from_numpy(gref), 5e-4)
+        close(corr, torch.from_numpy(np.corrcoef(gold[f"{name}_mu"].T)), 1e-5, 1e-6)
+    # public util.py-style entry points
+    from srgan_amd import losses as hl
+    mu = torch.from_numpy(gold["sin_mu"]).cuda()
+    close(hl.corrcoef(mu.t()), torch.from_numpy(np.corrcoef(gold["sin_mu"].T)), 1e-5, 1e-6)
+    assert abs(float(hl.corrcoef_loss(mu.t(), "cuda")) - gold["sin_vals"][1]) < 1e-5
+    torch.manual_seed(0)
+    hi = hl.histogram_imitation("cuda")                  # same CPU RNG draw as the reference constructor
+    close(hi.target, torch.from_numpy(gold["hist_target_seed0"]), 1e-5)
+    assert abs(float(hi.loss(mu)) - gold["sin_vals"][2]) < 2e-4 * gold["sin_vals"][2]
+    q = [torch.from_numpy(gold["ls_q1"]).cuda(), torch.from_numpy(gold["ls_q2"]).cuda()]
+    oh = hl.class_encode(torch.from_numpy(gold["ls_lab"]), "cuda", np.eye(4))
+    assert abs(float(hl.get_domainloss_D(q, oh, torch.nn.MSELoss())) - gold["ls_vals"][2]) < 1e-6
+    xs = torch.randn(5000, generator=torch.Generator().manual_seed(3))
+    from oracle import losses as ol
+    xd = xs.cuda().requires_grad_(True)
+    h = hl.GaussianHistogram(50, -10, 10, 0.2)(xd)
+    xr = xs.clone().requires_grad_(True)
+    hr = ol.soft_histogram(xr)
+    w = torch.linspace(0, 1, 50)
+    (h * w.cuda()).sum().backward()
+    (hr * w).sum().backward()
+    close(h, hr, 1e-5)
+    close(xd.grad, xr.grad, 1e-4)
 
 
 def test_adam_matches_torch14_math(ops):

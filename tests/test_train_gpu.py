@@ -1,0 +1,109 @@
+"""GPU: srgan_amd.SRGAN_training.train (HIP path) against the reference's own trajectories
+(tests/golden/train_*.npz, produced by running the imported reference) and against the CPU oracle.
+Bar: losses within 1e-3 relative (north_star); parameters after the steps within a few lr."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import trainer as otrainer
+from tests.common import build_hip_nets, close, close_params, oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+def run_hip(tier, batch, k, steps, seed, pretrained_e=False, size=128):
+    from srgan_amd import optim as hoptim
+    from srgan_amd.trainer import SRGAN_training
+    G, D, E = build_hip_nets(tier)
+    optE = None
+    if pretrained_e:   # 05-train cell 22: freeze trunk, Adam(lr=1e-3) over fcmean/fcvar, melt again
+        keys = [k_ for k_ in E.state_dict().keys() if not k_.startswith(("fcmean", "fcvar"))]
+        E.freeze_melt(keys, "freeze")
+        optE = hoptim.Adam(filter(lambda p: p.requires_grad, E.parameters()), lr=1e-3, betas=(0.5, 0.999))
+        E.freeze_melt(keys, "melt")
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    sg = SRGAN_training([G, D, E], [None, None, optE], [nn.MSELoss(), nn.MSELoss()], dict(otrainer.DEFAULT_LBD), k,
+                        "cuda", np.eye(4), batch, "mu", 8)
+    sg.opt_sche_initialization()
+    traj = []
+    for s in range(steps):
+        x, label = otrainer.synthetic_batch(batch, size, 4, seed=100 + s)
+        label = {"source": label["source"].cuda(), "target": label["target"]}   # as the notebook: source on device
+        errG, errD, errE = sg.train(x.cuda(), label)
+        traj.append([float(errG), float(errD), float(errE)])
+    return sg, np.array(traj)
+
+
+@pytest.mark.parametrize("name,k,steps,pre", [("train_T_b4_k2", 2, 3, False), ("train_T_b4_k5", 5, 2, False),
+                                              ("train_T_b4_k2_pretrainedE", 2, 2, True)])
+def test_train_trajectory_vs_reference_tier_T(golden_dir, name, k, steps, pre):
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    sg, traj = run_hip("T", 4, k, steps, seed=0, pretrained_e=pre)
+    close(sg.hi.target, gold["hist_target"], 1e-5, what="hist target")
+    np.testing.assert_allclose(traj, gold["losses"], rtol=1e-3)
+    lr_e = 1e-3 if pre else 1e-4
+    for net_name, net, lr, n_opt in (("G", sg.G, 1e-4, 2 * steps), ("D", sg.D, 1e-4, k * steps), ("E", sg.E, lr_e, steps)):
+        for key, v in net.state_dict().items():
+            close_params(v, gold[f"{net_name}.{key}"], lr, n_opt, what=f"{net_name}.{key}")
+
+
+def test_train_trajectory_vs_reference_full_size(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "train_F_b2_k1.npz"))
+    sg, traj = run_hip("F", 2, 1, 2, seed=0)
+    np.testing.assert_allclose(traj, gold["losses"], rtol=1e-3)
+    for net_name, net in (("G", sg.G), ("D", sg.D), ("E", sg.E)):
+        for key, v in net.state_dict().items():
+            ck = gold[f"{net_name}_ck.{key}"]
+            v = v.detach().double().cpu()
+            assert abs(float(v.norm()) - ck[1]) <= 1e-4 * max(ck[1], 1e-6), key
+            np.testing.assert_allclose(v.flatten()[:8].numpy(), ck[2:], atol=4e-4)
+
+
+def test_train_step_vs_oracle_with_loss_terms():
+    """Same seeds on both sides; compares every individual loss term of the step."""
+    PG, PD, PE = oracle_params("T")
+    torch.manual_seed(5)
+    orc = otrainer.SRGANOracle(PG, PD, PE, otrainer.DEFAULT_LBD, 3, np.eye(4), 6, "mu", 8)
+    x, label = otrainer.synthetic_batch(6, 128, 4, seed=42)
+    ref = [float(v) for v in orc.train(x, label)]
+
+    from srgan_amd.trainer import SRGAN_training
+    G, D, E = build_hip_nets("T")
+    torch.manual_seed(5)
+    sg = SRGAN_training([G, D, E], [None, None, None], [nn.MSELoss(), nn.MSELoss()], dict(otrainer.DEFAULT_LBD), 3,
+                        "cuda", np.eye(4), 6, "mu", 8)
+    sg.opt_sche_initialization()
+    out = [float(v) for v in sg.train(x.cuda(), {"source": label["source"].cuda(), "target": label["target"]})]
+    np.testing.assert_allclose(out, ref, rtol=1e-3)
+    t = {k: float(v) for k, v in sg.loss_terms.items()}
+    tr = orc.trace
+    pairs = [("errG_dis", "g_dis"), ("errG_class", "g_cls"), ("errG_cycle", "g_cyc"), ("errG_idt", "g_idt"),
+             ("errE_bKL", "bkl"), ("errE_corr", "corr"), ("errE_hist", "hist"), ("errG_reg", "g_reg"),
+             ("errG_idt_reg", "g_idt_reg")]
+    for a, b in pairs:
+        assert abs(t[a] - tr[b]) <= 1e-3 * max(abs(tr[b]), 1e-3), (a, t[a], tr[b])
+    assert abs(t["errD_real"] - tr["errD_parts"][-1][0]) <= 1e-3 * abs(tr["errD_parts"][-1][0])
+    for net, P, n_opt in ((sg.G, orc.G, 2), (sg.D, orc.D, 3), (sg.E, orc.E, 1)):
+        for key, v in net.state_dict().items():
+            close_params(v, P[key], 1e-4, n_opt, what=key)
+
+
+def test_latent_mode_and_generic_encoder_path():
+    """encoded_feature="latent": the style code is the noisy reparametrisation (RNG order matters)."""
+    PG, PD, PE = oracle_params("T")
+    lbd = dict(otrainer.DEFAULT_LBD)
+    torch.manual_seed(11)
+    orc = otrainer.SRGANOracle(PG, PD, PE, lbd, 2, np.eye(4), 4, "latent", 8)
+    x, label = otrainer.synthetic_batch(4, 128, 4, seed=7)
+    ref = [float(v) for v in orc.train(x, label)]
+    from srgan_amd.trainer import SRGAN_training
+    G, D, E = build_hip_nets("T")
+    torch.manual_seed(11)
+    sg = SRGAN_training([G, D, E], [None, None, None], [nn.MSELoss(), nn.MSELoss()], lbd, 2, "cuda", np.eye(4), 4, "latent", 8)
+    sg.opt_sche_initialization()
+    out = [float(v) for v in sg.train(x.cuda(), {"source": label["source"].cuda(), "target": label["target"]})]
+    np.testing.assert_allclose(out, ref, rtol=1e-3)
