@@ -151,6 +151,14 @@ int srgan_soft_histogram_bwd(const float* x, const float* g, long long n, int bi
 int srgan_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                     float beta2, float eps, int step_count, void* stream);
 
+/* ---- launch timer for bench.py's roofline leg (no reference counterpart) ---------------------
+ * While enabled every implicit-GEMM / weight-gradient launch is bracketed by HIP events on its own
+ * stream and tagged with its algorithmic FLOPs (2*N*Ho*Wo*O*kh*kw*I).  Collect after a device sync. */
+int srgan_prof_enable(int on);
+int srgan_prof_num_kernels(void);
+const char* srgan_prof_kernel_name(int kid);
+int srgan_prof_collect(int kid, double* total_ms, long long* launches, double* total_flops);
+
 #ifdef __cplusplus
 }
 #endif

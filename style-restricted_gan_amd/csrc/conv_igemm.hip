@@ -19,9 +19,46 @@
 // flight while the current tile is multiplied.  Within a 32-deep K tile lane (r, h) feeds the
 // MFMA k-slots {8q+4h+e} so that A and B fragments come from single ds_read_b128's.
 #include <algorithm>
+#include <string>
+#include <vector>
 #include "common.h"
 
 namespace srgan {
+
+// ---- optional in-process launch timer (bench.py roofline leg) -------------------------------
+// When enabled, every implicit-GEMM launch is bracketed by HIP events on ITS stream; durations are
+// read back after the timed region.  Off by default: no events, no overhead.
+struct ProfSlot { hipEvent_t a, b; int kid; double flops; };
+static bool g_prof_on = false;
+static std::vector<ProfSlot> g_prof_slots;      // used slots of the current session
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+static size_t g_prof_next = 0;
+static const char* const kProfNames[] = {
+    "igemm_kernel<128,128,2,2,gen>", "igemm_kernel<128,128,2,2,vec>", "igemm_kernel<128,64,2,2,gen>", "igemm_kernel<128,64,2,2,vec>",
+    "igemm_kernel<128,32,4,1,gen>",  "igemm_kernel<128,32,4,1,vec>",  "igemm_kernel<64,64,2,2,gen>",  "igemm_kernel<64,64,2,2,vec>",
+    "wgrad_kernel<gen>", "wgrad_kernel<vec>"};
+constexpr int kProfKernels = 10;
+
+struct ProfScope {
+  bool on;
+  hipStream_t st;
+  size_t idx;
+  ProfScope(int kid, double flops, hipStream_t s) : on(g_prof_on), st(s), idx(0) {
+    if (!on) return;
+    if (g_prof_next == g_prof_pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+      g_prof_pool.emplace_back(a, b);
+    }
+    auto& ev = g_prof_pool[g_prof_next++];
+    g_prof_slots.push_back({ev.first, ev.second, kid, flops});
+    idx = g_prof_slots.size() - 1;
+    (void)hipEventRecord(ev.first, st);
+  }
+  ~ProfScope() {
+    if (on) (void)hipEventRecord(g_prof_slots[idx].b, st);
+  }
+};
 
 struct IgemmParams {
   const float* src;
@@ -495,7 +532,9 @@ TileChoice choose_tile(long long M, int N) {
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_igemm(const IgemmParams& p, int phases, bool vec, hipStream_t st) {
+int launch_igemm(const IgemmParams& p, int phases, bool vec, hipStream_t st, double flops) {
+  constexpr int tile_id = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 128 && BN == 32) ? 2 : 3;
+  ProfScope scope(tile_id * 2 + (vec ? 1 : 0), flops, st);
   dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)phases, 1);
   if (vec)
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, p);
@@ -504,20 +543,25 @@ int launch_igemm(const IgemmParams& p, int phases, bool vec, hipStream_t st) {
   return check_launch("igemm_kernel");
 }
 
-int run_igemm(IgemmParams p, int phases, hipStream_t st) {
+int run_igemm(IgemmParams p, int phases, hipStream_t st, double flops) {
   TileChoice tc = choose_tile(p.M, p.Cd);
   p.m_tiles = (int)ceil_div(p.M, tc.BM);
   p.n_tiles = (int)ceil_div(p.Cd, tc.BN);
   const bool vec = (p.Cs % BK) == 0;
-  if (tc.BM == 128 && tc.BN == 128) return launch_igemm<128, 128, 2, 2>(p, phases, vec, st);
-  if (tc.BM == 128 && tc.BN == 64) return launch_igemm<128, 64, 2, 2>(p, phases, vec, st);
-  if (tc.BM == 128 && tc.BN == 32) return launch_igemm<128, 32, 4, 1>(p, phases, vec, st);
-  return launch_igemm<64, 64, 2, 2>(p, phases, vec, st);
+  if (tc.BM == 128 && tc.BN == 128) return launch_igemm<128, 128, 2, 2>(p, phases, vec, st, flops);
+  if (tc.BM == 128 && tc.BN == 64) return launch_igemm<128, 64, 2, 2>(p, phases, vec, st, flops);
+  if (tc.BM == 128 && tc.BN == 32) return launch_igemm<128, 32, 4, 1>(p, phases, vec, st, flops);
+  return launch_igemm<64, 64, 2, 2>(p, phases, vec, st, flops);
 }
 
 int npad_for(long long M, int N) {
   TileChoice tc = choose_tile(M, N);
   return (int)round_up(N, tc.BN);
+}
+
+// algorithmic FLOPs of one conv pass: 2 * (N*Ho*Wo) * O * (kh*kw*I)
+double conv_flops(const srgan_conv_desc* d) {
+  return 2.0 * d->N * d->Ho * d->Wo * (double)d->O * d->kh * d->kw * d->I;
 }
 
 int validate(const srgan_conv_desc* d) {
@@ -617,7 +661,7 @@ extern "C" int srgan_conv2d_fwd(const srgan_conv_desc* d, const float* x, const 
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
   if (int e = check_launch("pack_weights_kernel")) return e;
   p.wp = (const float*)ws;
-  return run_igemm(p, 1, st);
+  return run_igemm(p, 1, st, conv_flops(d));
 }
 
 extern "C" int srgan_conv2d_dgrad(const srgan_conv_desc* d, const float* dy, const float* w, float* dx,
@@ -656,7 +700,7 @@ extern "C" int srgan_conv2d_dgrad(const srgan_conv_desc* d, const float* dy, con
   if (int e = check_launch("pack_weights_kernel")) return e;
   p.wp = packed;
   p.dst = reflect ? padded : dx;
-  if (int e = run_igemm(p, phases, st)) return e;
+  if (int e = run_igemm(p, phases, st, conv_flops(d))) return e;
   if (reflect) {
     long long n = (long long)d->N * d->Hi * d->Wi * d->I;
     hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 256), 8192)), dim3(256), 0, st,
@@ -669,6 +713,7 @@ extern "C" int srgan_conv2d_dgrad(const srgan_conv_desc* d, const float* dy, con
 namespace srgan {
 template <int BMc, int BNn, int WM, int WN>
 static int launch_wgrad(const WgradParams& p, const WgradPlan& w, hipStream_t st) {
+  ProfScope scope(8 + (w.vec ? 1 : 0), 2.0 * p.M * (double)p.Cd * p.NN, st);
   dim3 grid((unsigned)(w.co_tiles * w.nn_tiles), (unsigned)w.splits, 1);
   if (w.vec)
     hipLaunchKernelGGL((wgrad_kernel<BMc, BNn, WM, WN, true>), grid, dim3(256), 0, st, p);
@@ -721,5 +766,34 @@ extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, cons
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(d->O, 64)), dim3(64), 0, st, (const float*)part, dbias, d->O, nparts);
     return check_launch("colsum_final_kernel");
   }
+  return 0;
+}
+
+// ---- launch-timer API (used only by bench.py) ------------------------------------------------
+extern "C" int srgan_prof_enable(int on) {
+  if (on) {
+    g_prof_slots.clear();
+    g_prof_next = 0;
+  }
+  g_prof_on = on != 0;
+  return 0;
+}
+extern "C" int srgan_prof_num_kernels(void) { return kProfKernels; }
+extern "C" const char* srgan_prof_kernel_name(int kid) {
+  return (kid >= 0 && kid < kProfKernels) ? kProfNames[kid] : "";
+}
+// Totals of the session for one kernel id; call after the streams have been synchronised.
+extern "C" int srgan_prof_collect(int kid, double* total_ms, long long* launches, double* total_flops) {
+  SRGAN_REQUIRE(total_ms && launches && total_flops, "prof_collect: null pointer");
+  double ms = 0.0, fl = 0.0;
+  long long n = 0;
+  for (const ProfSlot& s : g_prof_slots) {
+    if (s.kid != kid) continue;
+    float t = 0.f;
+    hipError_t e = hipEventElapsedTime(&t, s.a, s.b);
+    if (e != hipSuccess) { set_error("prof_collect: %s", hipGetErrorString(e)); return (int)e; }
+    ms += t; fl += s.flops; ++n;
+  }
+  *total_ms = ms; *launches = n; *total_flops = fl;
   return 0;
 }

@@ -59,6 +59,10 @@ SIGNATURES = {
     "srgan_soft_histogram_workspace": (c_size_t, [c_longlong, c_int]),
     "srgan_soft_histogram_fwd": (c_int, [P, c_longlong, c_int, c_float, c_float, c_float, P, P, c_size_t, P]),
     "srgan_soft_histogram_bwd": (c_int, [P, P, c_longlong, c_int, c_float, c_float, c_float, P, P]),
+    "srgan_prof_enable": (c_int, [c_int]),
+    "srgan_prof_num_kernels": (c_int, []),
+    "srgan_prof_kernel_name": (ctypes.c_char_p, [c_int]),
+    "srgan_prof_collect": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_longlong), POINTER(ctypes.c_double)]),
     "srgan_adam_step": (c_int, [P, P, P, P, c_longlong, c_float, c_float, c_float, c_float, c_int, P]),
 }
 
