@@ -1,0 +1,103 @@
+"""CPU, world_size=2 (gloo): the data-parallel plumbing of srgan_amd.dp.
+
+* GradReducer averages gradients across ranks (several buckets, a parameter without grad on one rank);
+* all_gather_rows is differentiable and hands every rank its own rows of the gradient;
+* the convention used by SRGAN_training for the GLOBAL-batch latent losses (evaluate on the gathered mu on every
+  rank, scale by world size, then average-all-reduce) reproduces the single-process gradient exactly, together with
+  per-sample-mean losses -- checked with the oracle's loss functions on a toy encoder.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _toy_losses(theta, bias, x, n_batch, mu_all_fn, ws_scale):
+    from oracle import losses as ol
+    mu = x @ theta + bias                                 # "encoder": [B_local, 8]
+    per_sample = (mu ** 2).mean()                         # stands for the image-mean losses (L1 / LSGAN)
+    mu_all = mu_all_fn(mu)
+    tgt = ol.analytic_hist_target()
+    latent = 10.0 * ol.batch_kl(mu_all, n_batch) + 100.0 * ol.corr_loss(mu_all.t()) + 100.0 * ol.HistogramImitation(target=tgt).loss(mu_all)
+    return per_sample + latent * ws_scale
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from srgan_amd import dp
+    r, w, device = dp.init_from_env("gloo")
+    assert (r, w) == (rank, world) and device.type == "cpu" and dp.is_distributed() and dp.world_size() == 2
+
+    # 1. GradReducer with tiny buckets and a missing grad
+    dp.BUCKET_BYTES = 64
+    params = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(7))]
+    params[0].grad = torch.full((5,), float(rank + 1))
+    params[1].grad = torch.arange(12.0).view(3, 4) * (rank + 1)
+    if rank == 0:
+        params[2].grad = torch.ones(7)
+    red = dp.GradReducer(params)
+    assert len(red._buckets()) == 3
+    red.reduce()
+    assert torch.allclose(params[0].grad, torch.full((5,), 1.5))
+    assert torch.allclose(params[1].grad, torch.arange(12.0).view(3, 4) * 1.5)
+    assert torch.allclose(params[2].grad, torch.full((7,), 0.5))
+
+    # 2. all_gather_rows forward / backward
+    x = (torch.arange(6.0).view(3, 2) + 10 * rank).requires_grad_(True)
+    g = dp.all_gather_rows(x)
+    assert g.shape == (6, 2) and torch.equal(g[3 * rank:3 * rank + 3], x.detach())
+    (g * torch.arange(12.0).view(6, 2)).sum().backward()
+    assert torch.equal(x.grad, torch.arange(12.0).view(6, 2)[3 * rank:3 * rank + 3])
+
+    # 3. DP gradient == single-process gradient for per-sample-mean + global-batch latent losses
+    gen = torch.Generator().manual_seed(0)
+    X = torch.randn(8, 5, generator=gen)
+    theta0, bias0 = torch.randn(5, 8, generator=gen) * 0.5, torch.randn(8, generator=gen) * 0.1
+    theta, bias = theta0.clone().requires_grad_(True), bias0.clone().requires_grad_(True)
+    loss = _toy_losses(theta, bias, X[4 * rank:4 * rank + 4], 8, dp.all_gather_rows, float(world))
+    loss.backward()
+    dp.BUCKET_BYTES = 64 << 20
+    dp.GradReducer([theta, bias]).reduce()
+    t1, b1 = theta0.clone().requires_grad_(True), bias0.clone().requires_grad_(True)
+    _toy_losses(t1, b1, X, 8, lambda m: m, 1.0).backward()
+    err = max(float((theta.grad - t1.grad).abs().max()), float((bias.grad - b1.grad).abs().max()))
+    out.put((rank, err, float(t1.grad.abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, scale in res:
+        assert err <= 1e-5 * scale, (rank, err, scale)
+
+
+def test_single_process_is_a_no_op():
+    from srgan_amd import dp
+    assert not dp.is_distributed() and dp.world_size() == 1 and dp.rank() == 0
+    x = torch.ones(2, 3, requires_grad=True)
+    assert dp.all_gather_rows(x) is x
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.ones(3)
+    dp.GradReducer([p]).reduce()
+    assert torch.equal(p.grad, torch.ones(3))
