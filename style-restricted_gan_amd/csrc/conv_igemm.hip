@@ -348,9 +348,11 @@ struct WgradParams {
 template <int BMc, int BNn, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   constexpr int TM = BMc / (WM * 32), TN = BNn / (WN * 32);
+  constexpr int A_IT = BMc / 32, B_IT = BNn / 32;     // float4 per thread per 32-row tile
+  constexpr int A_PR = BMc / 4, B_PR = BNn / 4;       // float4 per tile row
   __shared__ __attribute__((aligned(16))) float As[32 * BMc];
   __shared__ __attribute__((aligned(16))) float Bs[32 * BNn];
-  __shared__ int row_n[32], row_y[32], row_x[32];
+  __shared__ int rowtab[2][3][32];
 
   const int tid = threadIdx.x;
   const int ct = blockIdx.x % p.co_tiles, nt = blockIdx.x / p.co_tiles;
@@ -358,11 +360,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const int co0 = ct * BMc, nn0 = nt * BNn;
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int ntiles = (m_end - m_begin + 31) / 32;
 
   const int wave = tid >> 6, lane = tid & 63;
   const bool active = wave < WM * WN;   // small tiles use fewer than 4 MFMA waves
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 31, lh = lane >> 5;
+  const bool cd_vec = (p.Cd & 3) == 0;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -372,94 +376,123 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const bool cd_vec = (p.Cd & 3) == 0;
+  f32x4 a_reg[A_IT], b_reg[B_IT];
 
-  for (int mb = m_begin; mb < m_end; mb += 32) {
-    __syncthreads();  // previous tile fully consumed
-    if (tid < 32) {
-      const int m = mb + tid;
-      int n = 0, y0 = -(1 << 28), x0 = -(1 << 28);
+  auto fill_rowtab = [&](int t) {     // decode the 32 pixels of tile t (tid < 32 only)
+    const int m = m_begin + t * 32 + tid;
+    int n = 0, y0 = -(1 << 28), x0 = -(1 << 28);
+    if (m < m_end) {
+      n = m / (p.Hg * p.Wg);
+      int rem = m - n * (p.Hg * p.Wg);
+      int a = rem / p.Wg, b = rem - a * p.Wg;
+      y0 = a * p.stride - p.pad; x0 = b * p.stride - p.pad;
+    }
+    rowtab[t & 1][0][tid] = n; rowtab[t & 1][1][tid] = y0; rowtab[t & 1][2][tid] = x0;
+  };
+
+  auto gather = [&](int buf, int r, int ty, int tx, bool& ok) -> size_t {
+    int y = rowtab[buf][1][r] + ty, x = rowtab[buf][2][r] + tx;
+    if (p.reflect) {
+      if (y < 0) y = -y;
+      if (y >= p.Hi) y = 2 * p.Hi - 2 - y;
+      if (x < 0) x = -x;
+      if (x >= p.Wi) x = 2 * p.Wi - 2 - x;
+    }
+    ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+    return ((size_t)(rowtab[buf][0][r] * p.Hi + y) * p.Wi + x) * p.Cs;
+  };
+
+  auto load_tile = [&](int t) {
+    const int mb = m_begin + t * 32, buf = t & 1;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx / A_PR, c4 = idx - r * A_PR;
+      const int m = mb + r, co = co0 + c4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (m < m_end) {
-        n = m / (p.Hg * p.Wg);
-        int rem = m - n * (p.Hg * p.Wg);
-        int a = rem / p.Wg, b = rem - a * p.Wg;
-        y0 = a * p.stride - p.pad; x0 = b * p.stride - p.pad;
+        const float* src = p.dy + (size_t)m * p.Cd + co;
+        if (cd_vec) {
+          if (co < p.Cd) v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < p.Cd) v[e] = src[e];
+        }
       }
-      row_n[tid] = n; row_y[tid] = y0; row_x[tid] = x0;
+      a_reg[i] = v;
     }
-    // A' tile: dy rows (dense)
-    if (cd_vec) {
-      constexpr int PER_ROW = BMc / 4;
-      for (int idx = tid; idx < 32 * PER_ROW; idx += 256) {
-        const int r = idx / PER_ROW, c4 = idx - r * PER_ROW;
-        const int m = mb + r, co = co0 + c4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < m_end && co < p.Cd) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cd + co);
-        *reinterpret_cast<f32x4*>(&As[r * BMc + c4 * 4]) = v;
-      }
-    } else {
-      for (int idx = tid; idx < 32 * BMc; idx += 256) {
-        const int r = idx / BMc, c = idx - r * BMc;
-        const int m = mb + r, co = co0 + c;
-        As[idx] = (m < m_end && co < p.Cd) ? p.dy[(size_t)m * p.Cd + co] : 0.f;
-      }
-    }
-    __syncthreads();  // row table visible
     if constexpr (VEC) {
-      const int t = nn0 / p.Cs, c0 = nn0 - t * p.Cs;
-      const int ty = t / p.kw, tx = t - ty * p.kw;
-      constexpr int PER_ROW = BNn / 4;
-      for (int idx = tid; idx < 32 * PER_ROW; idx += 256) {
-        const int r = idx / PER_ROW, c4 = idx - r * PER_ROW;
-        int y = row_y[r] + ty, x = row_x[r] + tx;
-        if (p.reflect) {
-          if (y < 0) y = -y;
-          if (y >= p.Hi) y = 2 * p.Hi - 2 - y;
-          if (x < 0) x = -x;
-          if (x >= p.Wi) x = 2 * p.Wi - 2 - x;
-        }
+      const int tp = nn0 / p.Cs, c0 = nn0 - tp * p.Cs;
+      const int ty = tp / p.kw, tx = tp - ty * p.kw;
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx / B_PR, c4 = idx - r * B_PR;
+        bool ok;
+        const size_t off = gather(buf, r, ty, tx, ok);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi && nn0 < p.NN)
-          v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(row_n[r] * p.Hi + y) * p.Wi + x) * p.Cs + c0 + c4 * 4);
-        *reinterpret_cast<f32x4*>(&Bs[r * BNn + c4 * 4]) = v;
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.x + off + c0 + c4 * 4);
+        b_reg[i] = v;
       }
     } else {
-      for (int idx = tid; idx < 32 * BNn; idx += 256) {
-        const int r = idx / BNn, j = idx - r * BNn;
-        const int nn = nn0 + j;
-        float v = 0.f;
-        if (nn < p.NN) {
-          const int t = nn / p.Cs, c = nn - t * p.Cs;
-          const int ty = t / p.kw, tx = t - ty * p.kw;
-          int y = row_y[r] + ty, x = row_x[r] + tx;
-          if (p.reflect) {
-            if (y < 0) y = -y;
-            if (y >= p.Hi) y = 2 * p.Hi - 2 - y;
-            if (x < 0) x = -x;
-            if (x >= p.Wi) x = 2 * p.Wi - 2 - x;
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx / B_PR, c4 = idx - r * B_PR;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int nn = nn0 + c4 * 4 + e;
+          if (nn < p.NN) {
+            const int tp = nn / p.Cs, c = nn - tp * p.Cs;
+            const int ty = tp / p.kw, tx = tp - ty * p.kw;
+            bool ok;
+            const size_t off = gather(buf, r, ty, tx, ok);
+            if (ok) v[e] = p.x[off + c];
           }
-          if ((unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi)
-            v = p.x[((size_t)(row_n[r] * p.Hi + y) * p.Wi + x) * p.Cs + c];
         }
-        Bs[idx] = v;
+        b_reg[i] = v;
       }
     }
+  };
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(&As[(tid + 256 * i) * 4]) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(&Bs[(tid + 256 * i) * 4]) = b_reg[i];
+  };
+
+  if (ntiles > 0) {
+    if (tid < 32) fill_rowtab(0);
     __syncthreads();
+    load_tile(0);
+    if (ntiles > 1 && tid < 32) fill_rowtab(1);
+  }
+  for (int t = 0; t < ntiles; ++t) {
+    store_tile();
+    __syncthreads();                    // tile t in LDS; rowtab[(t+1)&1] visible
+    if (t + 1 < ntiles) {
+      load_tile(t + 1);                 // global loads in flight during the MFMAs below
+    }
     if (active) {
 #pragma unroll
-    for (int kp = 0; kp < 16; ++kp) {
-      float af[TM], bf[TN];
+      for (int kp = 0; kp < 16; ++kp) {
+        float af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = As[(2 * kp + lh) * BMc + wm * TM * 32 + i * 32 + lr];
+        for (int i = 0; i < TM; ++i) af[i] = As[(2 * kp + lh) * BMc + wm * TM * 32 + i * 32 + lr];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * kp + lh) * BNn + wn * TN * 32 + j * 32 + lr];
+        for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * kp + lh) * BNn + wn * TN * 32 + j * 32 + lr];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
     }
-    }
+    __syncthreads();                    // LDS consumed; rowtab[t&1] no longer needed by load_tile(t+1)
+    if (t + 2 < ntiles && tid < 32) fill_rowtab(t + 2);
   }
 
   if (!active) return;
@@ -588,10 +621,9 @@ WgradPlan plan_wgrad(const srgan_conv_desc* d) {
   const int NN = d->kh * d->kw * d->I;
   w.BMc = d->O <= 32 ? 32 : (d->O <= 64 ? 64 : 128);
   w.vec = (d->I % 32) == 0;
-  if (w.vec) w.BNn = (d->I % 128 == 0 && w.BMc <= 64) ? 128 : ((d->I % 64 == 0) ? 64 : 32);
+  if (w.vec) w.BNn = (d->I % 128 == 0) ? 128 : ((d->I % 64 == 0) ? 64 : 32);
   else w.BNn = 64;
-  if (w.BMc == 128 && w.BNn > 64) w.BNn = 64;
-  // supported shapes: (128,64) (64,128) (64,64) (32,128) (32,64) (64,32) (32,32)
+  // supported shapes: (128,128) (128,64) (128,32) (64,128) (64,64) (64,32) (32,128) (32,64) (32,32)
   w.co_tiles = (int)ceil_div(d->O, w.BMc);
   w.nn_tiles = (int)ceil_div(NN, w.BNn);
   w.Cdpad = w.co_tiles * w.BMc;
@@ -634,6 +666,7 @@ extern "C" size_t srgan_conv2d_workspace(const srgan_conv_desc* d) {
   size_t wg = (size_t)w.splits * w.Cdpad * w.NNpad * sizeof(float);
   size_t cs = (size_t)1024 * d->O * sizeof(float);
   if (wg + cs > bytes) bytes = wg + cs;
+  if (narrow_applicable(d)) bytes = std::max(bytes, narrow_workspace(d) + cs);
   return bytes + 4096;
 }
 
@@ -643,6 +676,7 @@ extern "C" int srgan_conv2d_fwd(const srgan_conv_desc* d, const float* x, const 
   SRGAN_REQUIRE(x && w && y && ws, "conv2d_fwd: null pointer");
   SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_fwd: workspace too small");
   hipStream_t st = as_stream(stream);
+  if (act == SRGAN_ACT_NONE && narrow_applicable(d)) return narrow_fwd(d, x, w, bias, y, ws, st);
   IgemmParams p{};
   p.src = x; p.bias = bias; p.dst = y;
   p.NB = d->N; p.Hs = d->Hi; p.Ws = d->Wi; p.Cs = d->I;
@@ -661,6 +695,7 @@ extern "C" int srgan_conv2d_fwd(const srgan_conv_desc* d, const float* x, const 
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
   if (int e = check_launch("pack_weights_kernel")) return e;
   p.wp = (const float*)ws;
+  if (act == SRGAN_ACT_NONE && dense_head_applicable(d)) return dense_head_fwd(d, x, p.wp, p.Kpad, bias, y, st);
   return run_igemm(p, 1, st, conv_flops(d));
 }
 
@@ -723,31 +758,10 @@ static int launch_wgrad(const WgradParams& p, const WgradPlan& w, hipStream_t st
 }
 }  // namespace srgan
 
-extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, const float* dy, float* dw,
-                                  float* dbias, void* ws, size_t ws_bytes, void* stream) {
-  if (int e = validate(d)) return e;
-  SRGAN_REQUIRE(x && dy && dw && ws, "conv2d_wgrad: null pointer");
-  SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_wgrad: workspace too small");
-  hipStream_t st = as_stream(stream);
-  WgradPlan w = plan_wgrad(d);
-  WgradParams p{};
-  p.x = x; p.dy = dy; p.slab = (float*)ws;
-  p.NB = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cs = d->I; p.Hg = d->Ho; p.Wg = d->Wo; p.Cd = d->O;
-  p.stride = d->stride; p.pad = d->pad; p.kw = d->kw; p.reflect = d->pad_mode == SRGAN_PAD_REFLECT;
-  p.NN = d->kh * d->kw * d->I; p.NNpad = w.NNpad; p.Cdpad = w.Cdpad;
-  p.M = d->N * d->Ho * d->Wo; p.rows_per_split = w.rows_per_split;
-  p.co_tiles = w.co_tiles; p.nn_tiles = w.nn_tiles;
-  int e = -1;
-  if (w.BMc == 128 && w.BNn == 64) e = launch_wgrad<128, 64, 2, 2>(p, w, st);
-  else if (w.BMc == 64 && w.BNn == 128) e = launch_wgrad<64, 128, 2, 2>(p, w, st);
-  else if (w.BMc == 64 && w.BNn == 64) e = launch_wgrad<64, 64, 2, 2>(p, w, st);
-  else if (w.BMc == 64 && w.BNn == 32) e = launch_wgrad<64, 32, 2, 1>(p, w, st);
-  else if (w.BMc == 32 && w.BNn == 128) e = launch_wgrad<32, 128, 1, 4>(p, w, st);
-  else if (w.BMc == 32 && w.BNn == 64) e = launch_wgrad<32, 64, 1, 2>(p, w, st);
-  else if (w.BMc == 32 && w.BNn == 32) e = launch_wgrad<32, 32, 1, 1>(p, w, st);
-  else if (w.BMc == 128 && w.BNn == 32) e = launch_wgrad<128, 32, 4, 1>(p, w, st);
-  else { set_error("wgrad: unsupported tile %dx%d", w.BMc, w.BNn); return -1; }
-  if (e) return e;
+namespace srgan {
+// slab sum -> dW (through the weight strides) and optional bias column sums
+static int finish_wgrad(const srgan_conv_desc* d, const WgradPlan& w, const float* dy, float* dw, float* dbias, void* ws,
+                        hipStream_t st) {
   WgradReduceParams r{};
   r.slab = (const float*)ws; r.dw = dw; r.sO = d->sO; r.sI = d->sI; r.sH = d->sH; r.sW = d->sW;
   r.O = d->O; r.I = d->I; r.kh = d->kh; r.kw = d->kw; r.splits = w.splits; r.Cdpad = w.Cdpad; r.NNpad = w.NNpad;
@@ -755,8 +769,8 @@ extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, cons
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, r);
   if (int e2 = check_launch("wgrad_reduce_kernel")) return e2;
   if (dbias) {
+    const int M = d->N * d->Ho * d->Wo;
     float* part = (float*)ws + (size_t)w.splits * w.Cdpad * w.NNpad;
-    const int M = p.M;
     int nparts = (int)std::min<long long>(1024, ceil_div(M, 64));
     int rpb = (int)ceil_div(M, nparts);
     nparts = (int)ceil_div(M, rpb);
@@ -767,6 +781,42 @@ extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, cons
     return check_launch("colsum_final_kernel");
   }
   return 0;
+}
+}  // namespace srgan
+
+extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, const float* dy, float* dw,
+                                  float* dbias, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(x && dy && dw && ws, "conv2d_wgrad: null pointer");
+  SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_wgrad: workspace too small");
+  hipStream_t st = as_stream(stream);
+  WgradPlan w = plan_wgrad(d);
+  if (narrow_applicable(d)) {
+    int n_slabs = 0;
+    if (int e = narrow_wgrad(d, x, dy, ws, &n_slabs, st)) return e;
+    w.splits = n_slabs; w.Cdpad = 4; w.NNpad = d->kh * d->kw * d->I;
+    return finish_wgrad(d, w, dy, dw, dbias, ws, st);
+  }
+  WgradParams p{};
+  p.x = x; p.dy = dy; p.slab = (float*)ws;
+  p.NB = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cs = d->I; p.Hg = d->Ho; p.Wg = d->Wo; p.Cd = d->O;
+  p.stride = d->stride; p.pad = d->pad; p.kw = d->kw; p.reflect = d->pad_mode == SRGAN_PAD_REFLECT;
+  p.NN = d->kh * d->kw * d->I; p.NNpad = w.NNpad; p.Cdpad = w.Cdpad;
+  p.M = d->N * d->Ho * d->Wo; p.rows_per_split = w.rows_per_split;
+  p.co_tiles = w.co_tiles; p.nn_tiles = w.nn_tiles;
+  int e = -1;
+  if (w.BMc == 128 && w.BNn == 128) e = launch_wgrad<128, 128, 2, 2>(p, w, st);
+  else if (w.BMc == 128 && w.BNn == 64) e = launch_wgrad<128, 64, 2, 2>(p, w, st);
+  else if (w.BMc == 64 && w.BNn == 128) e = launch_wgrad<64, 128, 2, 2>(p, w, st);
+  else if (w.BMc == 64 && w.BNn == 64) e = launch_wgrad<64, 64, 2, 2>(p, w, st);
+  else if (w.BMc == 64 && w.BNn == 32) e = launch_wgrad<64, 32, 2, 1>(p, w, st);
+  else if (w.BMc == 32 && w.BNn == 128) e = launch_wgrad<32, 128, 1, 4>(p, w, st);
+  else if (w.BMc == 32 && w.BNn == 64) e = launch_wgrad<32, 64, 1, 2>(p, w, st);
+  else if (w.BMc == 32 && w.BNn == 32) e = launch_wgrad<32, 32, 1, 1>(p, w, st);
+  else if (w.BMc == 128 && w.BNn == 32) e = launch_wgrad<128, 32, 4, 1>(p, w, st);
+  else { set_error("wgrad: unsupported tile %dx%d", w.BMc, w.BNn); return -1; }
+  if (e) return e;
+  return finish_wgrad(d, w, dy, dw, dbias, ws, st);
 }
 
 // ---- launch-timer API (used only by bench.py) ------------------------------------------------

@@ -187,17 +187,21 @@ __global__ void cbin_affine_fwd_kernel(const float* c, const float* W, const flo
   shift[idx] = tv * gamma[ch] + beta[ch];
 }
 
-// one thread per channel: dgamma, dbeta, dW row, db ; also writes da[N][C] for the dc pass
-__global__ void cbin_affine_bwd_ch(const float* c, const float* gamma, const float* t, const float* dscale,
-                                   const float* dshift, float* dgamma, float* dbeta, float* dW, float* db, float* da,
-                                   int N, int C, int nc) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+// one WAVE per channel: lanes stride over the batch, 64-lane shuffle reductions for dgamma, dbeta, db and
+// the num_con entries of the dW row; also writes da[N][C] for the dc pass.
+__global__ __launch_bounds__(256) void cbin_affine_bwd_ch(const float* c, const float* gamma, const float* t,
+                                                          const float* dscale, const float* dshift, float* dgamma,
+                                                          float* dbeta, float* dW, float* db, float* da, int N, int C,
+                                                          int nc) {
+  const int ch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
   if (ch >= C) return;
   float dg = 0.f, dbt = 0.f, dbb = 0.f;
   float dw[16];
-  for (int j = 0; j < nc; ++j) dw[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dw[j] = 0.f;
   const float g = gamma[ch];
-  for (int n = 0; n < N; ++n) {
+  for (int n = lane; n < N; n += 64) {
     const int i = n * C + ch;
     const float tv = t[i], ds = dshift[i];
     dg += dscale[i] + ds * tv;
@@ -205,21 +209,46 @@ __global__ void cbin_affine_bwd_ch(const float* c, const float* gamma, const flo
     const float a = g * ds * (1.f - tv * tv);
     da[i] = a;
     dbb += a;
-    for (int j = 0; j < nc; ++j) dw[j] += a * c[n * nc + j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nc) dw[j] += a * c[n * nc + j];
   }
-  dgamma[ch] = dg;
-  dbeta[ch] = dbt;
-  db[ch] = dbb;
-  for (int j = 0; j < nc; ++j) dW[ch * nc + j] = dw[j];
+  dg = wave_sum(dg);
+  dbt = wave_sum(dbt);
+  dbb = wave_sum(dbb);
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < nc) dw[j] = wave_sum(dw[j]);
+  if (lane == 0) {
+    dgamma[ch] = dg;
+    dbeta[ch] = dbt;
+    db[ch] = dbb;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < nc && lane == j) dW[ch * nc + j] = dw[j];
 }
 
-__global__ void cbin_affine_bwd_c(const float* W, const float* da, float* dc, int N, int C, int nc) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * nc) return;
-  const int n = idx / nc, j = idx - n * nc;
-  float s = 0.f;
-  for (int ch = 0; ch < C; ++ch) s += da[n * C + ch] * W[ch * nc + j];
-  dc[idx] = s;
+// one WAVE per sample: dc[n][j] = sum_ch da[n][ch] * W[ch][j]
+__global__ __launch_bounds__(256) void cbin_affine_bwd_c(const float* W, const float* da, float* dc, int N, int C, int nc) {
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int ch = lane; ch < C; ch += 64) {
+    const float a = da[n * C + ch];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nc) acc[j] += a * W[ch * nc + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < nc) {
+      const float v = wave_sum(acc[j]);
+      if (lane == j) dc[n * nc + j] = v;
+    }
 }
 
 namespace {
@@ -310,7 +339,7 @@ extern "C" int srgan_cbin_affine_bwd(const float* c, const float* W, const float
   hipStream_t st = as_stream(stream);
   SRGAN_REQUIRE(ws && ws_bytes >= (size_t)N * C * sizeof(float), "cbin_affine_bwd: workspace too small (N*C floats)");
   float* da = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(cbin_affine_bwd_ch, dim3((C + 63) / 64), dim3(64), 0, st, c, gamma, t, dscale, dshift, dgamma, dbeta, dW, db, da, N, C, num_con);
-  hipLaunchKernelGGL(cbin_affine_bwd_c, dim3((N * num_con + 255) / 256), dim3(256), 0, st, W, (const float*)da, dc, N, C, num_con);
+  hipLaunchKernelGGL(cbin_affine_bwd_ch, dim3((C + 3) / 4), dim3(256), 0, st, c, gamma, t, dscale, dshift, dgamma, dbeta, dW, db, da, N, C, num_con);
+  hipLaunchKernelGGL(cbin_affine_bwd_c, dim3((N + 3) / 4), dim3(256), 0, st, W, (const float*)da, dc, N, C, num_con);
   return check_launch("cbin_affine_bwd");
 }

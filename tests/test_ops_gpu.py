@@ -47,12 +47,18 @@ CONV_CASES = [
     (2, 32, 6, 6, 64, 1, 1, 0, False, True),      # 1x1 shortcut with bias
     (1, 16, 10, 10, 32, 4, 2, 1, False, False),   # generic channels, stride 2
     (2, 160, 6, 6, 96, 3, 1, 1, False, False),    # non power-of-two channels (vector path, N mask)
+    (2, 64, 64, 64, 3, 7, 1, 3, False, False),    # narrow-output direct kernels (G RGB head), exact tiles
+    (2, 32, 67, 45, 1, 4, 1, 1, False, True),     # narrow-output, ragged tiles, Cout=1 + bias
+    (3, 16, 40, 72, 4, 3, 1, 1, False, True),     # narrow-output, Cout=4, one channel chunk
+    (4, 128, 48, 48, 256, 3, 1, 1, False, False), # 128x128 block tiles on both GEMM kernels, split-K > 1
+    (8, 64, 64, 64, 64, 4, 2, 1, False, False),   # 128x64 tiles, many M tiles
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_fwd_bwd(ops, case):
     n, i, h, w, o, k, s, p, reflect, has_bias = case
+    torch.set_num_threads(16)
     x = rnd(n, i, h, w, seed=1).requires_grad_(True)
     wt = (rnd(o, i, k, k, seed=2) / np.sqrt(i * k * k)).requires_grad_(True)
     b = (rnd(o, seed=3) * 0.1).requires_grad_(True) if has_bias else None
