@@ -1,0 +1,39 @@
+"""Micro-benchmark of the implicit-GEMM kernels on the SRGAN layer shapes (B=32)."""
+import sys, os, ctypes, time
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "style-restricted_gan_amd"))
+import torch
+from srgan_amd import ops, _lib
+lib = _lib.load()
+B = int(os.environ.get("B", "32"))
+REP = int(os.environ.get("REP", "10"))
+shapes = [  # name, Cin, H, Cout, k, s, p
+    ("G.res 256->256 k3 @32", 256, 32, 256, 3, 1, 1),
+    ("G.down1 64->128 k4s2 @128", 64, 128, 128, 4, 2, 1),
+    ("G.down2 128->256 k4s2 @64", 128, 64, 256, 4, 2, 1),
+    ("D.c2 64->128 k4s2 @64", 64, 64, 128, 4, 2, 1),
+    ("D.c4 256->512 k4s2 @16", 256, 16, 512, 4, 2, 1),
+    ("E.l0 64->128 k3 @62", 64, 62, 128, 3, 1, 1),
+    ("E.l2 256->512 k3 @15", 256, 15, 512, 3, 1, 1),
+]
+only = os.environ.get("ONLY")
+def timeit(fn):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(REP): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / REP
+for name, ci, h, co, k, s, p in shapes:
+    if only and only not in name: continue
+    x = torch.randn(B, h, h, ci, device="cuda").permute(0, 3, 1, 2)
+    w = torch.randn(co, ci, k, k, device="cuda") / (ci * k * k) ** 0.5
+    y = ops.conv2d(x, w, None, s, p)
+    gy = torch.randn_like(y)
+    ho = y.shape[2]
+    desc = ops._conv_desc(B, h, h, ci, ho, ho, co, k, k, s, p, 0, w)
+    dx = torch.empty_like(x); dw = torch.empty_like(w)
+    fl = 2.0 * B * ho * ho * co * k * k * ci
+    t_f = timeit(lambda: ops._run_conv_fwd(desc, x, w, None, y, 0, 0.0))
+    t_d = timeit(lambda: ops._run_conv_dgrad(desc, gy, w, dx))
+    t_w = timeit(lambda: ops._run_conv_wgrad(desc, x, gy, dw, None))
+    print(f"{name:28s} GFLOP {fl/1e9:7.2f} | fwd {t_f*1e3:7.1f} us {fl/t_f/1e9:6.1f} TF | dgrad {t_d*1e3:7.1f} us {fl/t_d/1e9:6.1f} TF | wgrad {t_w*1e3:7.1f} us {fl/t_w/1e9:6.1f} TF")

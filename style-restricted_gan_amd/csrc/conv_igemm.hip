@@ -85,8 +85,9 @@ template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   static_assert(WM * WN == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) float As[BM * LDK];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+  // double-buffered operand tiles: tile t+1 is written while tile t is multiplied (one barrier per K tile)
+  __shared__ __attribute__((aligned(16))) float As2[2][BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs2[2][BN * LDK];
   __shared__ int row_n[BM], row_y[BM], row_x[BM], row_o[BM];
 
   const int tid = threadIdx.x;
@@ -143,20 +144,78 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     return ((size_t)(row_n[r] * p.Hs + y) * p.Ws + x) * p.Cs;
   };
 
+  // VEC path: the BM/32 rows a thread stages are fixed for the whole K loop.  Per row keep ONE 32-bit byte offset
+  // and a tap-validity bitmask in registers; the tap / channel position is wave-uniform, so each gather is
+  //   address = (scalar base of this tap & channel block) + (row offset or a safe offset)   [saddr + voffset form]
+  // and costs a handful of VALU ops instead of a multiply-add chain per load.
+  unsigned voff[VEC ? A_VEC_IT : 1];
+  unsigned long long vmask[VEC ? A_VEC_IT : 1];
+  unsigned mapy[VEC ? A_VEC_IT : 1], mapx[VEC ? A_VEC_IT : 1];   // reflect: mirrored tap displacement per nibble
+  float a_msk[VEC ? A_VEC_IT : 1];
+  const long long bias = ((long long)max(p.pad, p.Ty) * p.Ws + max(p.pad, p.Tx)) * p.Cs;   // keeps offsets >= 0
+  if constexpr (VEC) {
+    const unsigned seg16 = (tid & 7) * 16;
+#pragma unroll
+    for (int i = 0; i < A_VEC_IT; ++i) {
+      const int r = (tid >> 3) + 32 * i;
+      const int y0 = row_y[r], x0 = row_x[r];
+      const bool rowok = y0 > -(1 << 27);
+      const long long lin = rowok ? ((long long)(row_n[r] * p.Hs + y0) * p.Ws + x0) * p.Cs : 0;
+      voff[i] = (unsigned)((lin + bias) * 4) + seg16;
+      unsigned long long m = 0;
+      unsigned my = 0, mx = 0;
+      if (rowok) {
+        if (p.reflect) {
+          m = ~0ull;
+          for (int t = 0; t < p.Ty; ++t) {
+            int y = y0 + t;
+            y = y < 0 ? -y : y;
+            y = y >= p.Hs ? 2 * p.Hs - 2 - y : y;
+            my |= (unsigned)(y - y0) << (4 * t);
+          }
+          for (int t = 0; t < p.Tx; ++t) {
+            int x = x0 + t;
+            x = x < 0 ? -x : x;
+            x = x >= p.Ws ? 2 * p.Ws - 2 - x : x;
+            mx |= (unsigned)(x - x0) << (4 * t);
+          }
+        } else {
+          for (int t = 0; t < p.Ty * p.Tx; ++t) {
+            const int ty = t / p.Tx, tx = t - ty * p.Tx;
+            const int y = y0 + sgn * ty, x = x0 + sgn * tx;
+            if ((unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws) m |= 1ull << t;
+          }
+        }
+      }
+      vmask[i] = m; mapy[i] = my; mapx[i] = mx;
+    }
+  }
+  int tap_y = 0, tap_x = 0, tap_c = 0;       // position of the NEXT tile to load (VEC path)
+
   auto load_tiles = [&](int kt) {
     const int k0 = kt * BK;
     if constexpr (VEC) {
-      const int t = k0 / p.Cs, c0 = k0 - t * p.Cs;
-      const int ty = t / p.Tx, tx = t - ty * p.Tx;
-      const int seg = tid & 7;
+      const unsigned seg16 = (tid & 7) * 16;
+      const int t = tap_y * p.Tx + tap_x;
+      const long long tap_lin = p.reflect ? 0 : (long long)sgn * (tap_y * p.Ws + tap_x) * p.Cs;
+      const char* sb = reinterpret_cast<const char*>(p.src) + (tap_lin + tap_c - bias) * 4;   // wave-uniform
+      const unsigned safe = (unsigned)((bias - tap_lin) * 4) + seg16;                          // -> src + tap_c
 #pragma unroll
       for (int i = 0; i < A_VEC_IT; ++i) {
-        const int r = (tid >> 3) + 32 * i;
-        bool ok;
-        size_t off = src_index(r, ty, tx, ok);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(p.src + off + c0 + seg * 4);
-        a_reg[i] = v;
+        const bool ok = (vmask[i] >> t) & 1;
+        unsigned off = voff[i];
+        if (p.reflect) {
+          const unsigned dyv = (mapy[i] >> (4 * tap_y)) & 15u, dxv = (mapx[i] >> (4 * tap_x)) & 15u;
+          off += (dyv * p.Ws + dxv) * p.Cs * 4;
+        }
+        off = ok ? off : safe;
+        a_reg[i] = *reinterpret_cast<const f32x4*>(sb + off);
+        a_msk[i] = ok ? 1.f : 0.f;          // applied when the tile is written to LDS (keeps the load in flight)
+      }
+      tap_c += BK;
+      if (tap_c == p.Cs) {
+        tap_c = 0;
+        if (++tap_x == p.Tx) { tap_x = 0; ++tap_y; }
       }
     } else {
       const int kk = tid & 31;
@@ -181,13 +240,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
   };
 
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int buf) {
+    float* As = As2[buf];
+    float* Bs = Bs2[buf];
     if constexpr (VEC) {
       const int seg = tid & 7;
 #pragma unroll
       for (int i = 0; i < A_VEC_IT; ++i) {
         const int r = (tid >> 3) + 32 * i;
-        *reinterpret_cast<f32x4*>(&As[r * LDK + seg * 4]) = a_reg[i];
+        *reinterpret_cast<f32x4*>(&As[r * LDK + seg * 4]) = a_reg[i] * a_msk[i];
       }
     } else {
       const int kk = tid & 31;
@@ -217,34 +278,53 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  load_tiles(0);
-  store_tiles();
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tiles(kt + 1);
+  // Software pipeline over K tiles (one barrier per tile):
+  //   global loads of tile t+2 are issued right after the barrier of tile t and written to LDS during tile t+1,
+  //   the q=0 fragments of tile t+1 are read right after that barrier, under the last 16 MFMAs of tile t,
+  //   fragments of step q+1 are read before the MFMAs of step q.
+  f32x4 af[2][TM], bf[2][TN];
+  auto read_frags = [&](int buf, int q, int slot) {
+    const float* As = As2[buf];
+    const float* Bs = Bs2[buf];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 af[TM], bf[TN];
+    for (int i = 0; i < TM; ++i)
+      af[slot][i] = *reinterpret_cast<const f32x4*>(&As[(wm * TM * 32 + i * 32 + lr) * LDK + q * 8 + lh * 4]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      bf[slot][j] = *reinterpret_cast<const f32x4*>(&Bs[(wn * TN * 32 + j * 32 + lr) * LDK + q * 8 + lh * 4]);
+  };
+  auto mfma_step = [&](int slot) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const f32x4*>(&As[(wm * TM * 32 + i * 32 + lr) * LDK + q * 8 + lh * 4]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn * TN * 32 + j * 32 + lr) * LDK + q * 8 + lh * 4]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i][e], bf[slot][j][e], acc[i][j], 0, 0, 0);
+  };
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  read_frags(0, 0, 0);
+  if (nk > 1) load_tiles(1);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    read_frags(cur, 1, 1);
+    mfma_step(0);
+    read_frags(cur, 2, 0);
+    mfma_step(1);
+    if (more) store_tiles(cur ^ 1);          // tile kt+1 (its loads were issued a whole tile ago)
+    read_frags(cur, 3, 1);
+    mfma_step(0);
+    __syncthreads();                         // tile kt+1 visible; everyone has read the last fragments of tile kt
+    if (more) {
+      read_frags(cur ^ 1, 0, 0);
+      if (kt + 2 < nk) load_tiles(kt + 2);
     }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      store_tiles();
-      __syncthreads();
-    }
+    mfma_step(1);
   }
 
   // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -608,8 +688,10 @@ int validate(const srgan_conv_desc* d) {
   SRGAN_REQUIRE(d->pad_mode == SRGAN_PAD_ZERO || d->pad_mode == SRGAN_PAD_REFLECT, "conv desc: bad pad_mode");
   if (d->pad_mode == SRGAN_PAD_REFLECT)
     SRGAN_REQUIRE(d->stride == 1 && d->pad < d->Hi && d->pad < d->Wi, "reflect padding needs stride 1 and pad < size");
-  SRGAN_REQUIRE((long long)d->N * d->Hi * d->Wi * (long long)d->I < (1LL << 31) &&
-                (long long)d->N * d->Ho * d->Wo * (long long)d->O < (1LL << 31), "tensor too large for 32-bit pixel indexing");
+  SRGAN_REQUIRE((long long)d->N * d->Hi * d->Wi * (long long)d->I < (1LL << 30) - (1LL << 24) &&
+                (long long)d->N * d->Ho * d->Wo * (long long)d->O < (1LL << 30) - (1LL << 24),
+                "tensor too large: the gather uses 32-bit byte offsets (< 4 GiB per activation tensor)");
+  SRGAN_REQUIRE(d->kh * d->kw <= 64, "kernel window larger than 64 taps is not supported");
   return 0;
 }
 
