@@ -430,13 +430,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   constexpr int TM = BMc / (WM * 32), TN = BNn / (WN * 32);
   constexpr int A_IT = BMc / 32, B_IT = BNn / 32;     // float4 per thread per 32-row tile
   constexpr int A_PR = BMc / 4, B_PR = BNn / 4;       // float4 per tile row
-  __shared__ __attribute__((aligned(16))) float As[32 * BMc];
-  __shared__ __attribute__((aligned(16))) float Bs[32 * BNn];
+  // double-buffered tiles: tile t+1 is written to LDS in the middle of tile t's MFMAs (one barrier per tile)
+  __shared__ __attribute__((aligned(16))) float As2[2][32 * BMc];
+  __shared__ __attribute__((aligned(16))) float Bs2[2][32 * BNn];
   __shared__ int rowtab[2][3][32];
 
   const int tid = threadIdx.x;
-  const int ct = blockIdx.x % p.co_tiles, nt = blockIdx.x / p.co_tiles;
-  const int split = blockIdx.y;
+  // (an XCD-contiguous work order was measured here and was slower for the 256-channel layers: 530 vs 465 us)
+  const int tiles = p.co_tiles * p.nn_tiles;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;
+  const int ct = tile % p.co_tiles, nt = tile / p.co_tiles;
   const int co0 = ct * BMc, nn0 = nt * BNn;
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
@@ -537,11 +540,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
   };
 
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    float* As = As2[buf];
+    float* Bs = Bs2[buf];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(&As[(tid + 256 * i) * 4]) = a_reg[i];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(&Bs[(tid + 256 * i) * 4]) = b_reg[i];
+  };
+  auto mfma_range = [&](int buf, int kp0, int kp1) {
+    const float* As = As2[buf];
+    const float* Bs = Bs2[buf];
+#pragma unroll
+    for (int kp = kp0; kp < kp1; ++kp) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[(2 * kp + lh) * BMc + wm * TM * 32 + i * 32 + lr];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * kp + lh) * BNn + wn * TN * 32 + j * 32 + lr];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
   };
 
   if (ntiles > 0) {
@@ -549,30 +571,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     __syncthreads();
     load_tile(0);
     if (ntiles > 1 && tid < 32) fill_rowtab(1);
+    store_tile(0);
+    __syncthreads();                    // tile 0 in LDS, rowtab[1] visible
+    if (ntiles > 1) load_tile(1);
   }
   for (int t = 0; t < ntiles; ++t) {
-    store_tile();
-    __syncthreads();                    // tile t in LDS; rowtab[(t+1)&1] visible
-    if (t + 1 < ntiles) {
-      load_tile(t + 1);                 // global loads in flight during the MFMAs below
-    }
-    if (active) {
-#pragma unroll
-      for (int kp = 0; kp < 16; ++kp) {
-        float af[TM], bf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = As[(2 * kp + lh) * BMc + wm * TM * 32 + i * 32 + lr];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * kp + lh) * BNn + wn * TN * 32 + j * 32 + lr];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    __syncthreads();                    // LDS consumed; rowtab[t&1] no longer needed by load_tile(t+1)
-    if (t + 2 < ntiles && tid < 32) fill_rowtab(t + 2);
+    const int cur = t & 1;
+    if (active) mfma_range(cur, 0, 8);
+    if (t + 1 < ntiles) store_tile(cur ^ 1);               // tile t+1: its loads were issued half a tile ago
+    if (t + 2 < ntiles && tid < 32) fill_rowtab(t + 2);    // into rowtab[cur]: tile t's rows are no longer needed
+    if (active) mfma_range(cur, 8, 16);
+    __syncthreads();                    // tile t+1 and rowtab[cur] visible; everyone is done reading tile t
+    if (t + 2 < ntiles) load_tile(t + 2);                  // in flight during the first half of tile t+1
   }
 
   if (!active) return;
@@ -831,7 +841,7 @@ namespace srgan {
 template <int BMc, int BNn, int WM, int WN>
 static int launch_wgrad(const WgradParams& p, const WgradPlan& w, hipStream_t st) {
   ProfScope scope(8 + (w.vec ? 1 : 0), 2.0 * p.M * (double)p.Cd * p.NN, st);
-  dim3 grid((unsigned)(w.co_tiles * w.nn_tiles), (unsigned)w.splits, 1);
+  dim3 grid((unsigned)(w.co_tiles * w.nn_tiles * w.splits), 1, 1);
   if (w.vec)
     hipLaunchKernelGGL((wgrad_kernel<BMc, BNn, WM, WN, true>), grid, dim3(256), 0, st, p);
   else

@@ -91,6 +91,69 @@ __global__ void in_apply(const float* __restrict__ x, const float* __restrict__ 
   }
 }
 
+// Fast apply passes for power-of-two channel counts (C | 1024): with a float4 stride of 256*G per image a thread
+// always lands on the same 4 channels, so mean / rstd / scale / shift live in registers and the streaming loop has
+// no index arithmetic (grid = (G, N)).
+__global__ __launch_bounds__(256) void in_apply_pow2(const float* __restrict__ x, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const float* __restrict__ res,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     float* __restrict__ y, int HWC4, int C, int act, float slope) {
+  const int n = blockIdx.y;
+  const int c = (threadIdx.x * 4) % C;
+  const int nc = n * C + c;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + nc);
+  const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + nc);
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+  if (scale) {
+    sc = *reinterpret_cast<const f32x4*>(scale + nc);
+    sf = *reinterpret_cast<const f32x4*>(shift + nc);
+  }
+  const size_t base = (size_t)n * HWC4;
+  const f32x4* xp = reinterpret_cast<const f32x4*>(x) + base;
+  const f32x4* rp = res ? reinterpret_cast<const f32x4*>(res) + base : nullptr;
+  f32x4* yp = reinterpret_cast<f32x4*>(y) + base;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < HWC4; j += gridDim.x * 256) {
+    f32x4 v = ((xp[j] - mu) * rs) * sc + sf;      // same expression as the backward's mask recomputation
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], act, slope);
+    if (rp) v += rp[j];
+    yp[j] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void in_bwd_apply_pow2(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ dshift, const float* __restrict__ dscale,
+                                                         float* __restrict__ dx, int HWC4, int C, float inv_hw, int act,
+                                                         float slope) {
+  const int n = blockIdx.y;
+  const int c = (threadIdx.x * 4) % C;
+  const int nc = n * C + c;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + nc);
+  const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + nc);
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+  if (scale) {
+    sc = *reinterpret_cast<const f32x4*>(scale + nc);
+    sf = *reinterpret_cast<const f32x4*>(shift + nc);
+  }
+  const f32x4 mg = *reinterpret_cast<const f32x4*>(dshift + nc) * inv_hw;
+  const f32x4 mgx = *reinterpret_cast<const f32x4*>(dscale + nc) * inv_hw;
+  const f32x4 k = rs * sc;
+  const size_t base = (size_t)n * HWC4;
+  const f32x4* xp = reinterpret_cast<const f32x4*>(x) + base;
+  const f32x4* gp = reinterpret_cast<const f32x4*>(dy) + base;
+  f32x4* op = reinterpret_cast<f32x4*>(dx) + base;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < HWC4; j += gridDim.x * 256) {
+    const f32x4 xh = (xp[j] - mu) * rs;
+    f32x4 g = gp[j];
+    const f32x4 z = xh * sc + sf;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] *= act_grad(z[e], act, slope);
+    op[j] = k * (g - mg - xh * mgx);
+  }
+}
+
 // backward partial: {sum g, sum g*xh}, g = dy * act'(xh*scale+shift)
 __global__ __launch_bounds__(256) void in_bwd_partial(const float* __restrict__ x, const float* __restrict__ dy,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
@@ -252,6 +315,14 @@ __global__ __launch_bounds__(256) void cbin_affine_bwd_c(const float* W, const f
 }
 
 namespace {
+// C divides 1024 (so 256 threads * 4 floats wrap onto the same channels) and every float4 stays inside one pixel
+bool pow2_fast(int C, int HW) { return C >= 4 && (1024 % C) == 0 && (long long)HW * C / 4 < (1LL << 30); }
+int apply_grid(int hwc4, int N) {
+  long long per_image = ceil_div(hwc4, 256);                 // blocks if one float4 per thread
+  long long want = std::max<long long>(1, 2048 / std::max(1, N));
+  return (int)std::max<long long>(1, std::min(per_image, want));
+}
+
 void plan_split(int N, int HW, int C, int& S, int& rps) {
   const int chunks = (C + NORM_CH - 1) / NORM_CH;
   long long blocks = (long long)N * chunks;
@@ -285,7 +356,11 @@ extern "C" int srgan_instnorm_fwd(const float* x, const float* scale, const floa
   hipLaunchKernelGGL(in_stats_partial, g, dim3(256), 0, st, x, part, HW, C, S, rps);
   hipLaunchKernelGGL(in_stats_final, dim3((N * C + 255) / 256), dim3(256), 0, st, x, (const float2*)part, mean, rstd, N, HW, C, S, eps);
   const long long total = (long long)N * HW * C;
-  if ((C & 3) == 0) {
+  if (pow2_fast(C, HW)) {
+    const int hwc4 = HW * C / 4;
+    dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
+    hipLaunchKernelGGL(in_apply_pow2, g2, dim3(256), 0, st, x, scale, shift, res, mean, rstd, y, hwc4, C, act, slope);
+  } else if ((C & 3) == 0) {
     unsigned blocks = (unsigned)std::min<long long>(ceil_div(total / 4, 256), 8192);
     hipLaunchKernelGGL(in_apply<true>, dim3(blocks), dim3(256), 0, st, x, scale, shift, res, mean, rstd, y, total, HW * C, C, act, slope);
   } else {
@@ -310,7 +385,11 @@ extern "C" int srgan_instnorm_bwd(const float* x, const float* dy, const float* 
   hipLaunchKernelGGL(in_bwd_final, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float2*)part, dshift, dscale, N * C, C, S);
   const long long total = (long long)N * HW * C;
   const float inv_hw = 1.f / (float)HW;
-  if ((C & 3) == 0) {
+  if (pow2_fast(C, HW)) {
+    const int hwc4 = HW * C / 4;
+    dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
+    hipLaunchKernelGGL(in_bwd_apply_pow2, g2, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, hwc4, C, inv_hw, act, slope);
+  } else if ((C & 3) == 0) {
     unsigned blocks = (unsigned)std::min<long long>(ceil_div(total / 4, 256), 8192);
     hipLaunchKernelGGL(in_bwd_apply<true>, dim3(blocks), dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, total, HW * C, C, inv_hw, act, slope);
   } else {
