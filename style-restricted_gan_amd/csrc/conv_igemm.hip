@@ -721,7 +721,7 @@ WgradPlan plan_wgrad(const srgan_conv_desc* d) {
   w.Cdpad = w.co_tiles * w.BMc;
   w.NNpad = w.nn_tiles * w.BNn;
   long long tiles = (long long)w.co_tiles * w.nn_tiles;
-  long long want = ceil_div(1024, tiles);                 // ~4 blocks per CU
+  long long want = ceil_div(1024, tiles);                 // ~4 blocks per CU (768 measured slower: 82 vs 89 TFLOP/s)
   long long max_splits = ceil_div(M, 256);                // at least 8 K-tiles per split
   long long splits = want < 1 ? 1 : want;
   if (splits > max_splits) splits = max_splits;
@@ -768,7 +768,8 @@ extern "C" int srgan_conv2d_fwd(const srgan_conv_desc* d, const float* x, const 
   SRGAN_REQUIRE(x && w && y && ws, "conv2d_fwd: null pointer");
   SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_fwd: workspace too small");
   hipStream_t st = as_stream(stream);
-  if (act == SRGAN_ACT_NONE && narrow_applicable(d)) return narrow_fwd(d, x, w, bias, y, ws, st);
+  const bool wave_path = act == SRGAN_ACT_NONE && narrow_wave_applicable(d) && !dense_head_applicable(d);
+  if (act == SRGAN_ACT_NONE && !wave_path && narrow_applicable(d)) return narrow_fwd(d, x, w, bias, y, ws, st);
   IgemmParams p{};
   p.src = x; p.bias = bias; p.dst = y;
   p.NB = d->N; p.Hs = d->Hi; p.Ws = d->Wi; p.Cs = d->I;
@@ -776,7 +777,7 @@ extern "C" int srgan_conv2d_fwd(const srgan_conv_desc* d, const float* x, const 
   p.mode = 0; p.stride = d->stride; p.pad = d->pad; p.Ty = d->kh; p.Tx = d->kw;
   p.K = d->kh * d->kw * d->I; p.Kpad = (int)round_up(p.K, BK);
   p.M = d->N * d->Ho * d->Wo;
-  p.Npad = npad_for(p.M, d->O);
+  p.Npad = wave_path ? d->O : npad_for(p.M, d->O);
   p.reflect = d->pad_mode == SRGAN_PAD_REFLECT;
   p.act = act; p.slope = slope;
   PackParams q{};
@@ -788,6 +789,7 @@ extern "C" int srgan_conv2d_fwd(const srgan_conv_desc* d, const float* x, const 
   if (int e = check_launch("pack_weights_kernel")) return e;
   p.wp = (const float*)ws;
   if (act == SRGAN_ACT_NONE && dense_head_applicable(d)) return dense_head_fwd(d, x, p.wp, p.Kpad, bias, y, st);
+  if (wave_path) return narrow_wave_fwd(d, x, p.wp, p.Kpad, bias, y, st);
   return run_igemm(p, 1, st, conv_flops(d));
 }
 

@@ -165,6 +165,69 @@ __global__ __launch_bounds__(256) void narrow_conv_wgrad_kernel(NarrowParams p) 
   }
 }
 
+// Small feature maps with many channels (PatchGAN last_layer: 8x8x512 -> 7x7x1, k4 p1): one WAVE per output pixel,
+// lanes stride over the input channels (float4, coalesced), taps looped, 64-lane shuffle reduction at the end.
+// wp: [CO][Kpad], K = (tap, channel) contiguous (pack_weights_kernel mode 0 layout).
+template <int CO>
+__global__ __launch_bounds__(256) void narrow_wave_fwd_kernel(NarrowParams p, int Kpad) {
+  const int pix = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int M = p.N * p.Ho * p.Wo;
+  if (pix >= M) return;
+  const int n = pix / (p.Ho * p.Wo);
+  const int rem = pix - n * (p.Ho * p.Wo);
+  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  float acc[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+  for (int ky = 0; ky < p.kh; ++ky) {
+    const int y = oy + ky - p.pad;
+    if ((unsigned)y >= (unsigned)p.H) continue;
+    for (int kx = 0; kx < p.kw; ++kx) {
+      const int x = ox + kx - p.pad;
+      if ((unsigned)x >= (unsigned)p.W) continue;
+      const float* src = p.x + ((size_t)(n * p.H + y) * p.W + x) * p.Ci;
+      const float* wt = p.wp + (size_t)(ky * p.kw + kx) * p.Ci;
+      for (int c = lane * 4; c < p.Ci; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(wt + (size_t)o * Kpad + c);
+          acc[o] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    const float t = wave_sum(acc[o]);
+    if (lane == 0) p.y[(size_t)pix * CO + o] = t + (p.bias ? p.bias[o] : 0.f);
+  }
+}
+
+bool narrow_wave_applicable(const srgan_conv_desc* d) {
+  return d->O <= 4 && d->stride == 1 && d->pad_mode == SRGAN_PAD_ZERO && (d->I % 4) == 0 && d->I >= 128 &&
+         d->Ho * d->Wo <= 1024;
+}
+
+// wp: pack_weights_kernel(mode 0) output with Npad = O
+int narrow_wave_fwd(const srgan_conv_desc* d, const float* x, const float* wp, int Kpad, const float* bias, float* y,
+                    hipStream_t st) {
+  NarrowParams p{};
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y;
+  p.N = d->N; p.H = d->Hi; p.W = d->Wi; p.Ci = d->I; p.Ho = d->Ho; p.Wo = d->Wo; p.CO = d->O;
+  p.kh = d->kh; p.kw = d->kw; p.pad = d->pad;
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  dim3 grid((unsigned)ceil_div(M, 4));
+  switch (d->O) {
+    case 1: hipLaunchKernelGGL(narrow_wave_fwd_kernel<1>, grid, dim3(256), 0, st, p, Kpad); break;
+    case 2: hipLaunchKernelGGL(narrow_wave_fwd_kernel<2>, grid, dim3(256), 0, st, p, Kpad); break;
+    case 3: hipLaunchKernelGGL(narrow_wave_fwd_kernel<3>, grid, dim3(256), 0, st, p, Kpad); break;
+    default: hipLaunchKernelGGL(narrow_wave_fwd_kernel<4>, grid, dim3(256), 0, st, p, Kpad); break;
+  }
+  return check_launch("narrow_wave_fwd_kernel");
+}
+
 bool narrow_applicable(const srgan_conv_desc* d) {
   // (Ho*Wo >= 9: a 1x1 output would leave 255 of 256 lanes idle -- those are dense heads, see dense_head_applicable)
   return d->O <= 4 && d->stride == 1 && d->pad_mode == SRGAN_PAD_ZERO && (d->I % NCH) == 0 && d->kh <= 8 && d->kw <= 8 &&

@@ -41,6 +41,81 @@ __global__ __launch_bounds__(256) void in_stats_partial(const float* __restrict_
   }
 }
 
+// float4 variants (C % 4 == 0): 8 lanes cover the block's 32 channels, 32 row lanes stride over the rows
+__global__ __launch_bounds__(256) void in_stats_partial_v4(const float* __restrict__ x, float2* __restrict__ part,
+                                                           int HW, int C, int S, int rows_per_split) {
+  const int q = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int c = blockIdx.x * NORM_CH + q * 4;
+  const int s = blockIdx.y, n = blockIdx.z;
+  __shared__ f32x4 sh[2][32][8];
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const float* xp = x + (size_t)n * HW * C + c;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp);
+    const int r0 = s * rows_per_split, r1 = min(HW, r0 + rows_per_split);
+    for (int r = r0 + ty; r < r1; r += 32) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (size_t)r * C) - x0;
+      a += v;
+      b += v * v;
+    }
+  }
+  sh[0][ty][q] = a;
+  sh[1][ty][q] = b;
+  __syncthreads();
+  if (threadIdx.x < 32) {              // thread = one channel of the block: sum the 32 row lanes
+    const int cc = threadIdx.x, qq = cc >> 2, e = cc & 3;
+    float sa = 0.f, sb = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) { sa += sh[0][i][qq][e]; sb += sh[1][i][qq][e]; }
+    const int ch = blockIdx.x * NORM_CH + cc;
+    if (ch < C) part[((size_t)n * S + s) * C + ch] = make_float2(sa, sb);
+  }
+}
+
+__global__ __launch_bounds__(256) void in_bwd_partial_v4(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float2* __restrict__ part, int HW, int C, int S, int rows_per_split,
+                                                         int act, float slope) {
+  const int q = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int c = blockIdx.x * NORM_CH + q * 4;
+  const int s = blockIdx.y, n = blockIdx.z;
+  __shared__ f32x4 sh[2][32][8];
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const int nc = n * C + c;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + nc), rs = *reinterpret_cast<const f32x4*>(rstd + nc);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+    if (scale) {
+      sc = *reinterpret_cast<const f32x4*>(scale + nc);
+      sf = *reinterpret_cast<const f32x4*>(shift + nc);
+    }
+    const size_t base = (size_t)n * HW * C + c;
+    const int r0 = s * rows_per_split, r1 = min(HW, r0 + rows_per_split);
+    for (int r = r0 + ty; r < r1; r += 32) {
+      const size_t o = base + (size_t)r * C;
+      const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * rs;
+      f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+      const f32x4 z = xh * sc + sf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] *= act_grad(z[e], act, slope);
+      a += g;
+      b += g * xh;
+    }
+  }
+  sh[0][ty][q] = a;
+  sh[1][ty][q] = b;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int cc = threadIdx.x, qq = cc >> 2, e = cc & 3;
+    float sa = 0.f, sb = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) { sa += sh[0][i][qq][e]; sb += sh[1][i][qq][e]; }
+    const int ch = blockIdx.x * NORM_CH + cc;
+    if (ch < C) part[((size_t)n * S + s) * C + ch] = make_float2(sa, sb);
+  }
+}
+
 __global__ void in_stats_final(const float* __restrict__ x, const float2* __restrict__ part, float* __restrict__ mean,
                                float* __restrict__ rstd, int N, int HW, int C, int S, float eps) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -353,7 +428,8 @@ extern "C" int srgan_instnorm_fwd(const float* x, const float* scale, const floa
   SRGAN_REQUIRE(ws && ws_bytes >= (size_t)N * S * C * sizeof(float2), "instnorm_fwd: workspace too small");
   float2* part = reinterpret_cast<float2*>(ws);
   dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
-  hipLaunchKernelGGL(in_stats_partial, g, dim3(256), 0, st, x, part, HW, C, S, rps);
+  if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4, g, dim3(256), 0, st, x, part, HW, C, S, rps);
+  else hipLaunchKernelGGL(in_stats_partial, g, dim3(256), 0, st, x, part, HW, C, S, rps);
   hipLaunchKernelGGL(in_stats_final, dim3((N * C + 255) / 256), dim3(256), 0, st, x, (const float2*)part, mean, rstd, N, HW, C, S, eps);
   const long long total = (long long)N * HW * C;
   if (pow2_fast(C, HW)) {
@@ -381,7 +457,8 @@ extern "C" int srgan_instnorm_bwd(const float* x, const float* dy, const float* 
   SRGAN_REQUIRE(ws && ws_bytes >= (size_t)N * S * C * sizeof(float2), "instnorm_bwd: workspace too small");
   float2* part = reinterpret_cast<float2*>(ws);
   dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
-  hipLaunchKernelGGL(in_bwd_partial, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
+  if ((C & 3) == 0) hipLaunchKernelGGL(in_bwd_partial_v4, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
+  else hipLaunchKernelGGL(in_bwd_partial, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
   hipLaunchKernelGGL(in_bwd_final, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float2*)part, dshift, dscale, N * C, C, S);
   const long long total = (long long)N * HW * C;
   const float inv_hw = 1.f / (float)HW;
