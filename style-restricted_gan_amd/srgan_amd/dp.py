@@ -33,7 +33,8 @@ def init_from_env(backend=None):
     Returns (rank, world_size, device)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rk = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("SRGAN_DP_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # override: tests share 1 GPU
+    backend = backend or os.environ.get("SRGAN_DP_BACKEND")
     use_gpu = torch.cuda.is_available()
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
@@ -125,14 +126,14 @@ class GradReducer:
         ws = dist.get_world_size()
         on_gpu = self.params[0].is_cuda
         work = []
-        if on_gpu:
-            if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream()
-            self._comm_stream.wait_stream(torch.cuda.current_stream())
+        if on_gpu and self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
         for bucket in self._buckets():
             grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
             flat = torch.cat([g.reshape(-1) for g in grads])
             if on_gpu:
+                # the side stream must see the flattened bucket (and the backward that produced it) complete
+                self._comm_stream.wait_stream(torch.cuda.current_stream())
                 flat.record_stream(self._comm_stream)
                 with torch.cuda.stream(self._comm_stream):
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM)

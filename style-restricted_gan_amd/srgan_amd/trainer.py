@@ -80,6 +80,7 @@ class SRGAN_training():
             self.hi = histogram_imitation(device)
         self.loss_terms = {}           # last step's individual loss values (device scalars)
         self._reducers = {}
+        self.noise_fn = torch.randn    # style noise source (CPU default generator, as the reference); tests may inject
         ref = np.asarray(ref_label)
         self._ref_is_onehot = ref.ndim == 2 and ref.shape[0] == ref.shape[1] and np.array_equal(ref, np.eye(ref.shape[0]))
 
@@ -170,7 +171,7 @@ class SRGAN_training():
             elif self.encoded_feature == "mu":
                 latent_vector = mu
         else:
-            latent_vector = torch.randn(source_image.shape[0], self.ndim).to(self.device)
+            latent_vector = self.noise_fn(source_image.shape[0], self.ndim).to(self.device)
             info = latent_vector
         if isinstance(target_label, str):
             class_vector = self._onehot(target_label)

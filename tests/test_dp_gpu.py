@@ -1,0 +1,101 @@
+"""GPU: data-parallel equivalence of the HIP train step.  Two ranks (each half of the batch, sharing the one
+GPU of the test box, gloo as the transport) must reproduce the single-process step on the full batch:
+same parameters afterwards, rank-averaged losses equal to the full-batch losses.  Exercises the mu all-gather,
+the world-size scaling of the global-batch latent losses and the bucketed gradient all-reduce on device tensors."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+K, B, STEPS = 2, 4, 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _noise_source(rank, world):
+    gen = torch.Generator().manual_seed(77)
+
+    def fn(batch, ndim):          # every rank draws the GLOBAL noise and keeps its rows
+        full = torch.randn(batch * world, ndim, generator=gen)
+        return full[rank * batch:(rank + 1) * batch].clone()
+    return fn
+
+
+def _run(rank, world, out_q=None):
+    from oracle import trainer as otrainer
+    from tests.common import build_hip_nets
+    from srgan_amd.trainer import SRGAN_training
+    from srgan_amd import optim as hoptim
+    G, D, E = build_hip_nets("T")
+    torch.manual_seed(0)
+    # Adam with a large eps is nearly linear in the gradient: without it the first steps are lr*sign(g) and
+    # rounding-level differences between the two reduction orders are amplified to O(lr) parameter differences,
+    # which would hide (or fake) a real data-parallel discrepancy.
+    opts = [hoptim.Adam(net.parameters(), lr=1e-4, betas=(0.5, 0.999), eps=1e-2) for net in (G, D, E)]
+    sg = SRGAN_training([G, D, E], opts, [nn.MSELoss(), nn.MSELoss()], dict(otrainer.DEFAULT_LBD), K, "cuda",
+                        np.eye(4), B, "mu", 8)
+    sg.opt_sche_initialization()
+    sg.noise_fn = _noise_source(rank, world)
+    per = B // world
+    losses = []
+    for s in range(STEPS):
+        x, label = otrainer.synthetic_batch(B, 128, 4, seed=300 + s)
+        sl = slice(rank * per, (rank + 1) * per)
+        lab = {"source": label["source"][sl].cuda(), "target": label["target"][sl]}
+        losses.append([float(v) for v in sg.train(x[sl].cuda(), lab)])
+    state = {f"{n}.{k}": v.detach().cpu().numpy().copy() for n, net in (("G", sg.G), ("D", sg.D), ("E", sg.E)) for k, v in net.state_dict().items()}
+    terms = {k: float(v) for k, v in sg.loss_terms.items()}
+    if out_q is not None:
+        out_q.put((rank, losses, state if rank == 0 else None, terms))
+    return losses, state, terms
+
+
+def _worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SRGAN_DP_DEVICE="0", SRGAN_DP_BACKEND="gloo")
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "style-restricted_gan_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from srgan_amd import dp
+    dp.init_from_env()
+    assert dp.world_size() == world
+    _run(rank, world, out_q)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process():
+    from tests.common import close_params
+    ref_losses, ref_state, ref_terms = _run(0, 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    dp_losses = (np.array(res[0][1]) + np.array(res[1][1])) / 2
+    ref = np.array(ref_losses)
+    # errG / errD are per-sample means -> rank average == full batch; errE's latent part is global on every rank
+    np.testing.assert_allclose(dp_losses, ref, rtol=1e-3)
+    for key in ("errE_bKL", "errE_corr", "errE_hist"):
+        for r in res:
+            assert abs(r[3][key] - ref_terms[key]) <= 1e-3 * max(abs(ref_terms[key]), 1e-3), (key, r[3][key], ref_terms[key])
+    for key, v in res[0][2].items():
+        d = float(np.abs(v - ref_state[key]).max())
+        assert d <= 1e-5, (key, d)        # 4 optimiser steps of at most lr=1e-4 each; observed ~2e-6
