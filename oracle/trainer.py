@@ -211,3 +211,135 @@ def synthetic_batch(batch, size, n_class, seed=0):
     src = torch.randint(0, n_class, (batch,), generator=g)
     tgt = (src + torch.randint(1, n_class, (batch,), generator=g)) % n_class
     return x, {"source": src, "target": tgt}
+
+
+# =============================================================================================
+# Conventional SingleGAN (config 1 of BASELINE.json: notebook 01, 64x64, 2 domains, CPU plumbing)
+# =============================================================================================
+SINGLEGAN_LBD = dict(**{"class": 0.0}, cycle=5.0, idt=5.0, reg=0.5, idt_reg=0.0, KL=0.1,
+                     batch_KL=0.0, corr_enc=0.0, hist=0.0)      # util_notebook.py:12-16 preset "conventionalKL"
+
+
+class SingleGANOracle:
+    """CPU restatement of ``SingleGAN_training`` (pyfiles/util_notebook.py:76-417), per-domain discriminators
+    (``singleD=False``): D is a LIST of SingleDiscriminator_original_multi parameter dicts, one per class, each
+    seeing the boolean-masked sub-batch of its domain (:225-249, :286-293); the encoder is the CBIN-conditioned
+    ``Encoder_original(x, onehot(label))`` (:170-171); phase 2's identity-regression path uses a RANDOM latent
+    (:356).  ``update_D`` returns the LAST domain's errD (:251).  RNG order on the CPU default generator:
+    k x randn(B, ndim); phase 1: normal_ (recon), normal_ (identity); phase 2: normal_ (E(target)), then if
+    idt_reg*idt > 0: randn(B, ndim), normal_."""
+
+    def __init__(self, PG, PD_list, PE, lbd, k, ref_label, ndim, classes, n_batch, encoded_feature="latent",
+                 lr=(1e-4, 1e-4, 1e-4)):
+        self.G, self.E = _leafify(PG), _leafify(PE)
+        self.D = [_leafify(p) for p in PD_list]
+        self.lbd, self.k = dict(lbd), int(k)
+        self.ref_label, self.ndim, self.classes = ref_label, ndim, tuple(classes)
+        self.n_batch, self.encoded_feature = n_batch, encoded_feature
+        self.optG = Adam14(self.G.values(), lr[0])
+        self.optD = [Adam14(d.values(), lr[1]) for d in self.D]
+        self.optE = Adam14(self.E.values(), lr[2])
+        self.hi = losses.HistogramImitation() if self.lbd["hist"] > 0 else None
+        self.trace = {}
+
+    def _onehot(self, label):
+        return losses.one_hot_rows(label, self.ref_label)
+
+    def _translate(self, target_label, src, use_encoder=False, ref_image=None):
+        if use_encoder:
+            info = list(nets.encoder_original(self.E, ref_image, self._onehot(target_label)))
+            z = info[0] if self.encoded_feature == "latent" else info[1]
+        else:
+            z = torch.randn(src.shape[0], self.ndim)
+            info = z
+        c = torch.cat([self._onehot(target_label), z], 1)
+        return nets.generator(self.G, src, c), info
+
+    def update_D(self):
+        self.target_image, self.c_rand = self._translate(self.label["target"], self.source)
+        errD = None
+        for i in self.classes:
+            _zero(self.D[i])
+            errD = 0
+            real = self.source[self.label["source"] == i]
+            if real.shape[0] != 0:
+                errD = errD + losses.lsgan(nets.discriminator_original(self.D[i], real), 1.0)
+            fake = self.target_image[self.label["target"] == i].detach()
+            if fake.shape[0] != 0:
+                errD = errD + losses.lsgan(nets.discriminator_original(self.D[i], fake), 0.0)
+            errD.backward()
+            self.optD[i].step()
+            self.trace.setdefault("errD", []).append(float(errD))
+        return errD.detach()
+
+    def update_GandE(self):
+        L, tr = self.lbd, self.trace
+        _zero(self.G)
+        _zero(self.E)
+        src, lab = self.source, self.label
+        recon, enc_info = self._translate(lab["source"], self.target_image, True, src)
+        errG = 0
+        for i in self.classes:
+            fake = self.target_image[lab["target"] == i]
+            if fake.shape[0] != 0:
+                errG = errG + losses.lsgan(nets.discriminator_original(self.D[i], fake), 1.0) / len(self.classes)
+        tr["g_dis"] = float(errG)
+        g_cyc = (src - recon).abs().mean()
+        errG = errG + g_cyc * L["cycle"]
+        errE = 0
+        errE_report = g_cyc * L["cycle"]
+        tr["g_cyc"] = float(g_cyc)
+        _, mu, logvar = enc_info
+        if L["KL"] > 0:
+            kl = losses.conventional_kl(mu, logvar)
+            errE = errE + kl * L["KL"]
+            errE_report = errE_report + kl * L["KL"]
+            tr["kl"] = float(kl)
+        if L["idt"] > 0:
+            idt, _ = self._translate(lab["source"], src, True, src)
+            g_idt = (src - idt).abs().mean()
+            errG = errG + g_idt * L["idt"]
+            errE_report = errE_report + g_idt * L["idt"]
+            tr["g_idt"] = float(g_idt)
+        if L["batch_KL"] > 0:
+            bkl = losses.batch_kl(mu, self.n_batch)
+            errE = errE + bkl * L["batch_KL"]
+            errE_report = errE_report + bkl * L["batch_KL"]
+            if L["corr_enc"] > 0:
+                corr = losses.corr_loss(mu.t())
+                errE = errE + corr * L["corr_enc"]
+                errE_report = errE_report + corr * L["corr_enc"]
+            if L["hist"] > 0:
+                hist = self.hi.loss(mu)
+                errE = errE + hist * L["hist"]
+                errE_report = errE_report + hist * L["hist"]
+        errG.backward(retain_graph=True)
+        errE.backward(retain_graph=True)
+        self.optG.step()
+        self.optE.step()
+        _zero(self.G)
+        _zero(self.E)
+        _, t_enc, _ = nets.encoder_original(self.E, self.target_image, self._onehot(lab["target"]))
+        g_reg = (self.c_rand - t_enc).abs().mean()
+        errG_ex = g_reg * L["reg"]
+        tr["g_reg"] = float(g_reg)
+        if L["idt_reg"] * L["idt"] > 0:
+            idt_rand, src_c = self._translate(lab["source"], src, False)
+            _, idt_enc, _ = nets.encoder_original(self.E, idt_rand, self._onehot(lab["source"]))
+            g_idt_reg = (src_c - idt_enc).abs().mean()
+            errG_ex = errG_ex + g_idt_reg * L["idt_reg"] * (L["idt"] / L["cycle"])
+            tr["g_idt_reg"] = float(g_idt_reg)
+        errG_ex.backward()
+        self.optG.step()
+        return (errG + errG_ex).detach(), errE_report.detach()
+
+    def train(self, source_image, label):
+        self.trace = {}
+        self.source, self.label = source_image, label
+        errD0 = None
+        for i in range(self.k):
+            e = self.update_D()
+            if i == 0:
+                errD0 = e
+        errG, errE = self.update_GandE()
+        return [errG, errD0, errE]

@@ -29,7 +29,7 @@ from .losses import class_encode, get_domainloss_D, get_loss_D, histogram_imitat
 from .model import _cpu_normal_like
 from .optim import Adam
 
-__all__ = ["SRGAN_training"]
+__all__ = ["SRGAN_training", "SingleGAN_training"]
 
 
 @contextlib.contextmanager
@@ -328,3 +328,197 @@ class SRGAN_training():
         self.loss_terms = {}
         error = self.UnrolledUpdate()
         return error
+
+
+def _select_rows(x, mask):
+    """x[mask] along the batch dimension of an NHWC-dense (logical NCHW) tensor, keeping it NHWC-dense."""
+    mask = torch.as_tensor(mask).to(x.device)
+    return x.permute(0, 2, 3, 1)[mask].permute(0, 3, 1, 2)
+
+
+class SingleGAN_training():
+    """Conventional SingleGAN trainer on the HIP path -- BASELINE.json configs[0] (notebook 01).
+
+    Same constructor / method signatures as the reference class (pyfiles/util_notebook.py:76-417):
+      net = [G, D, E] with D a LIST of per-domain discriminators when ``singleD=False`` (each applied to the
+      boolean-masked sub-batch of its domain) or one SingleDiscriminator_solo_multi when ``singleD=True``;
+      E is the CBIN-conditioned ``Encoder_original(x, onehot(label))``.
+    Kept semantics: ``update_D`` returns the LAST domain's errD; the per-domain D optimisers are always rebuilt by
+    ``opt_sche_initialization``; phase 2's identity-regression path draws a RANDOM latent; stale-graph phase 2;
+    the no-op "unrolled" restore.  Networks are used where the caller put them (the reference does not move them).
+    """
+
+    def __init__(self, net, opt, criterion, lbd, unrolled_k, device, ref_label, ndim,
+                 classes, batch_size=64, encoded_feature="latent", singleD=False):
+        self.G, self.D, self.E = net[0], net[1], net[2]
+        self.optG, self.optD, self.optE = opt[0], opt[1], opt[2]
+        self.scheG, self.scheD, self.scheE = None, None, None
+        self.criterion, self.criterion_class = criterion
+        self.lbd = lbd
+        self.k = unrolled_k
+        self.device = device
+        self.ref_label = ref_label
+        self.n_batch = batch_size
+        self.encoded_feature = encoded_feature
+        self.ndim = ndim
+        self.classes = classes
+        self.singleD = singleD
+        self.source_image = None
+        self.target_image = None
+        self.recon_image = None
+        self.label = None
+        self.c_rand = None
+        self.enc_info = None
+        self.target_cenc = None
+        if lbd["hist"] > 0:
+            self.hi = histogram_imitation(device)
+        self.loss_terms = {}
+        self.noise_fn = torch.randn
+
+    def opt_sche_initialization(self, lr=[0.0001, 0.0001, 0.0001]):
+        lr_G, lr_D, lr_E = lr
+        if self.optG is None:
+            self.optG = Adam(self.G.parameters(), lr=lr_G, betas=(0.5, 0.999))
+        self.scheG = optim.lr_scheduler.ExponentialLR(self.optG, gamma=0.95)
+        if self.singleD:
+            if self.optD is None:
+                self.optD = Adam(self.D.parameters(), lr=lr_D, betas=(0.5, 0.999))
+            self.scheD = optim.lr_scheduler.ExponentialLR(self.optD, gamma=0.95)
+        else:
+            self.optD = []
+            self.scheD = []
+            for i in self.classes:
+                self.optD.append(Adam(self.D[i].parameters(), lr=lr_D, betas=(0.5, 0.999)))
+                self.scheD.append(optim.lr_scheduler.ExponentialLR(self.optD[i], gamma=0.95))
+        if self.optE is None:
+            self.optE = Adam(self.E.parameters(), lr=lr_E, betas=(0.5, 0.999))
+        self.scheE = optim.lr_scheduler.ExponentialLR(self.optE, gamma=0.95)
+        return
+
+    def _onehot(self, label):
+        return class_encode(label, self.device, self.ref_label)
+
+    def G_transformation(self, target_label, source_image, encoder=False, ref_image=None):
+        class_vector = self._onehot(target_label)
+        if encoder:
+            latent, mu, logvar = self.E(ref_image, class_vector)
+            info = [latent, mu, logvar]
+            latent_vector = latent if self.encoded_feature == "latent" else mu
+        else:
+            latent_vector = self.noise_fn(source_image.shape[0], self.ndim).to(self.device)
+            info = latent_vector
+        target_image = self.G(source_image, torch.cat([class_vector, latent_vector], 1))
+        return target_image, info
+
+    def _mask(self, which, i):
+        return (torch.as_tensor(self.label[which]) == i)
+
+    def update_D(self):
+        self.target_image, self.c_rand = self.G_transformation(self.label["target"], self.source_image, False)
+        if self.singleD:
+            self.D.zero_grad()
+            output, output_class = self.D(self.source_image)
+            errD_real = get_loss_D(output, 1., self.criterion, self.device)
+            errD_class = get_domainloss_D(output_class, self._onehot(self.label["source"]), self.criterion_class)
+            errD = errD_real + errD_class * self.lbd["class"]
+            output, _ = self.D(self.target_image.detach())
+            errD = errD + get_loss_D(output, 0., self.criterion, self.device)
+            errD.backward()
+            self.optD.step()
+            return errD
+        errD = None
+        for i in self.classes:
+            errD = 0
+            self.D[i].zero_grad()
+            m_real, m_fake = self._mask("source", i), self._mask("target", i)
+            if int(m_real.sum()) != 0:
+                errD = errD + get_loss_D(self.D[i](_select_rows(self.source_image, m_real)), 1., self.criterion, self.device)
+            if int(m_fake.sum()) != 0:
+                fake = _select_rows(self.target_image.detach(), m_fake)
+                errD = errD + get_loss_D(self.D[i](fake), 0., self.criterion, self.device)
+            errD.backward()
+            self.optD[i].step()
+        return errD
+
+    def update_GandE(self):
+        L = self.lbd
+        self.G.zero_grad()
+        self.E.zero_grad()
+        src = self.source_image
+        recon_image, source_enc_info = self.G_transformation(self.label["source"], self.target_image, True, src)
+        d_params = list(self.D.parameters()) if self.singleD else [p for d in self.D for p in d.parameters()]
+        errG = 0
+        with _frozen(d_params):                      # D's weight gradients are discarded by the next zero_grad
+            if self.singleD:
+                output, output_class = self.D(self.target_image)
+                errG_dis = get_loss_D(output, 1., self.criterion, self.device)
+                errG_class = get_domainloss_D(output_class, self._onehot(self.label["target"]), self.criterion_class)
+                errG = errG + errG_dis + errG_class * L["class"]
+            else:
+                for i in self.classes:
+                    m = self._mask("target", i)
+                    if int(m.sum()) != 0:
+                        out = self.D[i](_select_rows(self.target_image, m))
+                        errG = errG + get_loss_D(out, 1., self.criterion, self.device) / len(self.classes)
+        errG_cycle = ops.l1_mean(src, recon_image, 1.0)
+        errG = errG + errG_cycle * L["cycle"]
+        errE = 0
+        errE_output = errG_cycle * L["cycle"]
+        terms = dict(errG_cycle=errG_cycle)
+        _, mu, logvar = source_enc_info
+        if L["KL"] > 0:
+            errE_KL = -0.5 * torch.sum(1 + logvar - mu ** 2 - logvar.exp())     # [B, ndim] scalars: host-side glue
+            errE = errE + errE_KL * L["KL"]
+            errE_output = errE_output + errE_KL * L["KL"]
+            terms["errE_KL"] = errE_KL
+        if L["idt"] > 0:
+            identity_image, _ = self.G_transformation(self.label["source"], src, True, src)
+            errG_idt = ops.l1_mean(src, identity_image, 1.0)
+            errG = errG + errG_idt * L["idt"]
+            errE_output = errE_output + errG_idt * L["idt"]
+            terms["errG_idt"] = errG_idt
+        if L["batch_KL"] > 0:
+            w_corr = L["corr_enc"] if L["corr_enc"] > 0 else 0.0
+            w_hist = L["hist"] if L["hist"] > 0 else 0.0
+            target = self.hi.target if w_hist > 0 else torch.full((50,), 0.02, device=mu.device)
+            total, parts, _ = ops.latent_losses(mu, self.n_batch, target, L["batch_KL"], w_corr, w_hist)
+            errE = errE + total
+            errE_output = errE_output + total
+            terms.update(errE_bKL=parts[0], errE_corr=parts[1], errE_hist=parts[2])
+        (errG + errE).backward(retain_graph=True)
+        self.optG.step()
+        self.optE.step()
+
+        self.G.zero_grad()
+        self.E.zero_grad()
+        with _frozen(list(self.E.parameters())):
+            _, target_cenc, _ = self.E(self.target_image, self._onehot(self.label["target"]))
+            errG_reg = ops.l1_mean(self.c_rand, target_cenc, 1.0)
+            errG_ex = errG_reg * L["reg"]
+            terms["errG_reg"] = errG_reg
+            if L["idt_reg"] * L["idt"] > 0:
+                idt_random_image, source_c_rand = self.G_transformation(self.label["source"], src, False)
+                _, idt_cenc_rand, _ = self.E(idt_random_image, self._onehot(self.label["source"]))
+                errG_idt_reg = ops.l1_mean(source_c_rand, idt_cenc_rand, 1.0)
+                errG_ex = errG_ex + errG_idt_reg * (L["idt_reg"] * (L["idt"] / L["cycle"]))
+                terms["errG_idt_reg"] = errG_idt_reg
+            errG_ex.backward()
+        self.optG.step()
+        self.recon_image = recon_image.detach()
+        self.loss_terms.update({k: v.detach() for k, v in terms.items()})
+        return [errG.detach() + errG_ex.detach(), errE_output.detach()]
+
+    def UnrolledUpdate(self):
+        errorD = None
+        for i in range(self.k):
+            errD = self.update_D()
+            if i == 0:
+                errorD = errD.detach()
+        errorG, errorE = self.update_GandE()
+        return [errorG, errorD, errorE]
+
+    def train(self, source_image, label):
+        self.source_image = ops.to_nhwc(source_image)
+        self.label = label
+        self.loss_terms = {}
+        return self.UnrolledUpdate()

@@ -240,10 +240,40 @@ def golden_train():
     np.savez_compressed(os.path.join(HERE, "train_F_b2_k1.npz"), **run_train("F", 2, 1, 2, seed=0))
 
 
+def run_singlegan(k, steps, seed, lbd, batch=8):
+    """Config 1 (notebook 01): conventional SingleGAN, 64x64, 2 domains, per-domain D list, Encoder_original."""
+    G = load_fill(ref_model.SingleGenerator(3, 4, 2, 2, 1, "instance", num_con=2 + 8), 20)
+    D = [load_fill(ref_model.SingleDiscriminator_original_multi(3, 4, 2, 4, "instance"), 21 + i) for i in range(2)]
+    E = load_fill(ref_model.Encoder_original(3, 8, 4, 4, "instance", 2, "cpu"), 25)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    sg = ref_nb.SingleGAN_training([G, D, E], [LegacyAdam(G.parameters()), None, LegacyAdam(E.parameters())],
+                                   [nn.MSELoss(), nn.MSELoss()], dict(lbd), k, "cpu", np.eye(2), 8, (0, 1), batch, "latent", False)
+    sg.opt_sche_initialization()
+    losses = []
+    for s in range(steps):
+        x, label = synthetic_batch(batch, 64, 2, seed=200 + s)
+        errG, errD, errE = sg.train(x, label)
+        losses.append([float(errG), float(errD), float(errE)])
+    out = {"losses": np.array(losses, dtype=np.float64)}
+    for name, net in (("G", sg.G), ("D0", sg.D[0]), ("D1", sg.D[1]), ("E", sg.E)):
+        for k_, v in net.state_dict().items():
+            out[f"{name}.{k_}"] = v.detach().float().numpy()
+    return out
+
+
+def golden_singlegan():
+    base = {"class": 0.0, "cycle": 5.0, "idt": 5.0, "reg": 0.5, "idt_reg": 0.0, "KL": 0.1, "batch_KL": 0.0, "corr_enc": 0.0, "hist": 0.0}
+    np.savez_compressed(os.path.join(HERE, "singlegan_T_b8_k1.npz"), **run_singlegan(1, 3, 0, base))
+    ext = dict(base, idt_reg=0.5)
+    np.savez_compressed(os.path.join(HERE, "singlegan_T_b8_k2_idtreg.npz"), **run_singlegan(2, 2, 0, ext))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_shapes()
     golden_modules()
     golden_losses()
     golden_train()
+    golden_singlegan()
     print("golden fixtures written to", HERE)

@@ -123,3 +123,19 @@ def test_trainer_signature_and_optimiser_setup():
         assert opt.param_groups[0]["lr"] == 1e-4 and opt.param_groups[0]["betas"] == (0.5, 0.999)
     sg.scheG.step()
     assert sg.optG.param_groups[0]["lr"] == pytest.approx(0.95e-4)
+
+
+def test_singlegan_trainer_signature():
+    import inspect
+    from srgan_amd.trainer import SingleGAN_training
+    sig = inspect.signature(SingleGAN_training.__init__)
+    assert list(sig.parameters)[1:] == ["net", "opt", "criterion", "lbd", "unrolled_k", "device", "ref_label", "ndim",
+                                        "classes", "batch_size", "encoded_feature", "singleD"]
+    assert sig.parameters["singleD"].default is False and sig.parameters["encoded_feature"].default == "latent"
+    G = model.SingleGenerator(3, 4, 2, 2, 1, "instance", num_con=10)
+    D = [model.SingleDiscriminator_original_multi(3, 4, 2, 4, "instance") for _ in range(2)]
+    E = model.Encoder_original(3, 8, 4, 4, "instance", 2, "cpu")
+    lbd = {"class": 0, "cycle": 5, "idt": 5, "reg": .5, "idt_reg": 0, "KL": .1, "batch_KL": 0, "corr_enc": 0, "hist": 0}
+    sg = SingleGAN_training([G, D, E], [None, "ignored", None], [nn.MSELoss(), nn.MSELoss()], lbd, 1, "cpu", np.eye(2), 8, (0, 1))
+    sg.opt_sche_initialization()
+    assert isinstance(sg.optD, list) and len(sg.optD) == 2 and len(sg.scheD) == 2     # always rebuilt per domain

@@ -177,3 +177,32 @@ def test_train_step_full_size(golden_dir):
             # the sensitive check of the update itself.
             np.testing.assert_allclose(v.flatten()[:8].numpy(), ck[2:], atol=4e-4)
             assert abs(float(v.norm()) - ck[1]) <= 1e-4 * max(ck[1], 1e-6)
+
+
+# ---- config 1: conventional SingleGAN (notebook 01) -------------------------------------------
+SG_BASE = dict(**{"class": 0.0}, cycle=5.0, idt=5.0, reg=0.5, idt_reg=0.0, KL=0.1, batch_KL=0.0, corr_enc=0.0, hist=0.0)
+
+
+def singlegan_params():
+    PG = params.fill(params.generator_spec(3, 4, 2, 2, 1, 10), 20)
+    PD = [params.fill(params.discriminator_original_spec(3, 4, 2, 4), 21 + i) for i in range(2)]
+    PE = params.fill(params.encoder_original_spec(3, 8, 4, 4, 2), 25)
+    return PG, PD, PE
+
+
+@pytest.mark.parametrize("name,k,steps,lbd", [("singlegan_T_b8_k1", 1, 3, SG_BASE),
+                                              ("singlegan_T_b8_k2_idtreg", 2, 2, dict(SG_BASE, idt_reg=0.5))])
+def test_singlegan_trajectory_vs_reference(golden_dir, name, k, steps, lbd):
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    PG, PD, PE = singlegan_params()
+    torch.manual_seed(0)
+    np.random.seed(0)
+    orc = trainer.SingleGANOracle(PG, PD, PE, lbd, k, np.eye(2), 8, (0, 1), 8, "latent")
+    traj = []
+    for s in range(steps):
+        x, label = trainer.synthetic_batch(8, 64, 2, seed=200 + s)
+        traj.append([float(v) for v in orc.train(x, label)])
+    np.testing.assert_allclose(np.array(traj), gold["losses"], rtol=2e-4)
+    for name_, P in (("G", orc.G), ("D0", orc.D[0]), ("D1", orc.D[1]), ("E", orc.E)):
+        for key, p in P.items():
+            close(p.detach(), gold[f"{name_}.{key}"], 3e-4, 3e-6)

@@ -107,3 +107,40 @@ def test_latent_mode_and_generic_encoder_path():
     sg.opt_sche_initialization()
     out = [float(v) for v in sg.train(x.cuda(), {"source": label["source"].cuda(), "target": label["target"]})]
     np.testing.assert_allclose(out, ref, rtol=1e-3)
+
+
+# ---- config 1: conventional SingleGAN (BASELINE configs[0]) on the HIP path --------------------------------
+SG_BASE = dict(**{"class": 0.0}, cycle=5.0, idt=5.0, reg=0.5, idt_reg=0.0, KL=0.1, batch_KL=0.0, corr_enc=0.0, hist=0.0)
+
+
+@pytest.mark.parametrize("name,k,steps,lbd", [("singlegan_T_b8_k1", 1, 3, SG_BASE),
+                                              ("singlegan_T_b8_k2_idtreg", 2, 2, dict(SG_BASE, idt_reg=0.5))])
+def test_singlegan_trajectory_vs_reference(golden_dir, name, k, steps, lbd):
+    from oracle import params
+    from srgan_amd import model
+    from srgan_amd.trainer import SingleGAN_training
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    G = model.SingleGenerator(3, 4, 2, 2, 1, "instance", num_con=10)
+    G.load_state_dict(params.fill(params.generator_spec(3, 4, 2, 2, 1, 10), 20))
+    D = []
+    for i in range(2):
+        d = model.SingleDiscriminator_original_multi(3, 4, 2, 4, "instance")
+        d.load_state_dict(params.fill(params.discriminator_original_spec(3, 4, 2, 4), 21 + i))
+        D.append(d.cuda())
+    E = model.Encoder_original(3, 8, 4, 4, "instance", 2, "cuda")
+    E.load_state_dict(params.fill(params.encoder_original_spec(3, 8, 4, 4, 2), 25))
+    G.cuda(), E.cuda()
+    torch.manual_seed(0)
+    np.random.seed(0)
+    sg = SingleGAN_training([G, D, E], [None, None, None], [nn.MSELoss(), nn.MSELoss()], dict(lbd), k, "cuda", np.eye(2), 8,
+                            (0, 1), 8, "latent", False)
+    sg.opt_sche_initialization()
+    traj = []
+    for s in range(steps):
+        x, label = otrainer.synthetic_batch(8, 64, 2, seed=200 + s)
+        out = sg.train(x.cuda(), {"source": label["source"].cuda(), "target": label["target"]})
+        traj.append([float(v) for v in out])
+    np.testing.assert_allclose(np.array(traj), gold["losses"], rtol=1e-3)
+    for name_, net, n_opt in (("G", sg.G, 2 * steps), ("D0", sg.D[0], k * steps), ("D1", sg.D[1], k * steps), ("E", sg.E, steps)):
+        for key, v in net.state_dict().items():
+            close_params(v, gold[f"{name_}.{key}"], 1e-4, n_opt, what=f"{name_}.{key}")
