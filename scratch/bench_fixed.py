@@ -1,0 +1,25 @@
+import sys, os, ctypes
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "style-restricted_gan_amd"))
+import torch
+from srgan_amd import ops, _lib
+lib = _lib.load()
+def kernel_time(fn, reps=8):
+    fn(); torch.cuda.synchronize()
+    lib.srgan_prof_enable(1)
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); lib.srgan_prof_enable(0)
+    tot=0; n=0
+    for kid in range(lib.srgan_prof_num_kernels()):
+        ms, c, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+        lib.srgan_prof_collect(kid, ctypes.byref(ms), ctypes.byref(c), ctypes.byref(fl))
+        tot+=ms.value; n+=c.value
+    return tot/n*1e3
+B, h, co = 32, 32, 256
+for ci, k in [(32,1),(64,1),(256,1),(32,3),(64,3),(128,3),(256,3),(512,3),(1024,3)]:
+    x = torch.randn(B, h, h, ci, device="cuda").permute(0, 3, 1, 2)
+    w = torch.randn(co, ci, k, k, device="cuda") / 48
+    y = ops.conv2d(x, w, None, 1, k//2)
+    desc = ops._conv_desc(B, h, h, ci, h, h, co, k, k, 1, k//2, 0, w)
+    fl = 2.0 * B * h * h * co * k * k * ci
+    t = kernel_time(lambda: ops._run_conv_fwd(desc, x, w, None, y, 0, 0.0))
+    print(f"Cin={ci:5d} k={k} Ktiles={ci*k*k//32:4d} kernel {t:8.1f} us  {fl/t/1e6:6.1f} TF")

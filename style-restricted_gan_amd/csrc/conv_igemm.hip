@@ -19,6 +19,7 @@
 // flight while the current tile is multiplied.  Within a 32-deep K tile lane (r, h) feeds the
 // MFMA k-slots {8q+4h+e} so that A and B fragments come from single ds_read_b128's.
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "common.h"
@@ -36,8 +37,8 @@ static size_t g_prof_next = 0;
 static const char* const kProfNames[] = {
     "igemm_kernel<128,128,2,2,gen>", "igemm_kernel<128,128,2,2,vec>", "igemm_kernel<128,64,2,2,gen>", "igemm_kernel<128,64,2,2,vec>",
     "igemm_kernel<128,32,4,1,gen>",  "igemm_kernel<128,32,4,1,vec>",  "igemm_kernel<64,64,2,2,gen>",  "igemm_kernel<64,64,2,2,vec>",
-    "wgrad_kernel<gen>", "wgrad_kernel<vec>"};
-constexpr int kProfKernels = 10;
+    "wgrad_kernel<gen>", "wgrad_kernel<vec>", "igemm_kernel<256,128,4,2,gen>", "igemm_kernel<256,128,4,2,vec>"};
+constexpr int kProfKernels = 12;
 
 struct ProfScope {
   bool on;
@@ -82,9 +83,12 @@ constexpr int BK = 32;
 constexpr int LDK = BK + 4;
 
 template <int BM, int BN, int WM, int WN, bool VEC>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int NT = WM * WN * 64;        // threads per workgroup (4 or 8 waves)
+  constexpr int RP = NT / 8;              // tile rows staged per pass of float4 loads (8 float4 = 32 floats per row)
+  constexpr int RG = NT / 32;             // tile rows staged per pass of the generic element gather
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   // double-buffered operand tiles: tile t+1 is written while tile t is multiplied (one barrier per K tile)
   __shared__ __attribute__((aligned(16))) float As2[2][BM * LDK];
   __shared__ __attribute__((aligned(16))) float Bs2[2][BN * LDK];
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const int sgn = p.mode == 0 ? 1 : -1;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  for (int r = tid; r < BM; r += 256) {
+  for (int r = tid; r < BM; r += NT) {
     int m = m0 + r;
     int n = 0, y0 = -(1 << 28), x0 = -(1 << 28), o = -1;
     if (m < p.M) {
@@ -125,9 +129,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const int nk = p.Kpad / BK;
 
   // staging registers
-  constexpr int A_VEC_IT = BM / 32;      // float4 per thread (VEC)
-  constexpr int A_SC_IT = BM / 8;        // scalars per thread (generic)
-  constexpr int B_IT = BN / 32;
+  constexpr int A_VEC_IT = BM / RP;      // float4 per thread (VEC)
+  constexpr int A_SC_IT = BM / RG;       // scalars per thread (generic)
+  constexpr int B_IT = BN / RP;
   f32x4 a_reg[VEC ? A_VEC_IT : 1];
   float a_sc[VEC ? 1 : A_SC_IT];
   f32x4 b_reg[B_IT];
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const unsigned seg16 = (tid & 7) * 16;
 #pragma unroll
     for (int i = 0; i < A_VEC_IT; ++i) {
-      const int r = (tid >> 3) + 32 * i;
+      const int r = (tid >> 3) + RP * i;
       const int y0 = row_y[r], x0 = row_x[r];
       const bool rowok = y0 > -(1 << 27);
       const long long lin = rowok ? ((long long)(row_n[r] * p.Hs + y0) * p.Ws + x0) * p.Cs : 0;
@@ -180,10 +184,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             mx |= (unsigned)(x - x0) << (4 * t);
           }
         } else {
-          for (int t = 0; t < p.Ty * p.Tx; ++t) {
-            const int ty = t / p.Tx, tx = t - ty * p.Tx;
-            const int y = y0 + sgn * ty, x = x0 + sgn * tx;
-            if ((unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws) m |= 1ull << t;
+          int t = 0;
+          for (int ty = 0; ty < p.Ty; ++ty) {
+            const bool yok = (unsigned)(y0 + sgn * ty) < (unsigned)p.Hs;
+            for (int tx = 0; tx < p.Tx; ++tx, ++t)
+              if (yok && (unsigned)(x0 + sgn * tx) < (unsigned)p.Ws) m |= 1ull << t;
           }
         }
       }
@@ -196,6 +201,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const int k0 = kt * BK;
     if constexpr (VEC) {
       const unsigned seg16 = (tid & 7) * 16;
+      const unsigned cs4 = p.Cs * 4;
       const int t = tap_y * p.Tx + tap_x;
       const long long tap_lin = p.reflect ? 0 : (long long)sgn * (tap_y * p.Ws + tap_x) * p.Cs;
       const char* sb = reinterpret_cast<const char*>(p.src) + (tap_lin + tap_c - bias) * 4;   // wave-uniform
@@ -203,20 +209,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < A_VEC_IT; ++i) {
         const bool ok = (vmask[i] >> t) & 1;
-        unsigned off = voff[i];
-        if (p.reflect) {
-          const unsigned dyv = (mapy[i] >> (4 * tap_y)) & 15u, dxv = (mapx[i] >> (4 * tap_x)) & 15u;
-          off += (dyv * p.Ws + dxv) * p.Cs * 4;
-        }
+        // reflect: mirrored displacement from the nibble maps (all-zero maps otherwise, so no branch is needed)
+        const unsigned dyv = (mapy[i] >> (4 * tap_y)) & 15u, dxv = (mapx[i] >> (4 * tap_x)) & 15u;
+        unsigned off = voff[i] + (dyv * p.Ws + dxv) * cs4;
         off = ok ? off : safe;
         a_reg[i] = *reinterpret_cast<const f32x4*>(sb + off);
         a_msk[i] = ok ? 1.f : 0.f;          // applied when the tile is written to LDS (keeps the load in flight)
       }
-      tap_c += BK;
-      if (tap_c == p.Cs) {
-        tap_c = 0;
-        if (++tap_x == p.Tx) { tap_x = 0; ++tap_y; }
-      }
+      tap_c += BK;                                  // wave-uniform counters, branch-free wrap
+      const int wc = tap_c == p.Cs;
+      tap_c = wc ? 0 : tap_c;
+      tap_x += wc;
+      const int wx = tap_x == p.Tx;
+      tap_x = wx ? 0 : tap_x;
+      tap_y += wx;
     } else {
       const int kk = tid & 31;
       const int k = k0 + kk;
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       const int ty = t / p.Tx, tx = t - ty * p.Tx;
 #pragma unroll
       for (int i = 0; i < A_SC_IT; ++i) {
-        const int r = (tid >> 5) + 8 * i;
+        const int r = (tid >> 5) + RG * i;
         bool ok;
         size_t off = src_index(r, ty, tx, ok);
         a_sc[i] = (ok && kok) ? p.src[off + c] : 0.f;
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const int seg = tid & 7;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      const int r = (tid >> 3) + 32 * i;
+      const int r = (tid >> 3) + RP * i;
       b_reg[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)r * p.Kpad + k0 + seg * 4);
     }
   };
@@ -247,21 +253,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       const int seg = tid & 7;
 #pragma unroll
       for (int i = 0; i < A_VEC_IT; ++i) {
-        const int r = (tid >> 3) + 32 * i;
+        const int r = (tid >> 3) + RP * i;
         *reinterpret_cast<f32x4*>(&As[r * LDK + seg * 4]) = a_reg[i] * a_msk[i];
       }
     } else {
       const int kk = tid & 31;
 #pragma unroll
       for (int i = 0; i < A_SC_IT; ++i) {
-        const int r = (tid >> 5) + 8 * i;
+        const int r = (tid >> 5) + RG * i;
         As[r * LDK + kk] = a_sc[i];
       }
     }
     const int seg = tid & 7;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      const int r = (tid >> 3) + 32 * i;
+      const int r = (tid >> 3) + RP * i;
       *reinterpret_cast<f32x4*>(&Bs[r * LDK + seg * 4]) = b_reg[i];
     }
   };
@@ -425,7 +431,9 @@ struct WgradParams {
   int NN, NNpad, Cdpad, M, rows_per_split, co_tiles, nn_tiles;
 };
 
-template <int BMc, int BNn, int WM, int WN, bool VEC>
+// ROWS: every 32-pixel K tile lies inside one image row (Wg % 32 == 0, VEC only): the tile's (n, y) and the source row
+// base are wave-uniform scalars advanced with counters; a thread only adds its constant column offset.
+template <int BMc, int BNn, int WM, int WN, bool VEC, bool ROWS = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   constexpr int TM = BMc / (WM * 32), TN = BNn / (WN * 32);
   constexpr int A_IT = BMc / 32, B_IT = BNn / 32;     // float4 per thread per 32-row tile
@@ -485,7 +493,67 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     return ((size_t)(rowtab[buf][0][r] * p.Hi + y) * p.Wi + x) * p.Cs;
   };
 
+  // ---- ROWS fast path state (wave-uniform) ----
+  int rw_n = 0, rw_a = 0, rw_b = 0;            // image, grid row, first grid column of the NEXT tile to load
+  int tap_ty = 0, tap_tx = 0, tap_c0 = 0;
+  if constexpr (ROWS) {
+    const int hw = p.Hg * p.Wg;
+    rw_n = m_begin / hw;
+    const int rem = m_begin - rw_n * hw;
+    rw_a = rem / p.Wg;
+    rw_b = rem - rw_a * p.Wg;
+    const int tp = nn0 / p.Cs;
+    tap_c0 = nn0 - tp * p.Cs;
+    tap_ty = tp / p.kw;
+    tap_tx = tp - tap_ty * p.kw;
+  }
+
+  auto load_tile_rows = [&](int t) {
+    const int mb = m_begin + t * 32;
+    // A': 32 dense rows of dy starting at row mb (all valid: m_end - m_begin is a multiple of 32 on this path)
+    const float* abase = p.dy + (size_t)mb * p.Cd + co0;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx / A_PR, c4 = idx - r * A_PR;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (co0 + c4 * 4 < p.Cd) v = *reinterpret_cast<const f32x4*>(abase + (size_t)r * p.Cd + c4 * 4);
+      a_reg[i] = v;
+    }
+    // B': source row y is uniform for the tile; x = (b0 + r)*stride - pad + tx varies with the thread's row
+    int y = rw_a * p.stride - p.pad + tap_ty;
+    if (p.reflect) {
+      y = y < 0 ? -y : y;
+      y = y >= p.Hi ? 2 * p.Hi - 2 - y : y;
+    }
+    const bool yok = (unsigned)y < (unsigned)p.Hi;
+    const float* bbase = p.x + ((size_t)(rw_n * p.Hi + (yok ? y : 0)) * p.Wi) * p.Cs + tap_c0;
+    const int x0 = rw_b * p.stride - p.pad + tap_tx;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx / B_PR, c4 = idx - r * B_PR;
+      int x = x0 + r * p.stride;
+      if (p.reflect) {
+        x = x < 0 ? -x : x;
+        x = x >= p.Wi ? 2 * p.Wi - 2 - x : x;
+      }
+      const bool ok = yok && (unsigned)x < (unsigned)p.Wi;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(bbase + (size_t)(ok ? x : 0) * p.Cs + c4 * 4);
+      const float mk = ok ? 1.f : 0.f;
+      b_reg[i] = v * mk;
+    }
+    rw_b += 32;                                  // next tile: same image row, or wrap (Wg % 32 == 0)
+    const int wb = rw_b == p.Wg;
+    rw_b = wb ? 0 : rw_b;
+    rw_a += wb;
+    const int wa = rw_a == p.Hg;
+    rw_a = wa ? 0 : rw_a;
+    rw_n += wa;
+  };
+
   auto load_tile = [&](int t) {
+    if constexpr (ROWS) { load_tile_rows(t); return; }
     const int mb = m_begin + t * 32, buf = t & 1;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -567,10 +635,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   };
 
   if (ntiles > 0) {
-    if (tid < 32) fill_rowtab(0);
+    if (!ROWS && tid < 32) fill_rowtab(0);
     __syncthreads();
     load_tile(0);
-    if (ntiles > 1 && tid < 32) fill_rowtab(1);
+    if (!ROWS && ntiles > 1 && tid < 32) fill_rowtab(1);
     store_tile(0);
     __syncthreads();                    // tile 0 in LDS, rowtab[1] visible
     if (ntiles > 1) load_tile(1);
@@ -579,7 +647,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     const int cur = t & 1;
     if (active) mfma_range(cur, 0, 8);
     if (t + 1 < ntiles) store_tile(cur ^ 1);               // tile t+1: its loads were issued half a tile ago
-    if (t + 2 < ntiles && tid < 32) fill_rowtab(t + 2);    // into rowtab[cur]: tile t's rows are no longer needed
+    if (!ROWS && t + 2 < ntiles && tid < 32) fill_rowtab(t + 2);   // into rowtab[cur]: tile t's rows are no longer needed
     if (active) mfma_range(cur, 8, 16);
     __syncthreads();                    // tile t+1 and rowtab[cur] visible; everyone is done reading tile t
     if (t + 2 < ntiles) load_tile(t + 2);                  // in flight during the first half of tile t+1
@@ -651,18 +719,23 @@ TileChoice choose_tile(long long M, int N) {
   if (N <= 64) return {128, 64};
   long long tiles = ceil_div(M, 128) * ceil_div(N, 128);
   if (tiles < 256) return {64, 64};
+  // 8-wave 256x128 workgroups (one per CU, both waves of a SIMD barrier-coupled) when the grid fills the chip in whole
+  // rounds: avoids the tail in which one of two independent co-resident workgroups runs alone on its SIMDs
+  static const bool big = std::getenv("SRGAN_NO_BIG_TILE") == nullptr;
+  long long big_tiles = ceil_div(M, 256) * ceil_div(N, 128);
+  if (big && M % 256 == 0 && big_tiles >= 256) return {256, 128};
   return {128, 128};
 }
 
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(const IgemmParams& p, int phases, bool vec, hipStream_t st, double flops) {
-  constexpr int tile_id = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 128 && BN == 32) ? 2 : 3;
+  constexpr int tile_id = (BM == 256) ? 5 : (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 128 && BN == 32) ? 2 : 3;
   ProfScope scope(tile_id * 2 + (vec ? 1 : 0), flops, st);
   dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)phases, 1);
   if (vec)
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, st, p);
   else
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(WM * WN * 64), 0, st, p);
   return check_launch("igemm_kernel");
 }
 
@@ -671,6 +744,8 @@ int run_igemm(IgemmParams p, int phases, hipStream_t st, double flops) {
   p.m_tiles = (int)ceil_div(p.M, tc.BM);
   p.n_tiles = (int)ceil_div(p.Cd, tc.BN);
   const bool vec = (p.Cs % BK) == 0;
+  if (tc.BM == 256 && vec) return launch_igemm<256, 128, 4, 2>(p, phases, true, st, flops);
+  if (tc.BM == 256) { tc = {128, 128}; p.m_tiles = (int)ceil_div(p.M, 128); }
   if (tc.BM == 128 && tc.BN == 128) return launch_igemm<128, 128, 2, 2>(p, phases, vec, st, flops);
   if (tc.BM == 128 && tc.BN == 64) return launch_igemm<128, 64, 2, 2>(p, phases, vec, st, flops);
   if (tc.BM == 128 && tc.BN == 32) return launch_igemm<128, 32, 4, 1>(p, phases, vec, st, flops);
@@ -721,7 +796,8 @@ WgradPlan plan_wgrad(const srgan_conv_desc* d) {
   w.Cdpad = w.co_tiles * w.BMc;
   w.NNpad = w.nn_tiles * w.BNn;
   long long tiles = (long long)w.co_tiles * w.nn_tiles;
-  long long want = ceil_div(1024, tiles);                 // ~4 blocks per CU (768 measured slower: 82 vs 89 TFLOP/s)
+  static const long long wg_target = std::getenv("SRGAN_WGRAD_BLOCKS") ? std::atoll(std::getenv("SRGAN_WGRAD_BLOCKS")) : 1024;
+  long long want = ceil_div(wg_target, tiles);            // ~4 blocks per CU (768 measured slower: 82 vs 89 TFLOP/s)
   long long max_splits = ceil_div(M, 256);                // at least 8 K-tiles per split
   long long splits = want < 1 ? 1 : want;
   if (splits > max_splits) splits = max_splits;
@@ -844,7 +920,11 @@ template <int BMc, int BNn, int WM, int WN>
 static int launch_wgrad(const WgradParams& p, const WgradPlan& w, hipStream_t st) {
   ProfScope scope(8 + (w.vec ? 1 : 0), 2.0 * p.M * (double)p.Cd * p.NN, st);
   dim3 grid((unsigned)(w.co_tiles * w.nn_tiles * w.splits), 1, 1);
-  if (w.vec)
+  // row-aligned fast path: every 32-pixel tile inside one image row, every split a whole number of tiles
+  const bool rows = w.vec && (p.Wg % 32) == 0 && (p.rows_per_split % 32) == 0 && (p.M % 32) == 0 && (p.Cd % 4) == 0;
+  if (rows && BMc >= 64 && BNn >= 64)
+    hipLaunchKernelGGL((wgrad_kernel<(BMc >= 64 ? BMc : 64), (BNn >= 64 ? BNn : 64), (BMc >= 64 && BNn >= 64 ? WM : 2), (BMc >= 64 && BNn >= 64 ? WN : 2), true, true>), grid, dim3(256), 0, st, p);
+  else if (w.vec)
     hipLaunchKernelGGL((wgrad_kernel<BMc, BNn, WM, WN, true>), grid, dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL((wgrad_kernel<BMc, BNn, WM, WN, false>), grid, dim3(256), 0, st, p);

@@ -52,6 +52,10 @@ CONV_CASES = [
     (3, 16, 40, 72, 4, 3, 1, 1, False, True),     # narrow-output, Cout=4, one channel chunk
     (4, 128, 48, 48, 256, 3, 1, 1, False, False), # 128x128 block tiles on both GEMM kernels, split-K > 1
     (8, 64, 64, 64, 64, 4, 2, 1, False, False),   # 128x64 tiles, many M tiles
+    (4, 64, 32, 32, 128, 3, 1, 1, False, False),  # row-aligned weight-gradient path (Wo % 32 == 0), zero pad
+    (2, 32, 32, 64, 64, 3, 1, 1, True, False),    # row-aligned weight-gradient path with reflect padding
+    (2, 128, 64, 64, 128, 4, 2, 1, False, False), # row-aligned path, stride 2, 128x128 tiles, several splits
+    (32, 256, 16, 16, 256, 3, 1, 1, False, False),# 8-wave 256x128 forward / dgrad tiles
 ]
 
 
