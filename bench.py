@@ -95,6 +95,20 @@ def cpu_baseline(size, k):
                       f"({size}x{size}) after a k=1 batch-2 warm-up; {dt:.1f} s on {cores} threads"}
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed PMC summary (profiles/r*_pmc_traffic.json, collected
+    with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same bench command), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        entry = json.load(open(files[-1]))["kernels"].get(kernel_name)
+        return entry["hbm_bytes_per_launch"] if entry else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,8 +195,9 @@ def main():
                        "step_tflops_algorithmic": round(value * GFLOP_PER_IMAGE.get(args.size, 0) / 1e3, 2),
                        "losses_last_step": [round(float(v), 4) for v in last]},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(name),
                          "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
+                         "traffic_note": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, profiles/r*_pmc_traffic.json)",
                          "note": "achieved = sum of algorithmic conv FLOPs (2*N*Ho*Wo*O*kh*kw*I) of this kernel's launches / "
                                  "sum of their HIP-event durations inside the timed region (rank 0)",
                          "all_gemm_kernels": kernels},
