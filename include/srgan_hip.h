@@ -58,6 +58,16 @@ int srgan_conv2d_fwd(const srgan_conv_desc* d, const float* x, const float* w, c
 int srgan_conv2d_dgrad(const srgan_conv_desc* d, const float* dy, const float* w, float* dx,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* Packed-weight variants: the repacked weight operand ([phase][Npad][Kpad], or the narrow-output layout) depends only
+ * on (desc, kind, act); pack it once per optimiser step and reuse it for every forward (kind 0) / input-gradient
+ * (kind 1) of that step.  srgan_conv2d_fwd / _dgrad are exactly pack-into-workspace + the packed call. */
+size_t srgan_conv2d_packed_bytes(const srgan_conv_desc* d, int kind, int act);
+int srgan_conv2d_pack(const srgan_conv_desc* d, int kind, int act, const float* w, void* packed, size_t bytes, void* stream);
+int srgan_conv2d_fwd_packed(const srgan_conv_desc* d, const float* x, const void* packed, const float* bias, float* y,
+                            int act, float slope, void* stream);
+int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* dy, const void* packed, float* dx,
+                              void* ws, size_t ws_bytes, void* stream);
+
 /* Gradient w.r.t. the conv weight, written through (sO,sI,sH,sW) (overwrites, no accumulate);
  * dbias[O] (may be NULL) = column sums of dy. */
 int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, const float* dy, float* dw,

@@ -74,7 +74,8 @@ __device__ __forceinline__ float act_grad(float v, int act, float slope) {
 // conv_narrow.hip: direct kernels for Cout <= 4, stride-1, zero-pad layers
 bool narrow_applicable(const srgan_conv_desc* d);
 size_t narrow_workspace(const srgan_conv_desc* d);
-int narrow_fwd(const srgan_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, hipStream_t st);
+int narrow_pack(const srgan_conv_desc* d, const float* w, float* wp, hipStream_t st);
+int narrow_fwd_packed(const srgan_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, hipStream_t st);
 bool narrow_wave_applicable(const srgan_conv_desc* d);
 int narrow_wave_fwd(const srgan_conv_desc* d, const float* x, const float* wp, int Kpad, const float* bias, float* y, hipStream_t st);
 bool dense_head_applicable(const srgan_conv_desc* d);

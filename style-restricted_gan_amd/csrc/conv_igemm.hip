@@ -838,35 +838,124 @@ extern "C" size_t srgan_conv2d_workspace(const srgan_conv_desc* d) {
   return bytes + 4096;
 }
 
+namespace srgan {
+// ---- forward: which kernel family serves this layer, and the packed-weight layout it wants ----
+enum FwdPath { PATH_IGEMM = 0, PATH_NARROW = 1, PATH_WAVE = 2, PATH_DENSE = 3 };
+
+static FwdPath fwd_path(const srgan_conv_desc* d, int act) {
+  if (act == SRGAN_ACT_NONE) {
+    if (dense_head_applicable(d)) return PATH_DENSE;
+    if (narrow_wave_applicable(d)) return PATH_WAVE;
+    if (narrow_applicable(d)) return PATH_NARROW;
+  }
+  return PATH_IGEMM;
+}
+
+static void fwd_geometry(const srgan_conv_desc* d, FwdPath path, IgemmParams& p) {
+  p.NB = d->N; p.Hs = d->Hi; p.Ws = d->Wi; p.Cs = d->I;
+  p.Hg = d->Ho; p.Wg = d->Wo; p.Hd = d->Ho; p.Wd = d->Wo; p.Cd = d->O;
+  p.mode = 0; p.stride = d->stride; p.pad = d->pad; p.Ty = d->kh; p.Tx = d->kw;
+  p.K = d->kh * d->kw * d->I; p.Kpad = (int)round_up(p.K, BK);
+  p.M = d->N * d->Ho * d->Wo;
+  p.Npad = (path == PATH_WAVE || path == PATH_DENSE) ? d->O : npad_for(p.M, d->O);
+  p.reflect = d->pad_mode == SRGAN_PAD_REFLECT;
+}
+
+static size_t fwd_packed_bytes(const srgan_conv_desc* d, int act) {
+  const FwdPath path = fwd_path(d, act);
+  if (path == PATH_NARROW) return (size_t)d->I * d->kh * d->kw * 4 * sizeof(float);
+  IgemmParams p{};
+  fwd_geometry(d, path, p);
+  return (size_t)p.Npad * p.Kpad * sizeof(float);
+}
+
+static int fwd_pack(const srgan_conv_desc* d, int act, const float* w, float* dst, hipStream_t st) {
+  const FwdPath path = fwd_path(d, act);
+  if (path == PATH_NARROW) return narrow_pack(d, w, dst, st);
+  IgemmParams p{};
+  fwd_geometry(d, path, p);
+  PackParams q{};
+  q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
+  q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 0; q.stride = d->stride; q.pad = d->pad;
+  q.Ty = d->kh; q.Tx = d->kw; q.Cs = d->I; q.N = d->O; q.K = p.K; q.Kpad = p.Kpad; q.Npad = p.Npad; q.phases = 1;
+  long long total = (long long)q.Npad * q.Kpad;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
+  return check_launch("pack_weights_kernel");
+}
+
+static int fwd_run(const srgan_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act,
+                   float slope, hipStream_t st) {
+  const FwdPath path = fwd_path(d, act);
+  if (path == PATH_NARROW) return narrow_fwd_packed(d, x, wp, bias, y, st);
+  IgemmParams p{};
+  fwd_geometry(d, path, p);
+  p.src = x; p.bias = bias; p.dst = y; p.act = act; p.slope = slope; p.wp = wp;
+  if (path == PATH_DENSE) return dense_head_fwd(d, x, wp, p.Kpad, bias, y, st);
+  if (path == PATH_WAVE) return narrow_wave_fwd(d, x, wp, p.Kpad, bias, y, st);
+  return run_igemm(p, 1, st, conv_flops(d));
+}
+
+// ---- input gradient / transposed-conv forward ----
+struct DgradGeom { IgemmParams p; int phases; bool reflect; int Hd, Wd; size_t packed_elems; };
+
+static DgradGeom dgrad_geometry(const srgan_conv_desc* d) {
+  DgradGeom g{};
+  g.reflect = d->pad_mode == SRGAN_PAD_REFLECT;
+  const int s = d->stride;
+  // reflect: gradient w.r.t. the padded image (a pad-0 conv over Hi+2P), then fold.
+  const int P = g.reflect ? d->pad : 0;
+  g.Hd = d->Hi + 2 * P; g.Wd = d->Wi + 2 * P;
+  IgemmParams& p = g.p;
+  p.bias = nullptr;
+  p.NB = d->N; p.Hs = d->Ho; p.Ws = d->Wo; p.Cs = d->O;
+  p.Hg = (int)ceil_div(g.Hd, s); p.Wg = (int)ceil_div(g.Wd, s);
+  p.Hd = g.Hd; p.Wd = g.Wd; p.Cd = d->I;
+  p.mode = 1; p.stride = s; p.pad = g.reflect ? 0 : d->pad;
+  p.Ty = (int)ceil_div(d->kh, s); p.Tx = (int)ceil_div(d->kw, s);
+  p.K = p.Ty * p.Tx * d->O; p.Kpad = (int)round_up(p.K, BK);
+  p.M = d->N * p.Hg * p.Wg;
+  p.Npad = npad_for(p.M, d->I);
+  p.reflect = 0; p.act = SRGAN_ACT_NONE; p.slope = 0.f;
+  g.phases = s * s;
+  g.packed_elems = (size_t)g.phases * p.Npad * p.Kpad;
+  return g;
+}
+
+static int dgrad_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st) {
+  DgradGeom g = dgrad_geometry(d);
+  PackParams q{};
+  q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
+  q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 1; q.stride = d->stride; q.pad = g.p.pad;
+  q.Ty = g.p.Ty; q.Tx = g.p.Tx; q.Cs = d->O; q.N = d->I; q.K = g.p.K; q.Kpad = g.p.Kpad; q.Npad = g.p.Npad; q.phases = g.phases;
+  long long total = (long long)g.packed_elems;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
+  return check_launch("pack_weights_kernel");
+}
+
+// `scratch`: room for the padded gradient when the conv is reflect-padded
+static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp, float* dx, float* scratch, hipStream_t st) {
+  DgradGeom g = dgrad_geometry(d);
+  g.p.src = dy; g.p.wp = wp;
+  g.p.dst = g.reflect ? scratch : dx;
+  if (int e = run_igemm(g.p, g.phases, st, conv_flops(d))) return e;
+  if (g.reflect) {
+    long long n = (long long)d->N * d->Hi * d->Wi * d->I;
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 256), 8192)), dim3(256), 0, st,
+                       (const float*)scratch, dx, d->N, d->Hi, d->Wi, d->I, d->pad);
+    return check_launch("reflect_fold_kernel");
+  }
+  return 0;
+}
+}  // namespace srgan
+
 extern "C" int srgan_conv2d_fwd(const srgan_conv_desc* d, const float* x, const float* w, const float* bias,
                                 float* y, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
   if (int e = validate(d)) return e;
   SRGAN_REQUIRE(x && w && y && ws, "conv2d_fwd: null pointer");
   SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_fwd: workspace too small");
   hipStream_t st = as_stream(stream);
-  const bool wave_path = act == SRGAN_ACT_NONE && narrow_wave_applicable(d) && !dense_head_applicable(d);
-  if (act == SRGAN_ACT_NONE && !wave_path && narrow_applicable(d)) return narrow_fwd(d, x, w, bias, y, ws, st);
-  IgemmParams p{};
-  p.src = x; p.bias = bias; p.dst = y;
-  p.NB = d->N; p.Hs = d->Hi; p.Ws = d->Wi; p.Cs = d->I;
-  p.Hg = d->Ho; p.Wg = d->Wo; p.Hd = d->Ho; p.Wd = d->Wo; p.Cd = d->O;
-  p.mode = 0; p.stride = d->stride; p.pad = d->pad; p.Ty = d->kh; p.Tx = d->kw;
-  p.K = d->kh * d->kw * d->I; p.Kpad = (int)round_up(p.K, BK);
-  p.M = d->N * d->Ho * d->Wo;
-  p.Npad = wave_path ? d->O : npad_for(p.M, d->O);
-  p.reflect = d->pad_mode == SRGAN_PAD_REFLECT;
-  p.act = act; p.slope = slope;
-  PackParams q{};
-  q.w = w; q.dst = (float*)ws; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
-  q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 0; q.stride = d->stride; q.pad = d->pad;
-  q.Ty = d->kh; q.Tx = d->kw; q.Cs = d->I; q.N = d->O; q.K = p.K; q.Kpad = p.Kpad; q.Npad = p.Npad; q.phases = 1;
-  long long total = (long long)q.Npad * q.Kpad;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
-  if (int e = check_launch("pack_weights_kernel")) return e;
-  p.wp = (const float*)ws;
-  if (act == SRGAN_ACT_NONE && dense_head_applicable(d)) return dense_head_fwd(d, x, p.wp, p.Kpad, bias, y, st);
-  if (wave_path) return narrow_wave_fwd(d, x, p.wp, p.Kpad, bias, y, st);
-  return run_igemm(p, 1, st, conv_flops(d));
+  if (int e = fwd_pack(d, act, w, (float*)ws, st)) return e;
+  return fwd_run(d, x, (const float*)ws, bias, y, act, slope, st);
 }
 
 extern "C" int srgan_conv2d_dgrad(const srgan_conv_desc* d, const float* dy, const float* w, float* dx,
@@ -875,44 +964,40 @@ extern "C" int srgan_conv2d_dgrad(const srgan_conv_desc* d, const float* dy, con
   SRGAN_REQUIRE(dy && w && dx && ws, "conv2d_dgrad: null pointer");
   SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_dgrad: workspace too small");
   hipStream_t st = as_stream(stream);
-  const bool reflect = d->pad_mode == SRGAN_PAD_REFLECT;
-  const int s = d->stride;
-  // reflect: gradient w.r.t. the padded image (a pad-0 conv over Hi+2P), then fold.
-  const int P = reflect ? d->pad : 0;
-  const int Hd = d->Hi + 2 * P, Wd = d->Wi + 2 * P;
-  const int pad_eff = reflect ? 0 : d->pad;
-  IgemmParams p{};
-  p.src = dy; p.bias = nullptr;
-  p.NB = d->N; p.Hs = d->Ho; p.Ws = d->Wo; p.Cs = d->O;
-  p.Hg = (int)ceil_div(Hd, s); p.Wg = (int)ceil_div(Wd, s);
-  p.Hd = Hd; p.Wd = Wd; p.Cd = d->I;
-  p.mode = 1; p.stride = s; p.pad = pad_eff;
-  p.Ty = (int)ceil_div(d->kh, s); p.Tx = (int)ceil_div(d->kw, s);
-  p.K = p.Ty * p.Tx * d->O; p.Kpad = (int)round_up(p.K, BK);
-  p.M = d->N * p.Hg * p.Wg;
-  p.Npad = npad_for(p.M, d->I);
-  p.reflect = 0; p.act = SRGAN_ACT_NONE; p.slope = 0.f;
-  const int phases = s * s;
-  float* packed = (float*)ws;
-  size_t packed_elems = (size_t)phases * p.Npad * p.Kpad;
-  float* padded = (float*)ws + round_up((long long)packed_elems, 64);
-  PackParams q{};
-  q.w = w; q.dst = packed; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
-  q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 1; q.stride = s; q.pad = pad_eff;
-  q.Ty = p.Ty; q.Tx = p.Tx; q.Cs = d->O; q.N = d->I; q.K = p.K; q.Kpad = p.Kpad; q.Npad = p.Npad; q.phases = phases;
-  long long total = (long long)packed_elems;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
-  if (int e = check_launch("pack_weights_kernel")) return e;
-  p.wp = packed;
-  p.dst = reflect ? padded : dx;
-  if (int e = run_igemm(p, phases, st, conv_flops(d))) return e;
-  if (reflect) {
-    long long n = (long long)d->N * d->Hi * d->Wi * d->I;
-    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 256), 8192)), dim3(256), 0, st,
-                       padded, dx, d->N, d->Hi, d->Wi, d->I, d->pad);
-    return check_launch("reflect_fold_kernel");
-  }
-  return 0;
+  DgradGeom g = dgrad_geometry(d);
+  if (int e = dgrad_pack(d, w, (float*)ws, st)) return e;
+  return dgrad_run(d, dy, (const float*)ws, dx, (float*)ws + round_up((long long)g.packed_elems, 64), st);
+}
+
+// ---- packed-weight variants: pack once per optimiser step, reuse across the step's forwards / backwards ----
+extern "C" size_t srgan_conv2d_packed_bytes(const srgan_conv_desc* d, int kind, int act) {
+  if (validate(d) != 0) return 0;
+  return kind == 0 ? fwd_packed_bytes(d, act) : dgrad_geometry(d).packed_elems * sizeof(float);
+}
+
+extern "C" int srgan_conv2d_pack(const srgan_conv_desc* d, int kind, int act, const float* w, void* packed, size_t bytes,
+                                 void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(w && packed, "conv2d_pack: null pointer");
+  SRGAN_REQUIRE(kind == 0 || kind == 1, "conv2d_pack: kind must be 0 (forward) or 1 (input gradient)");
+  SRGAN_REQUIRE(bytes >= srgan_conv2d_packed_bytes(d, kind, act), "conv2d_pack: destination too small");
+  return kind == 0 ? fwd_pack(d, act, w, (float*)packed, as_stream(stream)) : dgrad_pack(d, w, (float*)packed, as_stream(stream));
+}
+
+extern "C" int srgan_conv2d_fwd_packed(const srgan_conv_desc* d, const float* x, const void* packed, const float* bias,
+                                       float* y, int act, float slope, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(x && packed && y, "conv2d_fwd_packed: null pointer");
+  return fwd_run(d, x, (const float*)packed, bias, y, act, slope, as_stream(stream));
+}
+
+extern "C" int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* dy, const void* packed, float* dx,
+                                         void* ws, size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(dy && packed && dx, "conv2d_dgrad_packed: null pointer");
+  if (d->pad_mode == SRGAN_PAD_REFLECT)
+    SRGAN_REQUIRE(ws && ws_bytes >= srgan_conv2d_workspace(d), "conv2d_dgrad_packed: workspace too small (reflect scratch)");
+  return dgrad_run(d, dy, (const float*)packed, dx, (float*)ws, as_stream(stream));
 }
 
 namespace srgan {

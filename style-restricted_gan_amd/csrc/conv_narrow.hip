@@ -243,15 +243,18 @@ size_t narrow_workspace(const srgan_conv_desc* d) {
   return std::max(pack, slab) + 1024;
 }
 
-int narrow_fwd(const srgan_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws,
-               hipStream_t st) {
+int narrow_pack(const srgan_conv_desc* d, const float* w, float* wp, hipStream_t st) {
+  const int total = d->I * d->kh * d->kw * 4;
+  hipLaunchKernelGGL(narrow_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, d->sO, d->sI, d->sH, d->sW, d->O,
+                     d->I, d->kh, d->kw);
+  return check_launch("narrow_pack_kernel");
+}
+
+int narrow_fwd_packed(const srgan_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, hipStream_t st) {
   NarrowParams p{};
-  p.x = x; p.wp = (const float*)ws; p.bias = bias; p.y = y;
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y;
   p.N = d->N; p.H = d->Hi; p.W = d->Wi; p.Ci = d->I; p.Ho = d->Ho; p.Wo = d->Wo; p.CO = d->O;
   p.kh = d->kh; p.kw = d->kw; p.pad = d->pad;
-  const int total = d->I * d->kh * d->kw * 4;
-  hipLaunchKernelGGL(narrow_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, (float*)ws, d->sO, d->sI, d->sH,
-                     d->sW, d->O, d->I, d->kh, d->kw);
   const size_t shmem = (size_t)(NT_H + d->kh - 1) * (NT_W + d->kw - 1) * NPIX * sizeof(float);
   dim3 grid((unsigned)ceil_div(d->Wo, NT_W), (unsigned)ceil_div(d->Ho, NT_H), (unsigned)d->N);
   switch (d->O) {

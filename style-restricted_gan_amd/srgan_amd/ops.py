@@ -110,16 +110,80 @@ def _conv_ws(desc, device):
     return workspace(device, nbytes), nbytes
 
 
+# ---- packed-weight cache ---------------------------------------------------------------------------
+# The repacked weight operand of a conv depends only on (weight values, geometry, kind).  Inside a trainer step the
+# weights change only at optimiser steps, so the trainer turns the cache on for the duration of ``train()`` and
+# invalidates a network's entries after each of its optimiser steps.  Outside such a scope (plain module calls) every
+# call repacks: there is no way to see a raw-pointer or ``.data`` update of a parameter from here.
+_pack_cache_on = False
+_pack_cache = {}          # (id(weight), kind, act_flag, geometry) -> packed tensor
+
+
+class pack_cache:
+    """Context manager: cache packed conv weights until ``invalidate_packed`` is called for their parameter."""
+
+    def __enter__(self):
+        global _pack_cache_on
+        self._prev = _pack_cache_on
+        _pack_cache_on = True
+        _pack_cache.clear()
+        return self
+
+    def __exit__(self, *exc):
+        global _pack_cache_on
+        _pack_cache_on = self._prev
+        _pack_cache.clear()
+        return False
+
+
+def invalidate_packed(params=None):
+    if params is None:
+        _pack_cache.clear()
+        return
+    ids = {id(p) for p in params}
+    for key in [k for k in _pack_cache if k[0] in ids]:
+        del _pack_cache[key]
+
+
+def _packed(desc, weight, kind, act):
+    key = (id(weight), kind, int(act != ACT_NONE), desc.N, desc.Hi, desc.Wi, desc.I, desc.O, desc.kh, desc.stride,
+           desc.pad, desc.pad_mode)
+    hit = _pack_cache.get(key)
+    if hit is None:
+        lib = _lib.load()
+        nbytes = lib.srgan_conv2d_packed_bytes(ctypes.byref(desc), kind, act)
+        if nbytes == 0:
+            raise _lib.SrganHipError("conv2d pack: " + lib.srgan_last_error().decode())
+        hit = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        _lib.check(lib.srgan_conv2d_pack(ctypes.byref(desc), kind, act, _ptr(weight), _ptr(hit), nbytes, _stream()),
+                   "conv2d_pack")
+        _pack_cache[key] = hit
+    return hit
+
+
 def _run_conv_fwd(desc, x, weight, bias, y, act, slope):
+    lib = _lib.load()
+    if _pack_cache_on:
+        wp = _packed(desc, weight, 0, act)
+        _lib.check(lib.srgan_conv2d_fwd_packed(ctypes.byref(desc), _ptr(x), _ptr(wp), _ptr(bias), _ptr(y), act,
+                                               float(slope), _stream()), "conv2d_fwd_packed")
+        return
     ws, nb = _conv_ws(desc, x.device)
-    _lib.check(_lib.load().srgan_conv2d_fwd(ctypes.byref(desc), _ptr(x), _ptr(weight), _ptr(bias), _ptr(y), act,
-                                            float(slope), _ptr(ws), nb, _stream()), "conv2d_fwd")
+    _lib.check(lib.srgan_conv2d_fwd(ctypes.byref(desc), _ptr(x), _ptr(weight), _ptr(bias), _ptr(y), act,
+                                    float(slope), _ptr(ws), nb, _stream()), "conv2d_fwd")
 
 
 def _run_conv_dgrad(desc, dy, weight, dx):
+    lib = _lib.load()
+    if _pack_cache_on:
+        wp = _packed(desc, weight, 1, ACT_NONE)
+        ws, nb = (_conv_ws(desc, dy.device) if desc.pad_mode == PAD_REFLECT else (None, 0))
+        _lib.check(lib.srgan_conv2d_dgrad_packed(ctypes.byref(desc), _ptr(dy), _ptr(wp), _ptr(dx), _ptr(ws), nb,
+                                                 _stream()), "conv2d_dgrad_packed")
+        return
     ws, nb = _conv_ws(desc, dy.device)
-    _lib.check(_lib.load().srgan_conv2d_dgrad(ctypes.byref(desc), _ptr(dy), _ptr(weight), _ptr(dx), _ptr(ws), nb,
-                                              _stream()), "conv2d_dgrad")
+    _lib.check(lib.srgan_conv2d_dgrad(ctypes.byref(desc), _ptr(dy), _ptr(weight), _ptr(dx), _ptr(ws), nb,
+                                      _stream()), "conv2d_dgrad")
 
 
 def _run_conv_wgrad(desc, x, dy, dw, dbias):

@@ -122,6 +122,11 @@ class SRGAN_training():
     def _opt_params(opt):
         return [p for g in opt.param_groups for p in g["params"]]
 
+    def _step(self, opt):
+        """optimiser step + drop the packed copies of the weights it just changed"""
+        opt.step()
+        ops.invalidate_packed(self._opt_params(opt))
+
     def _reduce_start(self, name, opt):
         if not dp.is_distributed():
             return None
@@ -200,7 +205,7 @@ class SRGAN_training():
         nxt = _next_fake() if _next_fake is not None else None      # overlaps the all-reduce
         if red is not None:
             red.finish()
-        self.optD.step()
+        self._step(self.optD)
         self.loss_terms.update(errD_real=errD_real.detach(), errD_class=errD_class.detach(), errD_fake=errD_fake.detach())
         if _next_fake is not None:
             return errD, nxt
@@ -267,8 +272,8 @@ class SRGAN_training():
         if redG is not None:
             redG.finish()
             redE.finish()
-        self.optG.step()
-        self.optE.step()
+        self._step(self.optG)
+        self._step(self.optE)
 
         # ---------------- phase 2: G only ----------------
         self.G.zero_grad()
@@ -291,7 +296,7 @@ class SRGAN_training():
         redG = self._reduce_start("G", self.optG)
         if redG is not None:
             redG.finish()
-        self.optG.step()
+        self._step(self.optG)
 
         self.recon_image = recon_image.detach()
         self.loss_terms.update({k: v.detach() for k, v in terms.items()})
@@ -326,7 +331,8 @@ class SRGAN_training():
         self.source_image = ops.to_nhwc(source_image)
         self.label = label
         self.loss_terms = {}
-        error = self.UnrolledUpdate()
+        with ops.pack_cache():        # weights only change at self._step() inside this scope
+            error = self.UnrolledUpdate()
         return error
 
 
