@@ -383,6 +383,10 @@ class _EncoderBase(nn.Module):
     def reparametrize(self, mu, logvar):
         return _ReparamFn.apply(mu, logvar, _cpu_normal_like(mu))
 
+    def reparam_with(self, mu, logvar, eps):
+        """reparametrize with caller-supplied N(0, I) noise (already on the device)."""
+        return _ReparamFn.apply(mu, logvar, eps)
+
 
 class Encoder_original(_EncoderBase):
     def __init__(self, nch_in, nch_out, nch=64, num_cls=3, norm_type="instance", num_con=2, device="cpu"):

@@ -90,6 +90,14 @@ def to_nchw(t):
     return out
 
 
+def cat_batch(tensors):
+    """Concatenate NHWC-dense activations along the batch dimension (stays NHWC-dense, differentiable).
+    Every layer of G / D / E is per-sample (instance norm, no batch norm), so running two batches as one is exact
+    and gives the GEMM kernels twice the rows per launch."""
+    tensors = [to_nhwc(t) for t in tensors]
+    return torch.cat([t.permute(0, 2, 3, 1) for t in tensors], 0).permute(0, 3, 1, 2)
+
+
 def _dense2d(t):
     return t if t.is_contiguous() else t.contiguous()
 

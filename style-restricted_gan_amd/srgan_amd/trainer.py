@@ -136,13 +136,22 @@ class SRGAN_training():
         red.start()
         return red
 
-    def _encode(self, image, feat=None):
-        """E(image) -> 5-list; with a precomputed trunk feature only the heads (+ a fresh noise draw) run."""
+    def _encode(self, image, feat=None, noise=None):
+        """E(image) -> 5-list; with a precomputed trunk feature only the heads run.  The reparametrisation noise is
+        drawn here (CPU default generator, as model.py:461) unless the caller pre-drew it to fix the RNG order."""
         E = dp.unwrap(self.E)
+        if feat is None and noise is not None and hasattr(E, "features"):
+            feat = E.features(image)
         if feat is not None and hasattr(E, "features"):
             mu, logvar = E.fcmean(feat), E.fcvar(feat)
-            return [E.reparametrize(mu, logvar), mu, logvar, E.fcclass(feat), None]
+            eps = noise if noise is not None else _cpu_normal_like(mu)
+            return [E.reparam_with(mu, logvar, eps), mu, logvar, E.fcclass(feat), None]
         return list(self.E(image))
+
+    def _fused_paths(self):
+        """The batched / fused execution needs this package's own modules (feature / logit entry points)."""
+        return (hasattr(dp.unwrap(self.D), "forward_logits") and self._ref_is_onehot
+                and hasattr(dp.unwrap(self.E), "features"))
 
     def _d_losses(self, image, gan_target, class_which, want_class):
         """LSGAN (+ class MSE) of D(image) through the fused head/loss kernels."""
@@ -197,8 +206,19 @@ class SRGAN_training():
         else:
             self.target_image, self.c_rand = _fake
 
-        errD_real, errD_class = self._d_losses(self.source_image, 1., "source", True)
-        errD_fake, _ = self._d_losses(self.target_image.detach(), 0., None, False)
+        if self._fused_paths():
+            # real and fake halves through D as ONE batch (per-sample network: exact; 2x the rows per GEMM launch)
+            B = self.source_image.shape[0]
+            outs, logits = dp.unwrap(self.D).forward_logits(ops.cat_batch([self.source_image, self.target_image.detach()]))
+            errD_real = get_loss_D([o[:B] for o in outs], 1., self.criterion, self.device)
+            errD_fake = get_loss_D([o[B:] for o in outs], 0., self.criterion, self.device)
+            lab, w = self._label_dev("source"), 1.0 / len(logits)
+            errD_class = 0.0
+            for z in logits:
+                errD_class = errD_class + ops.softmax_mse(z[:B], lab, w)[0]
+        else:
+            errD_real, errD_class = self._d_losses(self.source_image, 1., "source", True)
+            errD_fake, _ = self._d_losses(self.target_image.detach(), 0., None, False)
         errD = errD_real + errD_class * self.lbd["class"] + errD_fake
         errD.backward()
         red = self._reduce_start("D", self.optD)
@@ -227,7 +247,20 @@ class SRGAN_training():
         with _frozen(e_unused):
             feat = E.features(src) if hasattr(E, "features") else None
             source_enc_info = self._encode(src, feat)
-            recon_image, _ = self.G_transformation("source", self.target_image, True, src, _enc_info=source_enc_info)
+            pair = feat is not None and L["idt"] > 0
+            if pair:
+                # the reference calls E(source) a second time for the identity path: same weights, same input -> same
+                # mu; only the reparametrisation noise is drawn again (keeps the CPU RNG sequence identical).  The
+                # reconstruction G(target_image, c) and the identity G(source, c') then run as ONE batch through G.
+                idt_info = self._encode(src, feat)
+                pick = 0 if self.encoded_feature == "latent" else 1
+                oh = self._onehot("source")
+                c_pair = torch.cat([torch.cat([oh, source_enc_info[pick]], 1), torch.cat([oh, idt_info[pick]], 1)], 0)
+                both = self.G(ops.cat_batch([self.target_image, src]), c_pair)
+                nb = src.shape[0]
+                recon_image, identity_image = both[:nb], both[nb:]
+            else:
+                recon_image, _ = self.G_transformation("source", self.target_image, True, src, _enc_info=source_enc_info)
             with _frozen(list(self.D.parameters())):       # D's weight grads would be discarded
                 errG_dis, errG_class = self._d_losses(self.target_image, 1., "target", True)
             errG_cycle = ops.l1_mean(src, recon_image, 1.0)
@@ -244,10 +277,8 @@ class SRGAN_training():
                 terms["errE_KL"] = errE_KL
 
             if L["idt"] > 0:
-                # the reference calls E(source) a second time: same weights, same input -> same mu; only the
-                # reparametrisation noise is drawn again (keeps the CPU RNG sequence identical)
-                idt_info = self._encode(src, feat) if feat is not None else None
-                identity_image, _ = self.G_transformation("source", src, True, src, _enc_info=idt_info)
+                if not pair:
+                    identity_image, _ = self.G_transformation("source", src, True, src)
                 errG_idt = ops.l1_mean(src, identity_image, 1.0)
                 errG = errG + errG_idt * L["idt"]
                 errE_output = errE_output + errG_idt * L["idt"]
@@ -279,19 +310,35 @@ class SRGAN_training():
         self.G.zero_grad()
         self.E.zero_grad()
         with _frozen(list(self.E.parameters())):           # only optG steps: E's weight grads are discarded
-            _, target_cenc, _, _, _ = self._encode(self.target_image)
-            errG_reg = ops.l1_mean(self.c_rand, target_cenc, 1.0)
-            errG_ex = errG_reg * L["reg"]
-            terms["errG_reg"] = errG_reg
-            if L["idt_reg"] * L["idt"] > 0:
+            do_idt_reg = L["idt_reg"] * L["idt"] > 0
+            if do_idt_reg and self._fused_paths():
+                # reference order of the noise draws: E(target_image), E(source), E(idt_random_image)
+                nb = src.shape[0]
+                n1, n2, n3 = (torch.FloatTensor(nb, self.ndim).normal_().to(self.device) for _ in range(3))
                 with torch.no_grad():                       # its gradient only reaches E's parameters
-                    info = self._encode(src)
+                    info = self._encode(src, noise=n2)
                 idt_random_image, info = self.G_transformation("source", src, True, src, _enc_info=info)
-                source_c_rand = info[1]
-                _, idt_cenc_rand, _, _, _ = self._encode(idt_random_image)
-                errG_idt_reg = ops.l1_mean(source_c_rand, idt_cenc_rand, 1.0)
-                errG_ex = errG_ex + errG_idt_reg * (L["idt_reg"] * (L["idt"] / L["cycle"]))
-                terms["errG_idt_reg"] = errG_idt_reg
+                feats = E.features(ops.cat_batch([self.target_image, idt_random_image]))    # ONE batch through E
+                target_cenc = self._encode(None, feats[:nb], n1)[1]
+                idt_cenc_rand = self._encode(None, feats[nb:], n3)[1]
+                errG_reg = ops.l1_mean(self.c_rand, target_cenc, 1.0)
+                errG_idt_reg = ops.l1_mean(info[1], idt_cenc_rand, 1.0)
+                errG_ex = errG_reg * L["reg"] + errG_idt_reg * (L["idt_reg"] * (L["idt"] / L["cycle"]))
+                terms["errG_reg"], terms["errG_idt_reg"] = errG_reg, errG_idt_reg
+            else:
+                _, target_cenc, _, _, _ = self._encode(self.target_image)
+                errG_reg = ops.l1_mean(self.c_rand, target_cenc, 1.0)
+                errG_ex = errG_reg * L["reg"]
+                terms["errG_reg"] = errG_reg
+                if do_idt_reg:
+                    with torch.no_grad():                   # its gradient only reaches E's parameters
+                        info = self._encode(src)
+                    idt_random_image, info = self.G_transformation("source", src, True, src, _enc_info=info)
+                    source_c_rand = info[1]
+                    _, idt_cenc_rand, _, _, _ = self._encode(idt_random_image)
+                    errG_idt_reg = ops.l1_mean(source_c_rand, idt_cenc_rand, 1.0)
+                    errG_ex = errG_ex + errG_idt_reg * (L["idt_reg"] * (L["idt"] / L["cycle"]))
+                    terms["errG_idt_reg"] = errG_idt_reg
             errG_ex.backward()
         redG = self._reduce_start("G", self.optG)
         if redG is not None:
