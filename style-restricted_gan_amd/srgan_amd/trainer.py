@@ -26,7 +26,7 @@ import torch.optim as optim
 
 from . import dp, ops
 from .losses import class_encode, get_domainloss_D, get_loss_D, histogram_imitation
-from .model import _cpu_normal_like
+from .model import SingleGenerator, _cpu_normal_like
 from .optim import Adam
 
 __all__ = ["SRGAN_training", "SingleGAN_training"]
@@ -222,7 +222,7 @@ class SRGAN_training():
         errD = errD_real + errD_class * self.lbd["class"] + errD_fake
         errD.backward()
         red = self._reduce_start("D", self.optD)
-        nxt = _next_fake() if _next_fake is not None else None      # overlaps the all-reduce
+        nxt = _next_fake() if _next_fake is not None else None      # optional work to overlap with the all-reduce
         if red is not None:
             red.finish()
         self._step(self.optD)
@@ -356,19 +356,26 @@ class SRGAN_training():
         "restores" D from ``paramD = self.D.state_dict()``, which aliases the live tensors -- a no-op that
         is not replayed here.  Returns [errorG, errorD(first iteration), errorE]."""
         errorD = None
-
-        def make_fake(keep_graph):
-            if keep_graph:
-                return self.G_transformation("target", self.source_image, False)
-            with torch.no_grad():               # only the last translation's graph is ever back-propagated
-                return self.G_transformation("target", self.source_image, False)
-
-        fake = make_fake(self.k == 1)
-        for i in range(self.k):
-            if i + 1 < self.k:
-                errD, fake = self.update_D(_fake=fake, _next_fake=lambda i=i: make_fake(i + 2 == self.k))
-            else:
-                errD = self.update_D(_fake=fake)
+        src, k = self.source_image, self.k
+        nb = src.shape[0]
+        # G does not change during the k discriminator updates, so all k translations are computed up front, with the
+        # noise drawn in the reference's order (k x randn(B, ndim) on the CPU generator).  Only the LAST translation's
+        # graph is ever back-propagated (phases 1 and 2); the first k-1 run as ONE no-grad batch of (k-1)*B images.
+        noises = [self.noise_fn(nb, self.ndim).to(self.device) for _ in range(k)]
+        oh = self._onehot("target")
+        fakes = []
+        if k > 1 and isinstance(dp.unwrap(self.G), SingleGenerator):     # per-sample network: batching is exact
+            with torch.no_grad():
+                c_all = torch.cat([torch.cat([oh, z], 1) for z in noises[:-1]], 0)
+                imgs = self.G(ops.cat_batch([src] * (k - 1)), c_all)
+            fakes = [(imgs[i * nb:(i + 1) * nb], noises[i]) for i in range(k - 1)]
+        elif k > 1:
+            with torch.no_grad():
+                fakes = [(self.G(src, torch.cat([oh, z], 1)), z) for z in noises[:-1]]
+        fakes.append((self.G(src, torch.cat([oh, noises[-1]], 1)), noises[-1]))
+        for i in range(k):
+            errD = self.update_D(_fake=fakes[i])
+            fakes[i] = None
             if i == 0:
                 errorD = errD.detach()
         errorG, errorE = self.update_GandE()
