@@ -434,9 +434,10 @@ struct WgradParams {
 // ROWS: every 32-pixel K tile lies inside one image row (Wg % 32 == 0, VEC only): the tile's (n, y) and the source row
 // base are wave-uniform scalars advanced with counters; a thread only adds its constant column offset.
 template <int BMc, int BNn, int WM, int WN, bool VEC, bool ROWS = false>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel(WgradParams p) {
   constexpr int TM = BMc / (WM * 32), TN = BNn / (WN * 32);
-  constexpr int A_IT = BMc / 32, B_IT = BNn / 32;     // float4 per thread per 32-row tile
+  constexpr int NT = (WM * WN > 4 ? WM * WN : 4) * 64;   // threads: 4 waves (some idle for small tiles) or 8 waves
+  constexpr int A_IT = 8 * BMc / NT, B_IT = 8 * BNn / NT;     // float4 per thread per 32-row tile
   constexpr int A_PR = BMc / 4, B_PR = BNn / 4;       // float4 per tile row
   // double-buffered tiles: tile t+1 is written to LDS in the middle of tile t's MFMAs (one barrier per tile)
   __shared__ __attribute__((aligned(16))) float As2[2][32 * BMc];
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     const float* abase = p.dy + (size_t)mb * p.Cd + co0;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int idx = tid + 256 * i;
+      const int idx = tid + NT * i;
       const int r = idx / A_PR, c4 = idx - r * A_PR;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (co0 + c4 * 4 < p.Cd) v = *reinterpret_cast<const f32x4*>(abase + (size_t)r * p.Cd + c4 * 4);
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     const int x0 = rw_b * p.stride - p.pad + tap_tx;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      const int idx = tid + 256 * i;
+      const int idx = tid + NT * i;
       const int r = idx / B_PR, c4 = idx - r * B_PR;
       int x = x0 + r * p.stride;
       if (p.reflect) {
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     const int mb = m_begin + t * 32, buf = t & 1;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int idx = tid + 256 * i;
+      const int idx = tid + NT * i;
       const int r = idx / A_PR, c4 = idx - r * A_PR;
       const int m = mb + r, co = co0 + c4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       const int ty = tp / p.kw, tx = tp - ty * p.kw;
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NT * i;
         const int r = idx / B_PR, c4 = idx - r * B_PR;
         bool ok;
         const size_t off = gather(buf, r, ty, tx, ok);
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     } else {
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NT * i;
         const int r = idx / B_PR, c4 = idx - r * B_PR;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -612,9 +613,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     float* As = As2[buf];
     float* Bs = Bs2[buf];
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(&As[(tid + 256 * i) * 4]) = a_reg[i];
+    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(&As[(tid + NT * i) * 4]) = a_reg[i];
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(&Bs[(tid + 256 * i) * 4]) = b_reg[i];
+    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(&Bs[(tid + NT * i) * 4]) = b_reg[i];
   };
   auto mfma_range = [&](int buf, int kp0, int kp1) {
     const float* As = As2[buf];
@@ -723,7 +724,7 @@ TileChoice choose_tile(long long M, int N) {
   // rounds: avoids the tail in which one of two independent co-resident workgroups runs alone on its SIMDs
   static const bool big = std::getenv("SRGAN_NO_BIG_TILE") == nullptr;
   long long big_tiles = ceil_div(M, 256) * ceil_div(N, 128);
-  if (big && M % 256 == 0 && big_tiles >= 256) return {256, 128};
+  if (big && big_tiles >= 256) return {256, 128};
   return {128, 128};
 }
 
@@ -786,7 +787,10 @@ WgradPlan plan_wgrad(const srgan_conv_desc* d) {
   WgradPlan w;
   const long long M = (long long)d->N * d->Ho * d->Wo;
   const int NN = d->kh * d->kw * d->I;
-  w.BMc = d->O <= 32 ? 32 : (d->O <= 64 ? 64 : 128);
+  // 8-wave 256x128 weight-gradient tiles: measured SLOWER in the train step (88 vs 98 TFLOP/s, A/B on one device),
+  // kept behind a switch for experiments
+  static const bool big = std::getenv("SRGAN_BIG_WGRAD") != nullptr;
+  w.BMc = d->O <= 32 ? 32 : (d->O <= 64 ? 64 : ((big && d->O % 256 == 0 && d->I % 128 == 0 && M >= 16384) ? 256 : 128));   // 8-wave tiles need long pixel ranges
   w.vec = (d->I % 32) == 0;
   if (w.vec) w.BNn = (d->I % 128 == 0) ? 128 : ((d->I % 64 == 0) ? 64 : 32);
   else w.BNn = 64;
@@ -797,7 +801,7 @@ WgradPlan plan_wgrad(const srgan_conv_desc* d) {
   w.NNpad = w.nn_tiles * w.BNn;
   long long tiles = (long long)w.co_tiles * w.nn_tiles;
   static const long long wg_target = std::getenv("SRGAN_WGRAD_BLOCKS") ? std::atoll(std::getenv("SRGAN_WGRAD_BLOCKS")) : 1024;
-  long long want = ceil_div(wg_target, tiles);            // ~4 blocks per CU (768 measured slower: 82 vs 89 TFLOP/s)
+  long long want = ceil_div(w.BMc == 256 ? wg_target / 2 : wg_target, tiles);   // ~4 four-wave (2 eight-wave) blocks per CU
   long long max_splits = ceil_div(M, 256);                // at least 8 K-tiles per split
   long long splits = want < 1 ? 1 : want;
   if (splits > max_splits) splits = max_splits;
@@ -1007,12 +1011,13 @@ static int launch_wgrad(const WgradParams& p, const WgradPlan& w, hipStream_t st
   dim3 grid((unsigned)(w.co_tiles * w.nn_tiles * w.splits), 1, 1);
   // row-aligned fast path: every 32-pixel tile inside one image row, every split a whole number of tiles
   const bool rows = w.vec && (p.Wg % 32) == 0 && (p.rows_per_split % 32) == 0 && (p.M % 32) == 0 && (p.Cd % 4) == 0;
+  constexpr int NT = (WM * WN > 4 ? WM * WN : 4) * 64;
   if (rows && BMc >= 64 && BNn >= 64)
-    hipLaunchKernelGGL((wgrad_kernel<(BMc >= 64 ? BMc : 64), (BNn >= 64 ? BNn : 64), (BMc >= 64 && BNn >= 64 ? WM : 2), (BMc >= 64 && BNn >= 64 ? WN : 2), true, true>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((wgrad_kernel<(BMc >= 64 ? BMc : 64), (BNn >= 64 ? BNn : 64), (BMc >= 64 && BNn >= 64 ? WM : 2), (BMc >= 64 && BNn >= 64 ? WN : 2), true, true>), grid, dim3(BMc >= 64 && BNn >= 64 ? NT : 256), 0, st, p);
   else if (w.vec)
-    hipLaunchKernelGGL((wgrad_kernel<BMc, BNn, WM, WN, true>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((wgrad_kernel<BMc, BNn, WM, WN, true>), grid, dim3(NT), 0, st, p);
   else
-    hipLaunchKernelGGL((wgrad_kernel<BMc, BNn, WM, WN, false>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((wgrad_kernel<BMc, BNn, WM, WN, false>), grid, dim3(NT), 0, st, p);
   return check_launch("wgrad_kernel");
 }
 }  // namespace srgan
@@ -1064,7 +1069,8 @@ extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, cons
   p.M = d->N * d->Ho * d->Wo; p.rows_per_split = w.rows_per_split;
   p.co_tiles = w.co_tiles; p.nn_tiles = w.nn_tiles;
   int e = -1;
-  if (w.BMc == 128 && w.BNn == 128) e = launch_wgrad<128, 128, 2, 2>(p, w, st);
+  if (w.BMc == 256 && w.BNn == 128) e = launch_wgrad<256, 128, 4, 2>(p, w, st);
+  else if (w.BMc == 128 && w.BNn == 128) e = launch_wgrad<128, 128, 2, 2>(p, w, st);
   else if (w.BMc == 128 && w.BNn == 64) e = launch_wgrad<128, 64, 2, 2>(p, w, st);
   else if (w.BMc == 64 && w.BNn == 128) e = launch_wgrad<64, 128, 2, 2>(p, w, st);
   else if (w.BMc == 64 && w.BNn == 64) e = launch_wgrad<64, 64, 2, 2>(p, w, st);
