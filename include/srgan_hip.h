@@ -136,6 +136,10 @@ int srgan_mse_const(const float* o, long long n, float target, float weight, flo
  * label:[B] int64; q=softmax(z) is written to `q`; loss = mean((q-onehot)^2)*weight; dz via softmax Jacobian. */
 int srgan_softmax_mse(const float* z, const long long* label, int B, int n_class, float weight,
                       float* q, float* loss, float* dz, void* stream);
+/* nn.CrossEntropyLoss() (mean reduction) of the encoder pre-training job, 04_Facial_Recognition-Encoder.ipynb cell 18/22:
+ * loss = weight * mean_b(logsumexp(z_b) - z_b[label_b]); dz = weight * (softmax(z) - onehot) / B. */
+int srgan_softmax_xent(const float* z, const long long* label, int B, int n_class, float weight, float* loss,
+                       float* dz, void* stream);
 /* torch.mean(torch.abs(a-b)) util_notebook.py:625,639,676,686 ; da = weight*sign(a-b)/n, db = -da */
 size_t srgan_l1_workspace(long long n);
 int srgan_l1_mean(const float* a, const float* b, long long n, float weight, float* loss,

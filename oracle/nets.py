@@ -159,3 +159,12 @@ def encoder_original(P, x, c, noise=None):
     mu = F.linear(feat, P["fcmean.weight"], P["fcmean.bias"])
     logvar = F.linear(feat, P["fcvar.weight"], P["fcvar.bias"])
     return _reparam(mu, logvar, noise), mu, logvar
+
+
+def encoder_classifier(P, x):
+    """Encoder_classifier.forward (pyfiles/model.py:503-507): trunk -> LeakyReLU -> global pool -> fcclass -> softmax."""
+    h = F.conv2d(x, P["first_layer.weight"], P["first_layer.bias"], 2, 1)
+    for b in range(_count(P, "layers.{}.conv1.weight")):
+        h = _enc_block(P, b, h, inorm, inorm)
+    feat = F.leaky_relu(h, E_SLOPE).mean(dim=(2, 3))
+    return torch.softmax(F.linear(feat, P["fcclass.weight"], P["fcclass.bias"]), dim=1)

@@ -56,6 +56,26 @@ __global__ __launch_bounds__(256) void softmax_mse_kernel(const float* z, const 
   if (threadIdx.x == 0) loss[0] = weight * s / (float)(B * nc);
 }
 
+// nn.CrossEntropyLoss (mean): loss = mean_b( logsumexp(z_b) - z_b[label_b] ), dz = (softmax(z) - onehot) * weight / B
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* z, const long long* label, int B, int nc,
+                                                           float weight, float* loss, float* dz) {
+  __shared__ float red[16];
+  float s = 0.f;
+  const float gscale = weight / (float)B;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float mx = -INFINITY;
+    for (int j = 0; j < nc; ++j) mx = fmaxf(mx, z[b * nc + j]);
+    float den = 0.f;
+    for (int j = 0; j < nc; ++j) den += expf(z[b * nc + j] - mx);
+    const int lab = (int)label[b];
+    s += logf(den) + mx - z[b * nc + lab];
+    if (dz)
+      for (int j = 0; j < nc; ++j) dz[b * nc + j] = gscale * (expf(z[b * nc + j] - mx) / den - (j == lab ? 1.f : 0.f));
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) loss[0] = weight * s / (float)B;
+}
+
 __global__ __launch_bounds__(256) void l1_partial_kernel(const float* a, const float* b, long long n, float gscale,
                                                          float* part, float* da, float* db) {
   __shared__ float red[16];
@@ -352,4 +372,11 @@ extern "C" int srgan_soft_histogram_bwd(const float* x, const float* g, long lon
   const int blocks = (int)std::max<long long>(1, std::min<long long>(1024, ceil_div(n, 256)));
   hipLaunchKernelGGL(soft_hist_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, g, n, bins, lo, delta, sigma, dx);
   return check_launch("soft_histogram_bwd");
+}
+
+extern "C" int srgan_softmax_xent(const float* z, const long long* label, int B, int n_class, float weight, float* loss,
+                                  float* dz, void* stream) {
+  SRGAN_REQUIRE(z && label && loss && B > 0 && n_class > 0 && n_class <= 1024, "softmax_xent: bad argument");
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, as_stream(stream), z, label, B, n_class, weight, loss, dz);
+  return check_launch("softmax_xent_kernel");
 }

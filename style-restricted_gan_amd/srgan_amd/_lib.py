@@ -56,6 +56,7 @@ SIGNATURES = {
     "srgan_nhwc_to_nchw": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "srgan_mse_const": (c_int, [P, c_longlong, c_float, c_float, P, P, P]),
     "srgan_softmax_mse": (c_int, [P, P, c_int, c_int, c_float, P, P, P, P]),
+    "srgan_softmax_xent": (c_int, [P, P, c_int, c_int, c_float, P, P, P]),
     "srgan_l1_workspace": (c_size_t, [c_longlong]),
     "srgan_l1_mean": (c_int, [P, P, c_longlong, c_float, P, P, P, P, c_size_t, P]),
     "srgan_latent_losses": (c_int, [P, c_int, c_int, c_float, P, c_int, c_float, c_float, c_float, c_float, c_float, P, P, P, P]),

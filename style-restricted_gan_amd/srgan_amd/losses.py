@@ -10,8 +10,17 @@ import torch.nn as nn
 
 from . import ops
 
-__all__ = ["get_loss_D", "get_domainloss_D", "corrcoef", "corrcoef_loss", "GaussianHistogram",
+__all__ = ["CrossEntropyLoss", "get_loss_D", "get_domainloss_D", "corrcoef", "corrcoef_loss", "GaussianHistogram",
            "histogram_imitation", "class_encode", "get_target", "weights_init", "load_classifier"]
+
+
+class CrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss() (mean reduction) on the HIP path: the criterion of the encoder pre-training job
+    (04_Facial_Recognition-Encoder.ipynb cell 18; note the notebook applies it to the SOFTMAX output of
+    Encoder_classifier, i.e. a second softmax is taken inside the loss -- reproduced as is)."""
+
+    def forward(self, input, target):
+        return ops.softmax_xent(input, target, 1.0)
 
 
 def _require_mse(criterion, who):

@@ -603,6 +603,31 @@ def softmax_mse(z, label, weight=1.0):
     return _SoftmaxMseFn.apply(z, label, weight)
 
 
+class _SoftmaxXentFn(Function):
+    @staticmethod
+    def forward(ctx, z, label, weight):
+        _require_gpu(z, "softmax_xent")
+        z = _dense2d(z)
+        b, nc = z.shape
+        label = label.to(device=z.device, dtype=torch.int64).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        _lib.check(_lib.load().srgan_softmax_xent(_ptr(z), _ptr(label), b, nc, float(weight), _ptr(loss), _ptr(dz),
+                                                  _stream()), "softmax_xent")
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None, None
+
+
+def softmax_xent(z, label, weight=1.0):
+    """weight * mean cross-entropy of row-softmax(z) against integer labels (nn.CrossEntropyLoss semantics)."""
+    return _SoftmaxXentFn.apply(z, label, weight)
+
+
 class _L1MeanFn(Function):
     @staticmethod
     def forward(ctx, a, b, weight):

@@ -269,6 +269,30 @@ def golden_singlegan():
     np.savez_compressed(os.path.join(HERE, "singlegan_T_b8_k2_idtreg.npz"), **run_singlegan(2, 2, 0, ext))
 
 
+def golden_pretrain():
+    """Encoder pre-training job (notebook 04 cells 18/22): Encoder_classifier + CrossEntropyLoss on its softmax output,
+    Adam(lr=1e-4, default betas).  Tier-T widths, 3 steps, batch 8."""
+    net = ref_model.Encoder_classifier(3, 8, 4, 4, "instance", 4)
+    sd = net.state_dict()
+    net.load_state_dict({k: torch.from_numpy(oparams.fill_array(k, tuple(v.shape), 2)) for k, v in sd.items()})
+    opt = LegacyAdam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    crit = nn.CrossEntropyLoss()
+    losses, outs = [], None
+    for s in range(3):
+        x, label = synthetic_batch(8, 128, 4, seed=400 + s)
+        opt.zero_grad()
+        y = net(x)
+        loss = crit(y, label["source"])
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        outs = y.detach().numpy()
+    out = {"losses": np.array(losses), "last_probs": outs}
+    for k_, v in net.state_dict().items():
+        out["P." + k_] = v.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "pretrain_T_b8.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_shapes()
@@ -276,4 +300,5 @@ if __name__ == "__main__":
     golden_losses()
     golden_train()
     golden_singlegan()
+    golden_pretrain()
     print("golden fixtures written to", HERE)

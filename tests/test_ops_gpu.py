@@ -314,6 +314,18 @@ def test_losses(ops, golden_dir):
     close(xd.grad, xr.grad, 1e-4)
 
 
+def test_cross_entropy(ops):
+    z = rnd(9, 4, seed=1).requires_grad_(True)
+    lab = torch.tensor([0, 3, 1, 2, 2, 0, 1, 3, 3])
+    lr = F.cross_entropy(z, lab)
+    lr.backward()
+    zd = z.detach().cuda().requires_grad_(True)
+    l = ops.softmax_xent(zd, lab.cuda())
+    l.backward()
+    close(l, lr, 1e-6)
+    close(zd.grad, z.grad, 1e-5)
+
+
 def test_adam_matches_torch14_math(ops):
     from oracle.trainer import Adam14
     p = rnd(1000, seed=1)

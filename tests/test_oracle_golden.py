@@ -206,3 +206,24 @@ def test_singlegan_trajectory_vs_reference(golden_dir, name, k, steps, lbd):
     for name_, P in (("G", orc.G), ("D0", orc.D[0]), ("D1", orc.D[1]), ("E", orc.E)):
         for key, p in P.items():
             close(p.detach(), gold[f"{name_}.{key}"], 3e-4, 3e-6)
+
+
+def test_encoder_pretraining_steps_vs_reference(golden_dir):
+    """Notebook 04's job: Encoder_classifier + CrossEntropyLoss on its softmax output, Adam(1e-4, betas 0.9/0.999)."""
+    gold = np.load(os.path.join(golden_dir, "pretrain_T_b8.npz"))
+    spec = params.encoder_spec(3, 8, 4, 4, 4)
+    spec = {k: v for k, v in spec.items() if not k.startswith(("fcmean", "fcvar"))}
+    P = {k: v.requires_grad_(True) for k, v in params.fill(spec, 2).items()}
+    opt = trainer.Adam14(P.values(), lr=1e-4, betas=(0.9, 0.999))
+    out = []
+    for s in range(3):
+        x, label = trainer.synthetic_batch(8, 128, 4, seed=400 + s)
+        for p in P.values():
+            p.grad = None
+        y = nets.encoder_classifier(P, x)
+        loss = torch.nn.functional.cross_entropy(y, label["source"])
+        loss.backward()
+        opt.step()
+        out.append(float(loss))
+    np.testing.assert_allclose(out, gold["losses"], rtol=1e-5)
+    close(y.detach(), gold["last_probs"], 1e-5)

@@ -144,3 +144,30 @@ def test_singlegan_trajectory_vs_reference(golden_dir, name, k, steps, lbd):
     for name_, net, n_opt in (("G", sg.G, 2 * steps), ("D0", sg.D[0], k * steps), ("D1", sg.D[1], k * steps), ("E", sg.E, steps)):
         for key, v in net.state_dict().items():
             close_params(v, gold[f"{name_}.{key}"], 1e-4, n_opt, what=f"{name_}.{key}")
+
+
+def test_encoder_pretraining_steps_vs_reference(golden_dir):
+    """the encoder pre-training job of notebook 04 on the HIP path (Encoder_classifier, cross-entropy on its
+    softmax output, Adam(1e-4) with default betas), against the reference's own 3-step trajectory."""
+    from oracle import params
+    from srgan_amd import losses as hl, model, optim as hoptim
+    gold = np.load(os.path.join(golden_dir, "pretrain_T_b8.npz"))
+    net = model.Encoder_classifier(3, 8, 4, 4, "instance", 4)
+    spec = {k: v for k, v in params.encoder_spec(3, 8, 4, 4, 4).items() if not k.startswith(("fcmean", "fcvar"))}
+    net.load_state_dict(params.fill(spec, 2))
+    net.cuda()
+    opt = hoptim.Adam(net.parameters(), lr=1e-4)
+    crit = hl.CrossEntropyLoss()
+    out = []
+    for s in range(3):
+        x, label = otrainer.synthetic_batch(8, 128, 4, seed=400 + s)
+        opt.zero_grad()
+        y = net(x.cuda())
+        loss = crit(y, label["source"].cuda())
+        loss.backward()
+        opt.step()
+        out.append(float(loss))
+    np.testing.assert_allclose(out, gold["losses"], rtol=1e-4)
+    close(y, gold["last_probs"], 2e-4, what="class probabilities")
+    for key, v in net.state_dict().items():
+        close_params(v, gold["P." + key], 1e-4, 3, what=key)
