@@ -196,6 +196,18 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     }
   }
   int tap_y = 0, tap_x = 0, tap_c = 0;       // position of the NEXT tile to load (VEC path)
+  // generic path: per-row window origin and linear element offset of the thread's BM/RG rows
+  int g_y[VEC ? 1 : A_SC_IT], g_x[VEC ? 1 : A_SC_IT], g_lin[VEC ? 1 : A_SC_IT];
+  if constexpr (!VEC) {
+#pragma unroll
+    for (int i = 0; i < A_SC_IT; ++i) {
+      const int r = (tid >> 5) + RG * i;
+      g_y[i] = row_y[r];
+      g_x[i] = row_x[r];
+      const bool rowok = row_y[r] > -(1 << 27);
+      g_lin[i] = rowok ? ((row_n[r] * p.Hs + row_y[r]) * p.Ws + row_x[r]) * p.Cs : 0;
+    }
+  }
 
   auto load_tiles = [&](int kt) {
     const int k0 = kt * BK;
@@ -230,12 +242,26 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
       const int t = kok ? k / p.Cs : 0;
       const int c = k - t * p.Cs;
       const int ty = t / p.Tx, tx = t - ty * p.Tx;
+      if (p.reflect) {
 #pragma unroll
-      for (int i = 0; i < A_SC_IT; ++i) {
-        const int r = (tid >> 5) + RG * i;
-        bool ok;
-        size_t off = src_index(r, ty, tx, ok);
-        a_sc[i] = (ok && kok) ? p.src[off + c] : 0.f;
+        for (int i = 0; i < A_SC_IT; ++i) {
+          const int r = (tid >> 5) + RG * i;
+          bool ok;
+          size_t off = src_index(r, ty, tx, ok);
+          a_sc[i] = (ok && kok) ? p.src[off + c] : 0.f;
+        }
+      } else {
+        // zero padding: the thread's rows are fixed -> row origin and linear offset live in registers; one tap /
+        // channel offset per tile per thread, ~7 VALU ops per gathered element
+        const int dy = sgn * ty, dx = sgn * tx;
+        const int tapoff = (dy * p.Ws + dx) * p.Cs + c;
+#pragma unroll
+        for (int i = 0; i < A_SC_IT; ++i) {
+          const bool ok = kok && (unsigned)(g_y[i] + dy) < (unsigned)p.Hs && (unsigned)(g_x[i] + dx) < (unsigned)p.Ws;
+          const int off = ok ? g_lin[i] + tapoff : 0;
+          const float v = p.src[off];
+          a_sc[i] = ok ? v : 0.f;
+        }
       }
     }
     const int seg = tid & 7;
@@ -509,6 +535,21 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
     tap_tx = tp - tap_ty * p.kw;
   }
 
+  // generic-path column decode (K-invariant): columns nn0 + (tid % B_PR)*4 + e
+  int gq_ty[4] = {0, 0, 0, 0}, gq_tx[4] = {0, 0, 0, 0}, gq_off[4] = {0, 0, 0, 0};
+  bool gq_ok[4] = {false, false, false, false};
+  if constexpr (!VEC) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int nn = nn0 + (tid % B_PR) * 4 + e;
+      gq_ok[e] = nn < p.NN;
+      const int tp = gq_ok[e] ? nn / p.Cs : 0, c = gq_ok[e] ? nn - tp * p.Cs : 0;
+      gq_ty[e] = tp / p.kw;
+      gq_tx[e] = tp - gq_ty[e] * p.kw;
+      gq_off[e] = (gq_ty[e] * p.Wi + gq_tx[e]) * p.Cs + c;
+    }
+  }
+
   auto load_tile_rows = [&](int t) {
     const int mb = m_begin + t * 32;
     // A': 32 dense rows of dy starting at row mb (all valid: m_end - m_begin is a multiple of 32 on this path)
@@ -588,21 +629,28 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
         b_reg[i] = v;
       }
     } else {
+      // generic channel counts: the thread's 4 columns nn = (tap, channel) are the same for every tile -> their
+      // tap displacement / element offset were decoded once (gq_*); per tile only the row origin changes
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int idx = tid + NT * i;
-        const int r = idx / B_PR, c4 = idx - r * B_PR;
+        const int r = idx / B_PR;
+        const int y0 = rowtab[buf][1][r], x0 = rowtab[buf][2][r];
+        const int lin = ((rowtab[buf][0][r] * p.Hi + y0) * p.Wi + x0) * p.Cs;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int nn = nn0 + c4 * 4 + e;
-          if (nn < p.NN) {
-            const int tp = nn / p.Cs, c = nn - tp * p.Cs;
-            const int ty = tp / p.kw, tx = tp - ty * p.kw;
-            bool ok;
-            const size_t off = gather(buf, r, ty, tx, ok);
-            if (ok) v[e] = p.x[off + c];
+          int y = y0 + gq_ty[e], x = x0 + gq_tx[e];
+          int off = lin + gq_off[e];
+          if (p.reflect) {
+            const int yr = y < 0 ? -y : (y >= p.Hi ? 2 * p.Hi - 2 - y : y);
+            const int xr = x < 0 ? -x : (x >= p.Wi ? 2 * p.Wi - 2 - x : x);
+            off += ((yr - y) * p.Wi + (xr - x)) * p.Cs;
+            y = yr; x = xr;
           }
+          const bool ok = gq_ok[e] && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+          const float t = p.x[ok ? off : 0];
+          v[e] = ok ? t : 0.f;
         }
         b_reg[i] = v;
       }
@@ -690,6 +738,27 @@ __global__ void wgrad_reduce_kernel(WgradReduceParams p) {
     float v = 0.f;
     for (int s = 0; s < p.splits; ++s) v += p.slab[s * slab_stride + off];
     p.dw[o * p.sO + i * p.sI + ky * p.sH + kx * p.sW] = v;
+  }
+}
+
+// many slabs, few outputs (first-layer weights: 64x3x4x4 summed over 512 pixel ranges): one WAVE per output element,
+// lanes stride over the slabs, 64-lane shuffle sum -- the thread-per-output loop above would chain 512 dependent loads
+__global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(WgradReduceParams p) {
+  const long long total = (long long)p.O * p.kh * p.kw * p.I;
+  const size_t slab_stride = (size_t)p.Cdpad * p.NNpad;
+  const int lane = threadIdx.x & 63;
+  for (long long idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; idx < total;
+       idx += ((long long)gridDim.x * blockDim.x) >> 6) {
+    const int i = (int)(idx % p.I);
+    long long r = idx / p.I;
+    const int kx = (int)(r % p.kw); r /= p.kw;
+    const int ky = (int)(r % p.kh);
+    const int o = (int)(r / p.kh);
+    const size_t off = (size_t)o * p.NNpad + (size_t)(ky * p.kw + kx) * p.I + i;
+    float v = 0.f;
+    for (int s = lane; s < p.splits; s += 64) v += p.slab[s * slab_stride + off];
+    v = wave_sum(v);
+    if (lane == 0) p.dw[o * p.sO + i * p.sI + ky * p.sH + kx * p.sW] = v;
   }
 }
 
@@ -1030,7 +1099,10 @@ static int finish_wgrad(const srgan_conv_desc* d, const WgradPlan& w, const floa
   r.slab = (const float*)ws; r.dw = dw; r.sO = d->sO; r.sI = d->sI; r.sH = d->sH; r.sW = d->sW;
   r.O = d->O; r.I = d->I; r.kh = d->kh; r.kw = d->kw; r.splits = w.splits; r.Cdpad = w.Cdpad; r.NNpad = w.NNpad;
   long long total = (long long)d->O * d->kh * d->kw * d->I;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, r);
+  if (w.splits >= 64 && total <= 131072)
+    hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 4), 8192)), dim3(256), 0, st, r);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, r);
   if (int e2 = check_launch("wgrad_reduce_kernel")) return e2;
   if (dbias) {
     const int M = d->N * d->Ho * d->Wo;

@@ -82,6 +82,94 @@ __global__ __launch_bounds__(256) void narrow_conv_fwd_kernel(NarrowParams p) {
   }
 }
 
+// ---- register-blocked forward (v2) for K x K kernels, K = KW (7 for the RGB head) ---------------------------------
+// Each thread produces 4 horizontally adjacent output pixels x CO channels.  The halo tile is staged CHANNEL-PLANAR in
+// LDS ([c][y][x], x contiguous): for one (channel, ky) a thread reads 12 consecutive floats (3 conflict-free
+// ds_read_b128) and uses them for 4 pixels x KW taps x CO outputs = 84 FMAs (CO=3), with the KW*CO weights of that
+// (channel, ky) coming from one scalar (wave-uniform) load burst -- 28 FMAs per LDS read instead of 12.
+constexpr int N2_ROWS = 8, N2_COLS = 128, N2_CH = 8;        // output tile 8 x 128 pixels, 8 channels per pass (4 measured slower)
+
+template <int CO, int KW>
+__global__ __launch_bounds__(256) void narrow_conv_fwd4_kernel(NarrowParams p) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  constexpr int TH = N2_ROWS + KW - 1;
+  constexpr int TWP = N2_COLS + 8;                 // staged row: 128 + 6 halo, padded to a multiple of 4
+  constexpr int WROW = ((KW * CO + 3) / 4) * 4;    // weights per (channel, ky), padded for aligned scalar loads
+  const int n = blockIdx.z;
+  const int oy0 = blockIdx.y * N2_ROWS, ox0 = blockIdx.x * N2_COLS;
+  const int py = threadIdx.x >> 5, pg = threadIdx.x & 31;     // row in tile, 4-pixel group
+  float acc[4][CO];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[q][o] = p.bias ? p.bias[o] : 0.f;
+
+  for (int c0 = 0; c0 < p.Ci; c0 += N2_CH) {
+    __syncthreads();
+    // stage: NHWC global (float4 = 4 channels of a pixel) -> planar LDS
+    for (int idx = threadIdx.x; idx < TH * (N2_COLS + KW - 1) * (N2_CH / 4); idx += 256) {
+      const int half = idx % (N2_CH / 4);
+      const int pix = idx / (N2_CH / 4);
+      const int ty = pix / (N2_COLS + KW - 1), tx = pix - ty * (N2_COLS + KW - 1);
+      const int y = oy0 + ty - p.pad, x = ox0 + tx - p.pad;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+        v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(n * p.H + y) * p.W + x) * p.Ci + c0 + half * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[((half * 4 + e) * TH + ty) * TWP + tx] = v[e];
+    }
+    __syncthreads();
+    const float* wq = p.wp + (size_t)c0 * KW * WROW;          // [channel][ky][WROW]
+#pragma unroll 1
+    for (int c = 0; c < N2_CH; ++c) {
+#pragma unroll
+      for (int ky = 0; ky < KW; ++ky) {
+        const float* row = &tile[(c * TH + py + ky) * TWP + pg * 4];
+        float xs[12];
+        *reinterpret_cast<f32x4*>(xs) = *reinterpret_cast<const f32x4*>(row);
+        *reinterpret_cast<f32x4*>(xs + 4) = *reinterpret_cast<const f32x4*>(row + 4);
+        *reinterpret_cast<f32x4*>(xs + 8) = *reinterpret_cast<const f32x4*>(row + 8);
+        const float* wt = wq + (c * KW + ky) * WROW;            // wave-uniform -> scalar loads
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+          for (int o = 0; o < CO; ++o) {
+            const float w = wt[kx * CO + o];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q][o] = fmaf(xs[q + kx], w, acc[q][o]);
+          }
+      }
+    }
+  }
+  const int oy = oy0 + py, ox = ox0 + pg * 4;
+  if (oy < p.Ho) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ox + q < p.Wo) {
+        float* dst = p.y + ((size_t)(n * p.Ho + oy) * p.Wo + ox + q) * CO;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) dst[o] = acc[q][o];
+      }
+  }
+}
+
+// wp[ci][ky][WROW]: wp[(ci*KW + ky)*WROW + kx*CO + o] = W[o][ci][ky][kx]
+__global__ void narrow_pack4_kernel(const float* w, float* wp, long long sO, long long sI, long long sH, long long sW,
+                                    int CO, int Ci, int KW, int WROW) {
+  const int total = Ci * KW * WROW;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int j = idx % WROW;
+    const int r = idx / WROW;
+    const int ky = r % KW, ci = r / KW;
+    const int kx = j / CO, o = j - kx * CO;
+    wp[idx] = (kx < KW) ? w[o * sO + ci * sI + ky * sH + kx * sW] : 0.f;
+  }
+}
+
+static bool narrow4_applicable(const srgan_conv_desc* d) {
+  return d->O == 3 && d->kh == 7 && d->kw == 7 && (d->I % N2_CH) == 0 && d->Wo >= 64;
+}
+
 // wp[cc][tap][c][4] = W[o][cc*16+c][ky][kx] (o < CO, zero otherwise)
 __global__ void narrow_pack_kernel(const float* w, float* wp, long long sO, long long sI, long long sH, long long sW,
                                    int CO, int Ci, int kh, int kw) {
@@ -244,6 +332,13 @@ size_t narrow_workspace(const srgan_conv_desc* d) {
 }
 
 int narrow_pack(const srgan_conv_desc* d, const float* w, float* wp, hipStream_t st) {
+  if (narrow4_applicable(d)) {
+    const int wrow = ((d->kw * d->O + 3) / 4) * 4;
+    const int total4 = d->I * d->kw * wrow;
+    hipLaunchKernelGGL(narrow_pack4_kernel, dim3((total4 + 255) / 256), dim3(256), 0, st, w, wp, d->sO, d->sI, d->sH, d->sW,
+                       d->O, d->I, d->kw, wrow);
+    return check_launch("narrow_pack4_kernel");
+  }
   const int total = d->I * d->kh * d->kw * 4;
   hipLaunchKernelGGL(narrow_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, d->sO, d->sI, d->sH, d->sW, d->O,
                      d->I, d->kh, d->kw);
@@ -255,6 +350,12 @@ int narrow_fwd_packed(const srgan_conv_desc* d, const float* x, const float* wp,
   p.x = x; p.wp = wp; p.bias = bias; p.y = y;
   p.N = d->N; p.H = d->Hi; p.W = d->Wi; p.Ci = d->I; p.Ho = d->Ho; p.Wo = d->Wo; p.CO = d->O;
   p.kh = d->kh; p.kw = d->kw; p.pad = d->pad;
+  if (narrow4_applicable(d)) {
+    const size_t sh4 = (size_t)N2_CH * (N2_ROWS + 6) * (N2_COLS + 8) * sizeof(float);
+    dim3 g4((unsigned)ceil_div(d->Wo, N2_COLS), (unsigned)ceil_div(d->Ho, N2_ROWS), (unsigned)d->N);
+    hipLaunchKernelGGL((narrow_conv_fwd4_kernel<3, 7>), g4, dim3(256), sh4, st, p);
+    return check_launch("narrow_conv_fwd4_kernel");
+  }
   const size_t shmem = (size_t)(NT_H + d->kh - 1) * (NT_W + d->kw - 1) * NPIX * sizeof(float);
   dim3 grid((unsigned)ceil_div(d->Wo, NT_W), (unsigned)ceil_div(d->Ho, NT_H), (unsigned)d->N);
   switch (d->O) {
