@@ -165,6 +165,11 @@ int srgan_soft_histogram_bwd(const float* x, const float* g, long long n, int bi
 int srgan_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                     float beta2, float eps, int step_count, void* stream);
 
+/* The same update for a whole parameter list in ONE launch.  `table` (device memory): n_tensors records of five
+ * 64-bit words {p, g, m, v, numel}; all tensors must share the step count (they do: one optimiser = one list). */
+int srgan_adam_multi(const void* table, int n_tensors, long long max_numel, float lr, float beta1, float beta2,
+                     float eps, int step_count, void* stream);
+
 /* ---- launch timer for bench.py's roofline leg (no reference counterpart) ---------------------
  * While enabled every implicit-GEMM / weight-gradient launch is bracketed by HIP events on its own
  * stream and tagged with its algorithmic FLOPs (2*N*Ho*Wo*O*kh*kw*I).  Collect after a device sync. */

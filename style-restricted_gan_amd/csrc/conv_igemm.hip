@@ -37,8 +37,9 @@ static size_t g_prof_next = 0;
 static const char* const kProfNames[] = {
     "igemm_kernel<128,128,2,2,gen>", "igemm_kernel<128,128,2,2,vec>", "igemm_kernel<128,64,2,2,gen>", "igemm_kernel<128,64,2,2,vec>",
     "igemm_kernel<128,32,4,1,gen>",  "igemm_kernel<128,32,4,1,vec>",  "igemm_kernel<64,64,2,2,gen>",  "igemm_kernel<64,64,2,2,vec>",
-    "wgrad_kernel<gen>", "wgrad_kernel<vec>", "igemm_kernel<256,128,4,2,gen>", "igemm_kernel<256,128,4,2,vec>"};
-constexpr int kProfKernels = 12;
+    "wgrad_kernel<gen>", "wgrad_kernel<vec>", "igemm_kernel<256,128,4,2,gen>", "igemm_kernel<256,128,4,2,vec>",
+    "igemm_kernel<256,64,4,2,gen>", "igemm_kernel<256,64,4,2,vec>"};
+constexpr int kProfKernels = 14;
 
 struct ProfScope {
   bool on;
@@ -495,6 +496,9 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   f32x4 a_reg[A_IT], b_reg[B_IT];
+  float b_msk[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) b_msk[i] = 1.f;
 
   auto fill_rowtab = [&](int t) {     // decode the 32 pixels of tile t (tid < 32 only)
     const int m = m_begin + t * 32 + tid;
@@ -581,9 +585,8 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
         x = x >= p.Wi ? 2 * p.Wi - 2 - x : x;
       }
       const bool ok = yok && (unsigned)x < (unsigned)p.Wi;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(bbase + (size_t)(ok ? x : 0) * p.Cs + c4 * 4);
-      const float mk = ok ? 1.f : 0.f;
-      b_reg[i] = v * mk;
+      b_reg[i] = *reinterpret_cast<const f32x4*>(bbase + (size_t)(ok ? x : 0) * p.Cs + c4 * 4);
+      b_msk[i] = ok ? 1.f : 0.f;        // applied when the tile is written to LDS (keeps the load in flight)
     }
     rw_b += 32;                                  // next tile: same image row, or wrap (Wg % 32 == 0)
     const int wb = rw_b == p.Wg;
@@ -663,23 +666,28 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(&As[(tid + NT * i) * 4]) = a_reg[i];
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(&Bs[(tid + NT * i) * 4]) = b_reg[i];
+    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(&Bs[(tid + NT * i) * 4]) = ROWS ? b_reg[i] * b_msk[i] : b_reg[i];
   };
   auto mfma_range = [&](int buf, int kp0, int kp1) {
     const float* As = As2[buf];
     const float* Bs = Bs2[buf];
+    float af[2][TM], bf[2][TN];          // fragments of step kp+1 are read before the MFMAs of step kp
+    auto read = [&](int kp, int slot) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[slot][i] = As[(2 * kp + lh) * BMc + wm * TM * 32 + i * 32 + lr];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[slot][j] = Bs[(2 * kp + lh) * BNn + wn * TN * 32 + j * 32 + lr];
+    };
+    read(kp0, 0);
 #pragma unroll
     for (int kp = kp0; kp < kp1; ++kp) {
-      float af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = As[(2 * kp + lh) * BMc + wm * TM * 32 + i * 32 + lr];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * kp + lh) * BNn + wn * TN * 32 + j * 32 + lr];
+      const int slot = (kp - kp0) & 1;
+      if (kp + 1 < kp1) read(kp + 1, slot ^ 1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i], bf[slot][j], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -785,13 +793,13 @@ namespace {
 struct TileChoice { int BM, BN; };
 
 TileChoice choose_tile(long long M, int N) {
+  static const bool big = std::getenv("SRGAN_NO_BIG_TILE") == nullptr;
   if (N <= 32) return {128, 32};
-  if (N <= 64) return {128, 64};
+  if (N <= 64) return (big && ceil_div(M, 256) >= 256) ? TileChoice{256, 64} : TileChoice{128, 64};
   long long tiles = ceil_div(M, 128) * ceil_div(N, 128);
   if (tiles < 256) return {64, 64};
   // 8-wave 256x128 workgroups (one per CU, both waves of a SIMD barrier-coupled) when the grid fills the chip in whole
   // rounds: avoids the tail in which one of two independent co-resident workgroups runs alone on its SIMDs
-  static const bool big = std::getenv("SRGAN_NO_BIG_TILE") == nullptr;
   long long big_tiles = ceil_div(M, 256) * ceil_div(N, 128);
   if (big && big_tiles >= 256) return {256, 128};
   return {128, 128};
@@ -799,7 +807,7 @@ TileChoice choose_tile(long long M, int N) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(const IgemmParams& p, int phases, bool vec, hipStream_t st, double flops) {
-  constexpr int tile_id = (BM == 256) ? 5 : (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 128 && BN == 32) ? 2 : 3;
+  constexpr int tile_id = (BM == 256 && BN == 64) ? 6 : (BM == 256) ? 5 : (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 128 && BN == 32) ? 2 : 3;
   ProfScope scope(tile_id * 2 + (vec ? 1 : 0), flops, st);
   dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)phases, 1);
   if (vec)
@@ -814,8 +822,9 @@ int run_igemm(IgemmParams p, int phases, hipStream_t st, double flops) {
   p.m_tiles = (int)ceil_div(p.M, tc.BM);
   p.n_tiles = (int)ceil_div(p.Cd, tc.BN);
   const bool vec = (p.Cs % BK) == 0;
-  if (tc.BM == 256 && vec) return launch_igemm<256, 128, 4, 2>(p, phases, true, st, flops);
-  if (tc.BM == 256) { tc = {128, 128}; p.m_tiles = (int)ceil_div(p.M, 128); }
+  if (tc.BM == 256 && tc.BN == 128 && vec) return launch_igemm<256, 128, 4, 2>(p, phases, true, st, flops);
+  if (tc.BM == 256 && tc.BN == 64 && vec) return launch_igemm<256, 64, 4, 2>(p, phases, true, st, flops);
+  if (tc.BM == 256) { tc = {128, tc.BN}; p.m_tiles = (int)ceil_div(p.M, 128); }
   if (tc.BM == 128 && tc.BN == 128) return launch_igemm<128, 128, 2, 2>(p, phases, vec, st, flops);
   if (tc.BM == 128 && tc.BN == 64) return launch_igemm<128, 64, 2, 2>(p, phases, vec, st, flops);
   if (tc.BM == 128 && tc.BN == 32) return launch_igemm<128, 32, 4, 1>(p, phases, vec, st, flops);

@@ -195,6 +195,26 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// multi-tensor Adam: one launch for a whole parameter list.  `table` holds n_tensors records of 5 x 8 bytes:
+// {p, g, m, v, numel}; blockIdx.y selects the tensor, blockIdx.x grid-strides over its elements.
+__global__ void adam_multi_kernel(const unsigned long long* __restrict__ table, float step_size, float beta1, float beta2,
+                                  float eps, float inv_sqrt_bc2) {
+  const unsigned long long* rec = table + (size_t)blockIdx.y * 5;
+  float* __restrict__ p = reinterpret_cast<float*>(rec[0]);
+  const float* __restrict__ g = reinterpret_cast<const float*>(rec[1]);
+  float* __restrict__ m = reinterpret_cast<float*>(rec[2]);
+  float* __restrict__ v = reinterpret_cast<float*>(rec[3]);
+  const long long n = (long long)rec[4];
+  GRID_STRIDE(i, n) {
+    const float gi = g[i];
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  }
+}
+
 }  // namespace srgan
 
 using namespace srgan;
@@ -298,4 +318,17 @@ extern "C" int srgan_adam_step(float* p, const float* g, float* m, float* v, lon
   const float step_size = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
   LAUNCH1D(adam_kernel, n, stream, p, g, m, v, n, step_size, beta1, beta2, eps, inv_sqrt_bc2);
+}
+
+extern "C" int srgan_adam_multi(const void* table, int n_tensors, long long max_numel, float lr, float beta1, float beta2,
+                                float eps, int step_count, void* stream) {
+  SRGAN_REQUIRE(table && n_tensors > 0 && max_numel > 0 && step_count >= 1, "adam_multi: bad argument");
+  const double bc1 = 1.0 - std::pow((double)beta1, step_count);
+  const double bc2 = 1.0 - std::pow((double)beta2, step_count);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
+  const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>(ceil_div(max_numel, 256 * 4), 64));
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(bx, (unsigned)n_tensors), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const unsigned long long*>(table), step_size, beta1, beta2, eps, inv_sqrt_bc2);
+  return check_launch("adam_multi_kernel");
 }

@@ -7,7 +7,7 @@ import os
 from ctypes import c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrgan_hip.so")
+LIB_PATH = os.environ.get("SRGAN_HIP_LIB") or os.path.join(_HERE, "libsrgan_hip.so")   # override: A/B kernel experiments
 
 
 class ConvDesc(ctypes.Structure):
@@ -64,6 +64,7 @@ SIGNATURES = {
     "srgan_soft_histogram_workspace": (c_size_t, [c_longlong, c_int]),
     "srgan_soft_histogram_fwd": (c_int, [P, c_longlong, c_int, c_float, c_float, c_float, P, P, c_size_t, P]),
     "srgan_soft_histogram_bwd": (c_int, [P, P, c_longlong, c_int, c_float, c_float, c_float, P, P]),
+    "srgan_adam_multi": (c_int, [P, c_int, c_longlong, c_float, c_float, c_float, c_float, c_int, P]),
     "srgan_prof_enable": (c_int, [c_int]),
     "srgan_prof_num_kernels": (c_int, []),
     "srgan_prof_kernel_name": (ctypes.c_char_p, [c_int]),

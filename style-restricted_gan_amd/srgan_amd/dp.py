@@ -151,15 +151,19 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         inv = 1.0 / ws
         for bucket, flat in work:
-            off = 0
+            flat.mul_(inv)                      # one launch for the whole bucket
+            views, dsts, off = [], [], 0
             for p in bucket:
                 n = p.numel()
-                avg = flat[off:off + n].view_as(p) * inv
+                v = flat[off:off + n].view_as(p)
                 if p.grad is None:
-                    p.grad = avg.clone()
+                    p.grad = v.clone()
                 else:
-                    p.grad.copy_(avg)
+                    views.append(v)
+                    dsts.append(p.grad)
                 off += n
+            if dsts:
+                torch._foreach_copy_(dsts, views)   # one multi-tensor launch instead of one copy per parameter
 
     def reduce(self):
         self.start()

@@ -746,3 +746,9 @@ def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
     _require_gpu(p, "adam")
     _lib.check(_lib.load().srgan_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
                                            float(beta2), float(eps), int(step), _stream()), "adam_step")
+
+
+def adam_multi_step_(table_dev, n_tensors, max_numel, lr, beta1, beta2, eps, step):
+    """One launch of torch-1.4 Adam over a list of tensors described by a device pointer table (see optim.Adam)."""
+    _lib.check(_lib.load().srgan_adam_multi(_ptr(table_dev), int(n_tensors), int(max_numel), float(lr), float(beta1),
+                                            float(beta2), float(eps), int(step), _stream()), "adam_multi")

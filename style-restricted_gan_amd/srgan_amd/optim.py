@@ -21,6 +21,7 @@ class Adam(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            batches = {}                 # step count -> [(p, g, m, v)]: one multi-tensor launch per count
             for p in group["params"]:
                 if p.grad is None:       # torch 1.4 skips parameters that received no gradient
                     continue
@@ -33,5 +34,18 @@ class Adam(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if not p.data.is_contiguous():
                     raise RuntimeError("srgan_amd.optim.Adam needs contiguous parameters")
-                ops.adam_step_(p.data, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"], st["step"])
+                batches.setdefault(st["step"], []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"]))
+            for step, items in batches.items():
+                if len(items) == 1:
+                    pd, g, m, v = items[0]
+                    ops.adam_step_(pd, g, m, v, group["lr"], b1, b2, group["eps"], step)
+                    continue
+                rows = []
+                for pd, g, m, v in items:
+                    rows.extend((pd.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), pd.numel()))
+                host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+                table = host.to(items[0][0].device, non_blocking=True)
+                ops.adam_multi_step_(table, len(items), max(pd.numel() for pd, _, _, _ in items), group["lr"], b1, b2,
+                                     group["eps"], step)
+                self._keep_alive = (host, table, items)     # until the next step: the launch reads them asynchronously
         return loss
