@@ -71,6 +71,17 @@ __device__ __forceinline__ float act_grad(float v, int act, float slope) {
 }
 
 
+// launch-timer bracket (conv_igemm.hip) usable from the other translation units
+struct ProfToken { size_t idx; bool on; };
+ProfToken prof_begin(int kid, double flops, hipStream_t st);
+void prof_end(ProfToken t, hipStream_t st);
+
+// conv_wino.hip: Winograd F(2x2,3x3) for 3x3 stride-1 pad-1 layers; kind 0 = forward, 1 = input gradient
+bool wino_applicable(const srgan_conv_desc* d, int kind);
+size_t wino_packed_bytes(const srgan_conv_desc* d, int kind);
+int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hipStream_t st);
+int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst, hipStream_t st);
+
 // conv_narrow.hip: direct kernels for Cout <= 4, stride-1, zero-pad layers
 bool narrow_applicable(const srgan_conv_desc* d);
 size_t narrow_workspace(const srgan_conv_desc* d);

@@ -20,6 +20,8 @@
 // MFMA k-slots {8q+4h+e} so that A and B fragments come from single ds_read_b128's.
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "common.h"
@@ -38,8 +40,8 @@ static const char* const kProfNames[] = {
     "igemm_kernel<128,128,2,2,gen>", "igemm_kernel<128,128,2,2,vec>", "igemm_kernel<128,64,2,2,gen>", "igemm_kernel<128,64,2,2,vec>",
     "igemm_kernel<128,32,4,1,gen>",  "igemm_kernel<128,32,4,1,vec>",  "igemm_kernel<64,64,2,2,gen>",  "igemm_kernel<64,64,2,2,vec>",
     "wgrad_kernel<gen>", "wgrad_kernel<vec>", "igemm_kernel<256,128,4,2,gen>", "igemm_kernel<256,128,4,2,vec>",
-    "igemm_kernel<256,64,4,2,gen>", "igemm_kernel<256,64,4,2,vec>"};
-constexpr int kProfKernels = 14;
+    "igemm_kernel<256,64,4,2,gen>", "igemm_kernel<256,64,4,2,vec>", "wino_kernel"};
+constexpr int kProfKernels = 15;
 
 struct ProfScope {
   bool on;
@@ -61,6 +63,26 @@ struct ProfScope {
     if (on) (void)hipEventRecord(g_prof_slots[idx].b, st);
   }
 };
+
+// the same bracket for kernels that live in other translation units (conv_wino.hip)
+ProfToken prof_begin(int kid, double flops, hipStream_t st) {
+  ProfToken t{0, false};
+  if (!g_prof_on) return t;
+  if (g_prof_next == g_prof_pool.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return t;
+    g_prof_pool.emplace_back(a, b);
+  }
+  auto& ev = g_prof_pool[g_prof_next++];
+  g_prof_slots.push_back({ev.first, ev.second, kid, flops});
+  t.idx = g_prof_slots.size() - 1;
+  t.on = true;
+  (void)hipEventRecord(ev.first, st);
+  return t;
+}
+void prof_end(ProfToken t, hipStream_t st) {
+  if (t.on) (void)hipEventRecord(g_prof_slots[t.idx].b, st);
+}
 
 struct IgemmParams {
   const float* src;
@@ -859,7 +881,61 @@ int validate(const srgan_conv_desc* d) {
   return 0;
 }
 
-struct WgradPlan { int BMc, BNn, splits, rows_per_split, Cdpad, NNpad, co_tiles, nn_tiles; bool vec; };
+struct WgradPlan { int BMc, BNn, splits, rows_per_split, Cdpad, NNpad, co_tiles, nn_tiles; bool vec, rows; };
+
+// the instantiation that serves a (tile, vec, rows) choice
+struct WgradVariant { void (*fn)(WgradParams); int threads; };
+
+template <int BMc, int BNn, int WM, int WN>
+static WgradVariant wgrad_variant(bool vec, bool rows) {
+  constexpr int NT = (WM * WN > 4 ? WM * WN : 4) * 64;
+  if constexpr (BMc >= 64 && BNn >= 64) {
+    if (vec && rows) return {wgrad_kernel<BMc, BNn, WM, WN, true, true>, NT};
+  }
+  if (vec) return {wgrad_kernel<BMc, BNn, WM, WN, true>, NT};
+  return {wgrad_kernel<BMc, BNn, WM, WN, false>, NT};
+}
+
+static bool wgrad_lookup(int BMc, int BNn, bool vec, bool rows, WgradVariant* k) {
+  if (BMc == 256 && BNn == 128) *k = wgrad_variant<256, 128, 4, 2>(vec, rows);
+  else if (BMc == 128 && BNn == 128) *k = wgrad_variant<128, 128, 2, 2>(vec, rows);
+  else if (BMc == 128 && BNn == 64) *k = wgrad_variant<128, 64, 2, 2>(vec, rows);
+  else if (BMc == 128 && BNn == 32) *k = wgrad_variant<128, 32, 4, 1>(vec, rows);
+  else if (BMc == 64 && BNn == 128) *k = wgrad_variant<64, 128, 2, 2>(vec, rows);
+  else if (BMc == 64 && BNn == 64) *k = wgrad_variant<64, 64, 2, 2>(vec, rows);
+  else if (BMc == 64 && BNn == 32) *k = wgrad_variant<64, 32, 2, 1>(vec, rows);
+  else if (BMc == 32 && BNn == 128) *k = wgrad_variant<32, 128, 1, 4>(vec, rows);
+  else if (BMc == 32 && BNn == 64) *k = wgrad_variant<32, 64, 1, 2>(vec, rows);
+  else if (BMc == 32 && BNn == 32) *k = wgrad_variant<32, 32, 1, 1>(vec, rows);
+  else return false;
+  return true;
+}
+
+// Workgroups of a weight-gradient variant the whole device holds at once (one "round" of the grid).  The split count is
+// chosen so that the grid is a whole number of rounds: a grid of 2.04 rounds costs three (measured: 1044 blocks on 512
+// slots ran 409 us where 1008 blocks need 373 us).  Falls back to the LDS bound when no device is present (the
+// workspace query is a host-only call).
+static long long wgrad_round_slots(const WgradPlan& w) {
+  static std::mutex mu;
+  static std::map<int, long long> cache;
+  const int key = (w.BMc << 16) | (w.BNn << 4) | (w.vec ? 2 : 0) | (w.rows ? 1 : 0);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0, cus = 0, dev = 0;
+  WgradVariant k{};
+  if (wgrad_lookup(w.BMc, w.BNn, w.vec, w.rows, &k) && hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.fn, k.threads, 0) == hipSuccess && per_cu > 0 && cus > 0) {
+    // measured
+  } else {
+    (void)hipGetLastError();
+    cus = 256;
+    const int lds = 2 * 32 * (std::max(w.BMc, 64) + std::max(w.BNn, 64)) * 4 + 1024;
+    per_cu = std::max(1, std::min(8, 163840 / lds));
+  }
+  return cache[key] = (long long)per_cu * cus;
+}
 
 WgradPlan plan_wgrad(const srgan_conv_desc* d) {
   WgradPlan w;
@@ -873,15 +949,33 @@ WgradPlan plan_wgrad(const srgan_conv_desc* d) {
   if (w.vec) w.BNn = (d->I % 128 == 0) ? 128 : ((d->I % 64 == 0) ? 64 : 32);
   else w.BNn = 64;
   // supported shapes: (128,128) (128,64) (128,32) (64,128) (64,64) (64,32) (32,128) (32,64) (32,32)
+  // row-aligned fast path: every 32-pixel tile inside one image row, every split a whole number of tiles
+  w.rows = w.vec && (d->Wo % 32) == 0 && (M % 32) == 0 && (d->O % 4) == 0;
   w.co_tiles = (int)ceil_div(d->O, w.BMc);
   w.nn_tiles = (int)ceil_div(NN, w.BNn);
   w.Cdpad = w.co_tiles * w.BMc;
   w.NNpad = w.nn_tiles * w.BNn;
-  long long tiles = (long long)w.co_tiles * w.nn_tiles;
-  static const long long wg_target = std::getenv("SRGAN_WGRAD_BLOCKS") ? std::atoll(std::getenv("SRGAN_WGRAD_BLOCKS")) : 1024;
-  long long want = ceil_div(w.BMc == 256 ? wg_target / 2 : wg_target, tiles);   // ~4 four-wave (2 eight-wave) blocks per CU
-  long long max_splits = ceil_div(M, 256);                // at least 8 K-tiles per split
-  long long splits = want < 1 ? 1 : want;
+  const long long tiles = (long long)w.co_tiles * w.nn_tiles;
+  const long long max_splits = std::max<long long>(1, ceil_div(M, 256));   // at least 8 K-tiles per split
+  static const long long wg_target = std::getenv("SRGAN_WGRAD_BLOCKS") ? std::atoll(std::getenv("SRGAN_WGRAD_BLOCKS")) : 512;
+  static const bool legacy = std::getenv("SRGAN_WGRAD_LEGACY_SPLIT") != nullptr;
+  long long splits;
+  if (legacy) {
+    splits = ceil_div(w.BMc == 256 ? wg_target / 2 : wg_target, tiles);
+  } else {
+    // about wg_target blocks, rounded to whole device rounds; among the candidate round counts take the best-filled
+    const long long slots = wgrad_round_slots(w);
+    const long long r0 = std::max<long long>(1, (wg_target + slots / 2) / slots);
+    double best_fill = -1.0;
+    splits = 1;
+    for (long long r = r0; r <= r0 + 2; ++r) {
+      long long s = std::min(std::max<long long>(1, (slots * r) / tiles), max_splits);
+      const long long blocks = tiles * s;
+      const long long rounds = ceil_div(blocks, slots);
+      const double fill = (double)blocks / (double)(rounds * slots);
+      if (fill > best_fill + 0.04) { best_fill = fill; splits = s; }
+    }
+  }
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   w.rows_per_split = (int)round_up(ceil_div(M, splits), 32);
@@ -898,7 +992,10 @@ size_t pack_bytes(const srgan_conv_desc* d) {
   const int Ty = (int)ceil_div(d->kh, s), Tx = (int)ceil_div(d->kw, s);
   const long long Kd = round_up((long long)Ty * Tx * d->O, BK);
   const long long g = (long long)s * s * round_up(d->I, 128) * Kd;
-  return (size_t)((f > g ? f : g) * sizeof(float));
+  size_t bytes = (size_t)((f > g ? f : g) * sizeof(float));
+  if (wino_applicable(d, 0)) bytes = std::max(bytes, wino_packed_bytes(d, 0));
+  if (wino_applicable(d, 1)) bytes = std::max(bytes, wino_packed_bytes(d, 1));
+  return bytes;
 }
 
 }  // namespace
@@ -922,13 +1019,14 @@ extern "C" size_t srgan_conv2d_workspace(const srgan_conv_desc* d) {
 
 namespace srgan {
 // ---- forward: which kernel family serves this layer, and the packed-weight layout it wants ----
-enum FwdPath { PATH_IGEMM = 0, PATH_NARROW = 1, PATH_WAVE = 2, PATH_DENSE = 3 };
+enum FwdPath { PATH_IGEMM = 0, PATH_NARROW = 1, PATH_WAVE = 2, PATH_DENSE = 3, PATH_WINO = 4 };
 
 static FwdPath fwd_path(const srgan_conv_desc* d, int act) {
   if (act == SRGAN_ACT_NONE) {
     if (dense_head_applicable(d)) return PATH_DENSE;
     if (narrow_wave_applicable(d)) return PATH_WAVE;
     if (narrow_applicable(d)) return PATH_NARROW;
+    if (wino_applicable(d, 0)) return PATH_WINO;
   }
   return PATH_IGEMM;
 }
@@ -946,6 +1044,7 @@ static void fwd_geometry(const srgan_conv_desc* d, FwdPath path, IgemmParams& p)
 static size_t fwd_packed_bytes(const srgan_conv_desc* d, int act) {
   const FwdPath path = fwd_path(d, act);
   if (path == PATH_NARROW) return (size_t)d->I * d->kh * d->kw * 4 * sizeof(float);
+  if (path == PATH_WINO) return wino_packed_bytes(d, 0);
   IgemmParams p{};
   fwd_geometry(d, path, p);
   return (size_t)p.Npad * p.Kpad * sizeof(float);
@@ -954,6 +1053,7 @@ static size_t fwd_packed_bytes(const srgan_conv_desc* d, int act) {
 static int fwd_pack(const srgan_conv_desc* d, int act, const float* w, float* dst, hipStream_t st) {
   const FwdPath path = fwd_path(d, act);
   if (path == PATH_NARROW) return narrow_pack(d, w, dst, st);
+  if (path == PATH_WINO) return wino_pack(d, 0, w, dst, st);
   IgemmParams p{};
   fwd_geometry(d, path, p);
   PackParams q{};
@@ -969,6 +1069,7 @@ static int fwd_run(const srgan_conv_desc* d, const float* x, const float* wp, co
                    float slope, hipStream_t st) {
   const FwdPath path = fwd_path(d, act);
   if (path == PATH_NARROW) return narrow_fwd_packed(d, x, wp, bias, y, st);
+  if (path == PATH_WINO) return wino_run(d, 0, x, wp, bias, y, st);
   IgemmParams p{};
   fwd_geometry(d, path, p);
   p.src = x; p.bias = bias; p.dst = y; p.act = act; p.slope = slope; p.wp = wp;
@@ -978,7 +1079,7 @@ static int fwd_run(const srgan_conv_desc* d, const float* x, const float* wp, co
 }
 
 // ---- input gradient / transposed-conv forward ----
-struct DgradGeom { IgemmParams p; int phases; bool reflect; int Hd, Wd; size_t packed_elems; };
+struct DgradGeom { IgemmParams p; int phases; bool reflect, wino; int Hd, Wd; size_t packed_elems; };
 
 static DgradGeom dgrad_geometry(const srgan_conv_desc* d) {
   DgradGeom g{};
@@ -1000,11 +1101,14 @@ static DgradGeom dgrad_geometry(const srgan_conv_desc* d) {
   p.reflect = 0; p.act = SRGAN_ACT_NONE; p.slope = 0.f;
   g.phases = s * s;
   g.packed_elems = (size_t)g.phases * p.Npad * p.Kpad;
+  g.wino = wino_applicable(d, 1);
+  if (g.wino) g.packed_elems = wino_packed_bytes(d, 1) / sizeof(float);
   return g;
 }
 
 static int dgrad_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st) {
   DgradGeom g = dgrad_geometry(d);
+  if (g.wino) return wino_pack(d, 1, w, dst, st);
   PackParams q{};
   q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
   q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 1; q.stride = d->stride; q.pad = g.p.pad;
@@ -1019,7 +1123,11 @@ static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp,
   DgradGeom g = dgrad_geometry(d);
   g.p.src = dy; g.p.wp = wp;
   g.p.dst = g.reflect ? scratch : dx;
-  if (int e = run_igemm(g.p, g.phases, st, conv_flops(d))) return e;
+  if (g.wino) {
+    if (int e = wino_run(d, 1, dy, wp, nullptr, g.p.dst, st)) return e;
+  } else if (int e = run_igemm(g.p, g.phases, st, conv_flops(d))) {
+    return e;
+  }
   if (g.reflect) {
     long long n = (long long)d->N * d->Hi * d->Wi * d->I;
     hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 256), 8192)), dim3(256), 0, st,
@@ -1083,19 +1191,12 @@ extern "C" int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* 
 }
 
 namespace srgan {
-template <int BMc, int BNn, int WM, int WN>
 static int launch_wgrad(const WgradParams& p, const WgradPlan& w, hipStream_t st) {
+  WgradVariant k{};
+  if (!wgrad_lookup(w.BMc, w.BNn, w.vec, w.rows, &k)) { set_error("wgrad: unsupported tile %dx%d", w.BMc, w.BNn); return -1; }
   ProfScope scope(8 + (w.vec ? 1 : 0), 2.0 * p.M * (double)p.Cd * p.NN, st);
   dim3 grid((unsigned)(w.co_tiles * w.nn_tiles * w.splits), 1, 1);
-  // row-aligned fast path: every 32-pixel tile inside one image row, every split a whole number of tiles
-  const bool rows = w.vec && (p.Wg % 32) == 0 && (p.rows_per_split % 32) == 0 && (p.M % 32) == 0 && (p.Cd % 4) == 0;
-  constexpr int NT = (WM * WN > 4 ? WM * WN : 4) * 64;
-  if (rows && BMc >= 64 && BNn >= 64)
-    hipLaunchKernelGGL((wgrad_kernel<(BMc >= 64 ? BMc : 64), (BNn >= 64 ? BNn : 64), (BMc >= 64 && BNn >= 64 ? WM : 2), (BMc >= 64 && BNn >= 64 ? WN : 2), true, true>), grid, dim3(BMc >= 64 && BNn >= 64 ? NT : 256), 0, st, p);
-  else if (w.vec)
-    hipLaunchKernelGGL((wgrad_kernel<BMc, BNn, WM, WN, true>), grid, dim3(NT), 0, st, p);
-  else
-    hipLaunchKernelGGL((wgrad_kernel<BMc, BNn, WM, WN, false>), grid, dim3(NT), 0, st, p);
+  hipLaunchKernelGGL(k.fn, grid, dim3(k.threads), 0, st, p);
   return check_launch("wgrad_kernel");
 }
 }  // namespace srgan
@@ -1149,18 +1250,7 @@ extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, cons
   p.NN = d->kh * d->kw * d->I; p.NNpad = w.NNpad; p.Cdpad = w.Cdpad;
   p.M = d->N * d->Ho * d->Wo; p.rows_per_split = w.rows_per_split;
   p.co_tiles = w.co_tiles; p.nn_tiles = w.nn_tiles;
-  int e = -1;
-  if (w.BMc == 256 && w.BNn == 128) e = launch_wgrad<256, 128, 4, 2>(p, w, st);
-  else if (w.BMc == 128 && w.BNn == 128) e = launch_wgrad<128, 128, 2, 2>(p, w, st);
-  else if (w.BMc == 128 && w.BNn == 64) e = launch_wgrad<128, 64, 2, 2>(p, w, st);
-  else if (w.BMc == 64 && w.BNn == 128) e = launch_wgrad<64, 128, 2, 2>(p, w, st);
-  else if (w.BMc == 64 && w.BNn == 64) e = launch_wgrad<64, 64, 2, 2>(p, w, st);
-  else if (w.BMc == 64 && w.BNn == 32) e = launch_wgrad<64, 32, 2, 1>(p, w, st);
-  else if (w.BMc == 32 && w.BNn == 128) e = launch_wgrad<32, 128, 1, 4>(p, w, st);
-  else if (w.BMc == 32 && w.BNn == 64) e = launch_wgrad<32, 64, 1, 2>(p, w, st);
-  else if (w.BMc == 32 && w.BNn == 32) e = launch_wgrad<32, 32, 1, 1>(p, w, st);
-  else if (w.BMc == 128 && w.BNn == 32) e = launch_wgrad<128, 32, 4, 1>(p, w, st);
-  else { set_error("wgrad: unsupported tile %dx%d", w.BMc, w.BNn); return -1; }
+  int e = launch_wgrad(p, w, st);
   if (e) return e;
   return finish_wgrad(d, w, dy, dw, dbias, ws, st);
 }

@@ -1,0 +1,350 @@
+// Winograd F(2x2, 3x3) convolution for the 3x3 / stride-1 layers (the generator's residual trunk is 64 % of the
+// step's FLOPs: SURVEY.md section 8a row a2, reference pyfiles/model.py:196-201), fp32 on the exact-fp32 MFMA.
+//
+//   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// 16 multiplies per 4 outputs instead of 36: 2.25x fewer MFMA FLOPs than the implicit GEMM.  One fused kernel:
+//   * the filter transform U = G g G^T is done once per optimiser step by the pack kernel (layout below),
+//   * a workgroup (8 waves) owns 64 output tiles x 64 output channels for ALL 16 transform positions;
+//     per 8-channel chunk each thread gathers one (tile, channel) 4x4 patch from NHWC global memory, transforms it
+//     in registers (32 adds) and writes the 16 results to LDS; the chunk of U (32 KB, contiguous) is copied to LDS,
+//   * wave w multiplies positions 2w, 2w+1: [64 tiles x 8] x [8 x 64 channels] on v_mfma_f32_32x32x2_f32,
+//     LDS double-buffered, one barrier per chunk, global loads issued two chunks ahead,
+//   * epilogue: the 16 position accumulators meet in LDS (two halves of 32 channels), each thread applies A^T . A
+//     and stores 2x2 pixels x 32 contiguous channels.
+// The same kernel serves the input gradient (flipped / transposed filter in the pack kernel, pad' = 2 - pad + ...).
+#include <algorithm>
+#include <cstdlib>
+#include "common.h"
+
+namespace srgan {
+
+constexpr int WT = 64;   // output tiles per workgroup
+constexpr int WNB = 64;  // output channels per workgroup
+constexpr int WC = 8;    // reduce channels per chunk
+
+struct WinoParams {
+  const float* src;   // [NB][H][W][C]
+  const float* u;     // [n_tiles][nchunk][16][64][8] transformed filters
+  const float* bias;  // [Cd] or null
+  float* dst;         // [NB][Ho][Wo][Cd]
+  int NB, H, W, C, Ho, Wo, Cd;
+  int pad, reflect;
+  int TH, TW, T;      // tile grid per image, tiles in total
+  int nchunk, n_tiles, m_tiles;
+};
+
+__global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
+  // [buf][ V: 16 pos x 64 tiles x 8 ch | U: 16 pos x 64 couts x 8 ch ]  = 2 x 64 KB; reused whole by the epilogue
+  __shared__ __attribute__((aligned(16))) float lds[2 * 16384];
+  __shared__ int tile_o[WT];      // destination pixel index of the tile's (0,0) output, or -1
+  __shared__ int tile_f[WT];      // bit0: column 1 inside, bit1: row 1 inside
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  // XCD-aware order: hardware sends workgroup b to XCD b % 8; give each XCD a contiguous range of tile rows so the
+  // n_tiles workgroups that read the same input patch share one L2
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int m_tile = bid / p.n_tiles, n_tile = bid - m_tile * p.n_tiles;
+
+  // ---- gather role: thread = (tile tl, channel ch) ----
+  const int tl = tid >> 3, ch = tid & 7;
+  unsigned off[16];
+  unsigned okmask = 0;
+  {
+    const int t = m_tile * WT + tl;
+    const bool tv = t < p.T;
+    const int tt = tv ? t : 0;
+    const int per = p.TH * p.TW;
+    const int b = tt / per;
+    const int r = tt - b * per;
+    const int ty = r / p.TW, tx = r - ty * p.TW;
+    if (ch == 0) {
+      const int oy = 2 * ty, ox = 2 * tx;
+      tile_o[tl] = tv ? (b * p.Ho + oy) * p.Wo + ox : -1;
+      tile_f[tl] = ((ox + 1 < p.Wo) ? 1 : 0) | ((oy + 1 < p.Ho) ? 2 : 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int iy = 2 * ty - p.pad + i;
+      bool yok = tv;
+      if (p.reflect) {
+        iy = iy < 0 ? -iy : iy;
+        iy = iy >= p.H ? 2 * p.H - 2 - iy : iy;
+      } else {
+        yok = yok && (unsigned)iy < (unsigned)p.H;
+      }
+      iy = min(max(iy, 0), p.H - 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int ix = 2 * tx - p.pad + j;
+        bool ok = yok;
+        if (p.reflect) {
+          ix = ix < 0 ? -ix : ix;
+          ix = ix >= p.W ? 2 * p.W - 2 - ix : ix;
+        } else {
+          ok = ok && (unsigned)ix < (unsigned)p.W;
+        }
+        ix = min(max(ix, 0), p.W - 1);
+        off[i * 4 + j] = (unsigned)(((b * p.H + iy) * p.W + ix) * p.C + ch) * 4u;
+        okmask |= (ok ? 1u : 0u) << (i * 4 + j);
+      }
+    }
+  }
+
+  const float* ubase = p.u + (size_t)n_tile * p.nchunk * 8192;
+  float d[16];
+  f32x4 ur[4];
+  auto load_chunk = [&](int kc) {
+    const char* sb = reinterpret_cast<const char*>(p.src) + (size_t)kc * (WC * 4);   // wave-uniform base
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = *reinterpret_cast<const float*>(sb + off[i]);
+    const float* us = ubase + (size_t)kc * 8192;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ur[i] = *reinterpret_cast<const f32x4*>(us + (i * 512 + tid) * 4);
+  };
+  // B^T d B in registers, 16 results to V[pos][tile][ch] (lane-linear: conflict-free), U copied as is
+  auto store_chunk = [&](int buf) {
+    float* V = lds + buf * 16384;
+    float* U = V + 8192;
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = ((okmask >> i) & 1u) ? d[i] : 0.f;
+    float t[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      t[0 * 4 + c] = x[0 * 4 + c] - x[2 * 4 + c];
+      t[1 * 4 + c] = x[1 * 4 + c] + x[2 * 4 + c];
+      t[2 * 4 + c] = x[2 * 4 + c] - x[1 * 4 + c];
+      t[3 * 4 + c] = x[1 * 4 + c] - x[3 * 4 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      V[(r * 4 + 0) * 512 + tid] = t[r * 4 + 0] - t[r * 4 + 2];
+      V[(r * 4 + 1) * 512 + tid] = t[r * 4 + 1] + t[r * 4 + 2];
+      V[(r * 4 + 2) * 512 + tid] = t[r * 4 + 2] - t[r * 4 + 1];
+      V[(r * 4 + 3) * 512 + tid] = t[r * 4 + 1] - t[r * 4 + 3];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(U + (i * 512 + tid) * 4) = ur[i];
+  };
+
+  // ---- multiply role: wave = positions 2*wave, 2*wave+1 over the whole 64 x 64 tile ----
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.f;
+
+  f32x4 af[2][2], bf[2][2];   // [slot = position within the wave][row / column tile]
+  auto read_frags = [&](int buf, int slot) {
+    const float* V = lds + buf * 16384 + (2 * wave + slot) * 512;
+    const float* U = lds + buf * 16384 + 8192 + (2 * wave + slot) * 512;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[slot][i] = *reinterpret_cast<const f32x4*>(V + (i * 32 + lr) * 8 + lh * 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bf[slot][j] = *reinterpret_cast<const f32x4*>(U + (j * 32 + lr) * 8 + lh * 4);
+  };
+  auto mfma_steps = [&](int slot, int e0, int e1) {
+#pragma unroll
+    for (int e = e0; e < e1; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[slot][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i][e], bf[slot][j][e], acc[slot][i][j], 0, 0, 0);
+  };
+
+  const int nk = p.nchunk;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  read_frags(0, 0);
+  if (nk > 1) load_chunk(1);
+  for (int kc = 0; kc < nk; ++kc) {
+    const int cur = kc & 1;
+    const bool more = kc + 1 < nk;
+    read_frags(cur, 1);
+    mfma_steps(0, 0, 4);
+    if (more) store_chunk(cur ^ 1);        // chunk kc+1: its loads were issued a whole chunk ago
+    mfma_steps(1, 0, 2);
+    __syncthreads();                       // chunk kc+1 visible; every wave holds its last fragments of chunk kc
+    if (more) {
+      read_frags(cur ^ 1, 0);
+      if (kc + 2 < nk) load_chunk(kc + 2);
+    }
+    mfma_steps(1, 2, 4);
+  }
+
+  // ---- epilogue: A^T M A, two halves of 32 output channels ----
+  const int cl = tid & 31, tg = tid >> 5;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int tile = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          lds[(2 * wave + a) * 2048 + tile * 32 + lr] = acc[a][i][half][e];
+        }
+    __syncthreads();
+    const int n = n_tile * WNB + half * 32 + cl;
+    const bool nok = n < p.Cd;
+    const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int tile = tg + 16 * q;
+      float m[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) m[k] = lds[k * 2048 + tile * 32 + cl];
+      float s0[4], s1[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        s0[c] = m[0 * 4 + c] + m[1 * 4 + c] + m[2 * 4 + c];
+        s1[c] = m[1 * 4 + c] - m[2 * 4 + c] - m[3 * 4 + c];
+      }
+      const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
+      const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
+      const int o = tile_o[tile], f = tile_f[tile];
+      if (nok && o >= 0) {
+        float* dp = p.dst + (size_t)o * p.Cd + n;
+        dp[0] = y00;
+        if (f & 1) dp[p.Cd] = y01;
+        if (f & 2) {
+          dp[(size_t)p.Wo * p.Cd] = y10;
+          if (f & 1) dp[(size_t)(p.Wo + 1) * p.Cd] = y11;
+        }
+      }
+    }
+  }
+}
+
+// ---- filter transform: U[n_tile][chunk][pos][64][8] = (G g G^T)[pos], one thread per (n, c) pair ----
+// kind 0 (forward): g = w[n][c][ky][kx];  kind 1 (input gradient): g = w[c][n][2-ky][2-kx]
+struct WinoPackParams {
+  const float* w;
+  float* dst;
+  long long sO, sI, sH, sW;
+  int N, C, kind, nchunk, n_tiles;
+};
+
+__global__ void wino_pack_kernel(WinoPackParams p) {
+  const long long total = (long long)p.n_tiles * WNB * p.nchunk * WC;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(idx % WC);
+    long long r = idx / WC;
+    const int nl = (int)(r % WNB); r /= WNB;
+    const int chunk = (int)(r % p.nchunk);
+    const int ntile = (int)(r / p.nchunk);
+    const int n = ntile * WNB + nl, c = chunk * WC + cc;
+    float g[3][3];
+    const bool ok = n < p.N && c < p.C;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        float v = 0.f;
+        if (ok) v = p.kind == 0 ? p.w[n * p.sO + c * p.sI + ky * p.sH + kx * p.sW]
+                                : p.w[c * p.sO + n * p.sI + (2 - ky) * p.sH + (2 - kx) * p.sW];
+        g[ky][kx] = v;
+      }
+    // rows: G g  (4x3), G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+    float h[4][3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      h[0][kx] = g[0][kx];
+      h[1][kx] = 0.5f * (g[0][kx] + g[1][kx] + g[2][kx]);
+      h[2][kx] = 0.5f * (g[0][kx] - g[1][kx] + g[2][kx]);
+      h[3][kx] = g[2][kx];
+    }
+    float* out = p.dst + (((size_t)ntile * p.nchunk + chunk) * 16) * (WNB * WC) + nl * WC + cc;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      out[(a * 4 + 0) * (WNB * WC)] = h[a][0];
+      out[(a * 4 + 1) * (WNB * WC)] = 0.5f * (h[a][0] + h[a][1] + h[a][2]);
+      out[(a * 4 + 2) * (WNB * WC)] = 0.5f * (h[a][0] - h[a][1] + h[a][2]);
+      out[(a * 4 + 3) * (WNB * WC)] = h[a][2];
+    }
+  }
+}
+
+// ---- host side ----
+// kind 0: y = conv(x, w) ; kind 1: dx = conv(dy, flipped w^T) with pad' = 2 - pad (zero pad) or the full
+// correlation onto the reflect-padded image (pad' = 2, output Hi+2p), folded by the caller.
+static bool wino_disabled() {
+  static const bool off = std::getenv("SRGAN_NO_WINOGRAD") != nullptr;
+  return off;
+}
+
+bool wino_applicable(const srgan_conv_desc* d, int kind) {
+  if (wino_disabled()) return false;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return false;
+  const int C = kind == 0 ? d->I : d->O, N = kind == 0 ? d->O : d->I;
+  if (C % WC != 0 || C < 32 || N < 32) return false;
+  if (d->Hi < 3 || d->Wi < 3) return false;
+  return true;
+}
+
+static void wino_dims(const srgan_conv_desc* d, int kind, int* C, int* N, int* n_tiles, int* nchunk) {
+  *C = kind == 0 ? d->I : d->O;
+  *N = kind == 0 ? d->O : d->I;
+  *n_tiles = (int)ceil_div(*N, WNB);
+  *nchunk = *C / WC;
+}
+
+size_t wino_packed_bytes(const srgan_conv_desc* d, int kind) {
+  int C, N, n_tiles, nchunk;
+  wino_dims(d, kind, &C, &N, &n_tiles, &nchunk);
+  return (size_t)n_tiles * nchunk * 8192 * sizeof(float);
+}
+
+int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hipStream_t st) {
+  WinoPackParams q{};
+  int C, N;
+  wino_dims(d, kind, &C, &N, &q.n_tiles, &q.nchunk);
+  q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW; q.N = N; q.C = C; q.kind = kind;
+  const long long total = (long long)q.n_tiles * WNB * q.nchunk * WC;
+  hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
+  return check_launch("wino_pack_kernel");
+}
+
+// dst geometry: kind 0 -> [N][Ho][Wo][O]; kind 1 -> [N][Hd][Wd][I] with Hd = Hi (zero pad) or Hi + 2 (reflect scratch)
+int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst,
+             hipStream_t st) {
+  WinoParams p{};
+  int C, N;
+  wino_dims(d, kind, &C, &N, &p.n_tiles, &p.nchunk);
+  const bool reflect = d->pad_mode == SRGAN_PAD_REFLECT;
+  p.src = src; p.u = packed; p.bias = bias; p.dst = dst;
+  p.NB = d->N; p.C = C; p.Cd = N;
+  if (kind == 0) {
+    p.H = d->Hi; p.W = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo; p.pad = d->pad; p.reflect = reflect ? 1 : 0;
+  } else {
+    p.H = d->Ho; p.W = d->Wo; p.reflect = 0;
+    p.pad = reflect ? 2 : 2 - d->pad;
+    p.Ho = d->Ho + 2 * p.pad - 2; p.Wo = d->Wo + 2 * p.pad - 2;
+  }
+  p.TH = (p.Ho + 1) / 2; p.TW = (p.Wo + 1) / 2;
+  const long long T = (long long)p.NB * p.TH * p.TW;
+  SRGAN_REQUIRE(T < (1LL << 30), "winograd: too many tiles");
+  p.T = (int)T;
+  p.m_tiles = (int)ceil_div(T, WT);
+  const long long grid = (long long)p.m_tiles * p.n_tiles;
+  SRGAN_REQUIRE(grid < (1LL << 31), "winograd: grid too large");
+  ProfToken tok = prof_begin(14, 2.0 * 16.0 * (double)T * C * N, st);   // EXECUTED MFMA FLOPs (2.25x below the direct count)
+  hipLaunchKernelGGL(wino_kernel, dim3((unsigned)grid), dim3(512), 0, st, p);
+  prof_end(tok, st);
+  return check_launch("wino_kernel");
+}
+
+}  // namespace srgan

@@ -59,8 +59,12 @@ def test_train_trajectory_vs_reference_full_size(golden_dir):
         for key, v in net.state_dict().items():
             ck = gold[f"{net_name}_ck.{key}"]
             v = v.detach().double().cpu()
-            assert abs(float(v.norm()) - ck[1]) <= 1e-4 * max(ck[1], 1e-6), key
-            np.testing.assert_allclose(v.flatten()[:8].numpy(), ck[2:], atol=4e-4)
+            # Adam's first steps move an element by ~lr * sign(g): where g is within rounding of zero the sign -- and
+            # with it up to 2 * lr * steps of that element -- depends on summation order (Winograd vs direct conv,
+            # GPU vs CPU).  One such element is budgeted on top of the relative bound.
+            flip = 2 * 1e-4 * 4      # 2 * lr * (at most 2 optimiser steps per train step x 2 train steps)
+            assert abs(float(v.norm()) - ck[1]) <= 1e-4 * max(ck[1], 1e-6) + flip, key
+            np.testing.assert_allclose(v.flatten()[:8].numpy(), ck[2:], atol=flip)
 
 
 def test_train_step_vs_oracle_with_loss_terms():
