@@ -15,7 +15,12 @@
 // The same kernel serves the input gradient (flipped / transposed filter in the pack kernel, pad' = 2 - pad + ...).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
+
+#ifndef WINO_EXP
+#define WINO_EXP 0
+#endif
 
 namespace srgan {
 
@@ -25,7 +30,7 @@ constexpr int WC = 8;    // reduce channels per chunk
 
 struct WinoParams {
   const float* src;   // [NB][H][W][C]
-  const float* u;     // [n_tiles][nchunk][16][64][8] transformed filters
+  const float* u;     // [n_tiles][nchunk][16 pos][2 halves][64 couts][4 ch] transformed filters
   const float* bias;  // [Cd] or null
   float* dst;         // [NB][Ho][Wo][Cd]
   int NB, H, W, C, Ho, Wo, Cd;
@@ -35,8 +40,15 @@ struct WinoParams {
 };
 
 __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
-  // [buf][ V: 16 pos x 64 tiles x 8 ch | U: 16 pos x 64 couts x 8 ch ]  = 2 x 64 KB; reused whole by the epilogue
-  __shared__ __attribute__((aligned(16))) float lds[2 * 16384];
+  // V image, double-buffered: [buf][16 pos][2 channel halves][64 tiles x 4 ch + 16 pad] (+32 pad per position).
+  // A lane's MFMA fragment (4 channels of one tile) is one 16-B slot and a 16-lane read group covers 256 contiguous
+  // bytes (conflict-free ds_read_b128); the 16-float pad puts the two halves a gather wave writes on different
+  // banks; the position stride 576 % 64 == 0 keeps the paired store (ds_write2st64_b32) usable.
+  // The transformed filters never touch LDS: position p of U is used by exactly one wave, which loads its fragments
+  // straight from the packed image into registers.  The epilogue reuses the whole array (32768 floats).
+  constexpr int VH = 64 * 4 + 16, VP = 2 * VH + 32, VSZ = 16 * VP;
+  static_assert(2 * VSZ <= 32768, "V buffers must fit the epilogue image");
+  __shared__ __attribute__((aligned(16))) float lds[32768];
   __shared__ int tile_o[WT];      // destination pixel index of the tile's (0,0) output, or -1
   __shared__ int tile_f[WT];      // bit0: column 1 inside, bit1: row 1 inside
 
@@ -49,10 +61,11 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
   const int m_tile = bid / p.n_tiles, n_tile = bid - m_tile * p.n_tiles;
 
-  // ---- gather role: thread = (tile tl, channel ch) ----
+  // ---- gather role: thread = (tile tl, channel ch); 16 byte offsets, out-of-image taps point past the buffer
+  // (the buffer load's range check returns 0 for them: zero padding without a select) ----
   const int tl = tid >> 3, ch = tid & 7;
+  constexpr unsigned kOutside = 0x80000000u;
   unsigned off[16];
-  unsigned okmask = 0;
   {
     const int t = m_tile * WT + tl;
     const bool tv = t < p.T;
@@ -73,10 +86,10 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
       if (p.reflect) {
         iy = iy < 0 ? -iy : iy;
         iy = iy >= p.H ? 2 * p.H - 2 - iy : iy;
+        iy = min(max(iy, 0), p.H - 1);
       } else {
         yok = yok && (unsigned)iy < (unsigned)p.H;
       }
-      iy = min(max(iy, 0), p.H - 1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int ix = 2 * tx - p.pad + j;
@@ -84,51 +97,59 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
         if (p.reflect) {
           ix = ix < 0 ? -ix : ix;
           ix = ix >= p.W ? 2 * p.W - 2 - ix : ix;
+          ix = min(max(ix, 0), p.W - 1);
         } else {
           ok = ok && (unsigned)ix < (unsigned)p.W;
         }
-        ix = min(max(ix, 0), p.W - 1);
-        off[i * 4 + j] = (unsigned)(((b * p.H + iy) * p.W + ix) * p.C + ch) * 4u;
-        okmask |= (ok ? 1u : 0u) << (i * 4 + j);
+        off[i * 4 + j] = ok ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.C + ch) * 4u : kOutside;
       }
     }
   }
+  // descriptors from wave-uniform values only; the per-chunk advance goes into the scalar offset
+  const unsigned src_bytes = (unsigned)((size_t)p.NB * p.H * p.W * p.C * 4);
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, src_bytes, 0x00020000);
+  const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u) + (size_t)n_tile * p.nchunk * 8192, 0,
+                                                       (unsigned)p.nchunk * 32768u, 0x00020000);
+  // this lane's fragment of U inside a chunk image [16 pos][2 halves][64 couts][4]: position 2*wave + slot, column
+  // tile j -> byte offset ubase + slot * 2048 + j * 512
+  const unsigned ubase = (unsigned)((2 * wave) * 512 + lh * 256 + lr * 4) * 4u;
 
-  const float* ubase = p.u + (size_t)n_tile * p.nchunk * 8192;
   float d[16];
-  f32x4 ur[4];
-  auto load_chunk = [&](int kc) {
-    const char* sb = reinterpret_cast<const char*>(p.src) + (size_t)kc * (WC * 4);   // wave-uniform base
+  f32x4 bfr[2][2][2];      // [chunk parity][slot = position within the wave][column tile]
+  auto load_x = [&](int kc) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) d[i] = *reinterpret_cast<const float*>(sb + off[i]);
-    const float* us = ubase + (size_t)kc * 8192;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ur[i] = *reinterpret_cast<const f32x4*>(us + (i * 512 + tid) * 4);
+    for (int i = 0; i < 16; ++i)
+      d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off[i], kc * (WC * 4), 0));
   };
-  // B^T d B in registers, 16 results to V[pos][tile][ch] (lane-linear: conflict-free), U copied as is
-  auto store_chunk = [&](int buf) {
-    float* V = lds + buf * 16384;
-    float* U = V + 8192;
-    float x[16];
+  auto load_u = [&](int kc, auto par) {
+    constexpr int P = decltype(par)::value;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = ((okmask >> i) & 1u) ? d[i] : 0.f;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfr[P][a][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ubase + a * 2048 + j * 512, kc * 32768, 0));
+  };
+  // B^T d B in registers, 16 results to V[pos][half][tile][ch & 3]
+  auto store_v = [&](int buf) {
+#if WINO_EXP == 4
+    return;
+#endif
+    float* V = lds + buf * VSZ + (ch >> 2) * VH + tl * 4 + (ch & 3);
     float t[16];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      t[0 * 4 + c] = x[0 * 4 + c] - x[2 * 4 + c];
-      t[1 * 4 + c] = x[1 * 4 + c] + x[2 * 4 + c];
-      t[2 * 4 + c] = x[2 * 4 + c] - x[1 * 4 + c];
-      t[3 * 4 + c] = x[1 * 4 + c] - x[3 * 4 + c];
+      t[0 * 4 + c] = d[0 * 4 + c] - d[2 * 4 + c];
+      t[1 * 4 + c] = d[1 * 4 + c] + d[2 * 4 + c];
+      t[2 * 4 + c] = d[2 * 4 + c] - d[1 * 4 + c];
+      t[3 * 4 + c] = d[1 * 4 + c] - d[3 * 4 + c];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      V[(r * 4 + 0) * 512 + tid] = t[r * 4 + 0] - t[r * 4 + 2];
-      V[(r * 4 + 1) * 512 + tid] = t[r * 4 + 1] + t[r * 4 + 2];
-      V[(r * 4 + 2) * 512 + tid] = t[r * 4 + 2] - t[r * 4 + 1];
-      V[(r * 4 + 3) * 512 + tid] = t[r * 4 + 1] - t[r * 4 + 3];
+      V[(r * 4 + 0) * VP] = t[r * 4 + 0] - t[r * 4 + 2];
+      V[(r * 4 + 1) * VP] = t[r * 4 + 1] + t[r * 4 + 2];
+      V[(r * 4 + 2) * VP] = t[r * 4 + 2] - t[r * 4 + 1];
+      V[(r * 4 + 3) * VP] = t[r * 4 + 1] - t[r * 4 + 3];
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(U + (i * 512 + tid) * 4) = ur[i];
   };
 
   // ---- multiply role: wave = positions 2*wave, 2*wave+1 over the whole 64 x 64 tile ----
@@ -142,45 +163,83 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.f;
 
-  f32x4 af[2][2], bf[2][2];   // [slot = position within the wave][row / column tile]
+  f32x4 af[2][2];   // [slot][row tile]
   auto read_frags = [&](int buf, int slot) {
-    const float* V = lds + buf * 16384 + (2 * wave + slot) * 512;
-    const float* U = lds + buf * 16384 + 8192 + (2 * wave + slot) * 512;
+    const float* V = lds + buf * VSZ + (2 * wave + slot) * VP + lh * VH;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) af[slot][i] = *reinterpret_cast<const f32x4*>(V + (i * 32 + lr) * 8 + lh * 4);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bf[slot][j] = *reinterpret_cast<const f32x4*>(U + (j * 32 + lr) * 8 + lh * 4);
+    for (int i = 0; i < 2; ++i) af[slot][i] = *reinterpret_cast<const f32x4*>(V + (i * 32 + lr) * 4);
   };
-  auto mfma_steps = [&](int slot, int e0, int e1) {
+  auto mfma_steps = [&](auto par, int slot, int e0, int e1) {
+    constexpr int P = decltype(par)::value;
 #pragma unroll
     for (int e = e0; e < e1; ++e)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[slot][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i][e], bf[slot][j][e], acc[slot][i][j], 0, 0, 0);
+          acc[slot][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i][e], bfr[P][slot][j][e], acc[slot][i][j], 0, 0, 0);
   };
 
+  // Two waves share a SIMD (wave w and w + 4).  They run the chunk's non-MFMA work (patch transform, LDS stores, the
+  // next global loads) at DIFFERENT points of the iteration -- class 0 between its MFMA groups, class 1 in front
+  // of them.  The LDS / memory counters are in-order and the compiler merges their state at every control-flow
+  // join, so the steady-state loop holds one straight-line body per (class, chunk parity); the tail iterations
+  // (no store / no load) are separate instantiations.
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using T = std::true_type;
+  using F = std::false_type;
+  const int cls = wave >> 2;
   const int nk = p.nchunk;
-  load_chunk(0);
-  store_chunk(0);
+  load_x(0);
+  load_u(0, I0{});
+  store_v(0);
   __syncthreads();
   read_frags(0, 0);
-  if (nk > 1) load_chunk(1);
-  for (int kc = 0; kc < nk; ++kc) {
-    const int cur = kc & 1;
-    const bool more = kc + 1 < nk;
-    read_frags(cur, 1);
-    mfma_steps(0, 0, 4);
-    if (more) store_chunk(cur ^ 1);        // chunk kc+1: its loads were issued a whole chunk ago
-    mfma_steps(1, 0, 2);
-    __syncthreads();                       // chunk kc+1 visible; every wave holds its last fragments of chunk kc
-    if (more) {
-      read_frags(cur ^ 1, 0);
-      if (kc + 2 < nk) load_chunk(kc + 2);
+  if (nk > 1) load_x(1);
+  auto iter = [&](int kc, auto c1, auto par, auto st, auto ld) {
+    constexpr bool C1 = decltype(c1)::value, ST = decltype(st)::value, LD = decltype(ld)::value;
+    constexpr int P = decltype(par)::value;
+    using NP = std::integral_constant<int, 1 - P>;
+    read_frags(P, 1);
+    // the LDS stores must have drained when the wave reaches the barrier, or every wave waits for them with the
+    // matrix pipe idle: >= 16 MFMAs are kept between the stores and the barrier (sched_barrier pins the order)
+    if constexpr (C1) {
+      if constexpr (ST) {
+        load_u(kc + 1, NP{});              // fragments of chunk kc+1: wanted at the top of the next iteration
+        store_v(1 - P);                    // chunk kc+1: its loads were issued a whole chunk ago
+        if constexpr (LD) load_x(kc + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mfma_steps(par, 0, 0, 4);
+    } else {
+      mfma_steps(par, 0, 0, 2);
+      if constexpr (ST) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(kc + 1, NP{});
+        store_v(1 - P);
+        if constexpr (LD) load_x(kc + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mfma_steps(par, 0, 2, 4);
     }
-    mfma_steps(1, 2, 4);
-  }
+    mfma_steps(par, 1, 0, 2);
+    __builtin_amdgcn_sched_barrier(0);     // keep those MFMAs in front of the barrier
+    __syncthreads();                       // chunk kc+1 visible; every wave holds its last fragments of chunk kc
+    if constexpr (ST) read_frags(1 - P, 0);
+    mfma_steps(par, 1, 2, 4);
+  };
+  auto run = [&](auto c1) {
+    int kc = 0;
+    for (; kc + 3 < nk; kc += 2) {
+      iter(kc, c1, I0{}, T{}, T{});
+      iter(kc + 1, c1, I1{}, T{}, T{});
+    }
+    // nchunk is even (wino_applicable): exactly two chunks are left
+    iter(kc, c1, I0{}, T{}, F{});
+    iter(kc + 1, c1, I1{}, F{}, F{});
+  };
+  if (cls == 0) run(F{}); else run(T{});
 
   // ---- epilogue: A^T M A, two halves of 32 output channels ----
   const int cl = tid & 31, tg = tid >> 5;
@@ -228,7 +287,7 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   }
 }
 
-// ---- filter transform: U[n_tile][chunk][pos][64][8] = (G g G^T)[pos], one thread per (n, c) pair ----
+// ---- filter transform: U[n_tile][chunk][pos][c/4][64][c%4] = (G g G^T)[pos], one thread per (n, c) pair ----
 // kind 0 (forward): g = w[n][c][ky][kx];  kind 1 (input gradient): g = w[c][n][2-ky][2-kx]
 struct WinoPackParams {
   const float* w;
@@ -267,7 +326,8 @@ __global__ void wino_pack_kernel(WinoPackParams p) {
       h[2][kx] = 0.5f * (g[0][kx] - g[1][kx] + g[2][kx]);
       h[3][kx] = g[2][kx];
     }
-    float* out = p.dst + (((size_t)ntile * p.nchunk + chunk) * 16) * (WNB * WC) + nl * WC + cc;
+    // within a position: [channel half][cout][4 channels] -- the LDS image of the kernel, copied linearly
+    float* out = p.dst + (((size_t)ntile * p.nchunk + chunk) * 16) * (WNB * WC) + (cc >> 2) * (WNB * 4) + nl * 4 + (cc & 3);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       out[(a * 4 + 0) * (WNB * WC)] = h[a][0];
@@ -290,8 +350,11 @@ bool wino_applicable(const srgan_conv_desc* d, int kind) {
   if (wino_disabled()) return false;
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return false;
   const int C = kind == 0 ? d->I : d->O, N = kind == 0 ? d->O : d->I;
-  if (C % WC != 0 || C < 32 || N < 32) return false;
+  if (C % (2 * WC) != 0 || C < 32 || N < 32) return false;   // an even number of 8-channel chunks
   if (d->Hi < 3 || d->Wi < 3) return false;
+  // the gather's "outside" offset (2 GiB) must lie past the end of the source tensor
+  const long long src_elems = (long long)d->N * (kind == 0 ? (long long)d->Hi * d->Wi * d->I : (long long)d->Ho * d->Wo * d->O);
+  if (src_elems >= (1LL << 29)) return false;
   return true;
 }
 

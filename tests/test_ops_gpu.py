@@ -56,7 +56,7 @@ CONV_CASES = [
     (2, 32, 32, 64, 64, 3, 1, 1, True, False),    # row-aligned weight-gradient path with reflect padding
     (2, 128, 64, 64, 128, 4, 2, 1, False, False), # row-aligned path, stride 2, 128x128 tiles, several splits
     (32, 256, 16, 16, 256, 3, 1, 1, False, False),# 8-wave 256x128 forward / dgrad tiles
-    (3, 40, 7, 11, 40, 3, 1, 1, False, True),     # Winograd path: odd sizes, ragged tile / channel blocks, bias
+    (3, 48, 7, 11, 40, 3, 1, 1, False, True),     # Winograd path: odd sizes, ragged tile / channel blocks, bias
     (2, 48, 5, 4, 72, 3, 1, 1, True, True),       # Winograd path: reflect padding, bias, 2 output-channel blocks
     (5, 64, 32, 32, 64, 3, 1, 1, False, False),   # Winograd path: tiles not a multiple of 64 per image boundary
 ]
