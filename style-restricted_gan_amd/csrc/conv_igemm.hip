@@ -40,8 +40,8 @@ static const char* const kProfNames[] = {
     "igemm_kernel<128,128,2,2,gen>", "igemm_kernel<128,128,2,2,vec>", "igemm_kernel<128,64,2,2,gen>", "igemm_kernel<128,64,2,2,vec>",
     "igemm_kernel<128,32,4,1,gen>",  "igemm_kernel<128,32,4,1,vec>",  "igemm_kernel<64,64,2,2,gen>",  "igemm_kernel<64,64,2,2,vec>",
     "wgrad_kernel<gen>", "wgrad_kernel<vec>", "igemm_kernel<256,128,4,2,gen>", "igemm_kernel<256,128,4,2,vec>",
-    "igemm_kernel<256,64,4,2,gen>", "igemm_kernel<256,64,4,2,vec>", "wino_kernel"};
-constexpr int kProfKernels = 15;
+    "igemm_kernel<256,64,4,2,gen>", "igemm_kernel<256,64,4,2,vec>", "wino_kernel", "wino_wgrad_kernel"};
+constexpr int kProfKernels = 16;
 
 struct ProfScope {
   bool on;
@@ -1010,6 +1010,7 @@ extern "C" size_t srgan_conv2d_workspace(const srgan_conv_desc* d) {
   if (d->pad_mode == SRGAN_PAD_REFLECT)
     bytes += (size_t)d->N * (d->Hi + 2 * d->pad) * (d->Wi + 2 * d->pad) * d->I * sizeof(float);
   WgradPlan w = plan_wgrad(d);
+  if (wino_wgrad_applicable(d)) wino_wgrad_slab(d, &w.splits, &w.Cdpad, &w.NNpad);
   size_t wg = (size_t)w.splits * w.Cdpad * w.NNpad * sizeof(float);
   size_t cs = (size_t)1024 * d->O * sizeof(float);
   if (wg + cs > bytes) bytes = wg + cs;
@@ -1237,6 +1238,11 @@ extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, cons
   SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_wgrad: workspace too small");
   hipStream_t st = as_stream(stream);
   WgradPlan w = plan_wgrad(d);
+  if (wino_wgrad_applicable(d)) {
+    wino_wgrad_slab(d, &w.splits, &w.Cdpad, &w.NNpad);
+    if (int e = wino_wgrad_run(d, x, dy, (float*)ws, st)) return e;
+    return finish_wgrad(d, w, dy, dw, dbias, ws, st);
+  }
   if (narrow_applicable(d)) {
     int n_slabs = 0;
     if (int e = narrow_wgrad(d, x, dy, ws, &n_slabs, st)) return e;

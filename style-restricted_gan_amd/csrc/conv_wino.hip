@@ -287,6 +287,257 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   }
 }
 
+// ---- weight gradient:  dU[pos][o][i] = sum_tiles (A dY A^T)[pos][t][o] * (B^T d B)[pos][t][i],  dW = G^T dU G ----
+// Same 2.25x saving; both MFMA operands are transformed data, so both go through LDS.
+//   * a workgroup owns 64 output channels x 64 input channels for all 16 positions over a SPLIT of the tiles;
+//     a chunk is 8 tiles at the same 8 tile positions of consecutive images, so a thread's gather offsets (and the
+//     padding mask folded into them) are constant while the scalar offset walks over the batch,
+//   * thread = (tile of the chunk, channel): 16 + 4 buffer loads, two register transforms, 32 LDS stores laid out
+//     [pos][tile half][channel][4 tiles] so that a lane's MFMA fragment (4 consecutive K = tiles) is one 16-B slot,
+//   * epilogue: positions meet in LDS, each thread applies G^T . G and writes the 3x3 taps of its (o, i) pairs into
+//     the split-K slab [split][O][9 * I] that wgrad_reduce_kernel (conv_igemm.hip) sums.
+struct WinoWgradParams {
+  const float* x;     // [NB][H][W][C]
+  const float* dy;    // [NB][Ho][Wo][O]
+  float* slab;        // [splits][Opad][9 * C]
+  int NB, H, W, C, Ho, Wo, O;
+  int pad, reflect;
+  int TH, TW;          // tile grid per image
+  int groups;          // ceil(TH * TW / 8): 8-tile position groups per image
+  int groups_per_split, splits;
+  int o_tiles, i_tiles, Opad;
+};
+
+__global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
+  // [buf][ Z: 16 pos x 2 tile halves x 64 o x 4 tiles | V: same with 64 i ] = 2 x 64 KB, reused by the epilogue
+  __shared__ __attribute__((aligned(16))) float lds[32768];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  int bid = blockIdx.x;
+  const int split = bid / (p.o_tiles * p.i_tiles);
+  bid -= split * (p.o_tiles * p.i_tiles);
+  const int o_tile = bid / p.i_tiles, i_tile = bid - o_tile * p.i_tiles;
+
+  // gather role: tile of the chunk = 4 * (wave >> 2) + (lane & 3), channel = 16 * (wave & 3) + (lane >> 2)
+  const int th = wave >> 2, tq = lane & 3;
+  const int chl = (wave & 3) * 16 + (lane >> 2);
+  const int ci = i_tile * 64 + chl, co = o_tile * 64 + chl;
+  constexpr unsigned kOutside = 0x80000000u;
+  unsigned offx[16], offd[4];
+  auto set_group = [&](int g) {       // offsets of this thread's tile at tile-position group g (image 0)
+    const int q = g * 8 + th * 4 + tq;
+    const bool tv = q < p.TH * p.TW && g < p.groups;
+    const int qq = tv ? q : 0;
+    const int ty = qq / p.TW, tx = qq - ty * p.TW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int iy = 2 * ty - p.pad + i;
+      bool yok = tv && ci < p.C;
+      if (p.reflect) {
+        iy = iy < 0 ? -iy : iy;
+        iy = iy >= p.H ? 2 * p.H - 2 - iy : iy;
+        iy = min(max(iy, 0), p.H - 1);
+      } else {
+        yok = yok && (unsigned)iy < (unsigned)p.H;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int ix = 2 * tx - p.pad + j;
+        bool ok = yok;
+        if (p.reflect) {
+          ix = ix < 0 ? -ix : ix;
+          ix = ix >= p.W ? 2 * p.W - 2 - ix : ix;
+          ix = min(max(ix, 0), p.W - 1);
+        } else {
+          ok = ok && (unsigned)ix < (unsigned)p.W;
+        }
+        offx[i * 4 + j] = ok ? (unsigned)((iy * p.W + ix) * p.C + ci) * 4u : kOutside;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int oy = 2 * ty + i, ox = 2 * tx + j;
+        const bool ok = tv && co < p.O && oy < p.Ho && ox < p.Wo;
+        offd[i * 2 + j] = ok ? (unsigned)((oy * p.Wo + ox) * p.O + co) * 4u : kOutside;
+      }
+  };
+  const unsigned x_img = (unsigned)(p.H * p.W * p.C) * 4u, d_img = (unsigned)(p.Ho * p.Wo * p.O) * 4u;
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, x_img * (unsigned)p.NB, 0x00020000);
+  const auto rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, d_img * (unsigned)p.NB, 0x00020000);
+
+  // load cursor (two chunks ahead of the multiply): group lg, image lb
+  const int g0 = split * p.groups_per_split;
+  const int g1 = min(g0 + p.groups_per_split, p.groups);
+  const int nk = max(g1 - g0, 0) * p.NB;
+  int lg = g0, lb = 0;
+  set_group(lg);
+  float dx[16], dd[4];
+  auto load_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      dx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, offx[i], lb * x_img, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      dd[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, offd[i], lb * d_img, 0));
+    if (++lb == p.NB) {      // next tile-position group (wave-uniform, once per NB chunks)
+      lb = 0;
+      ++lg;
+      set_group(lg);
+    }
+  };
+  const int wofs = th * 256 + (wave & 3) * 64 + lane;     // [half][channel][tile & 3], lane-linear
+  auto store_chunk = [&](int buf) {
+    float* Z = lds + buf * 16384 + wofs;
+    float* V = Z + 8192;
+    float t[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      t[0 * 4 + c] = dx[0 * 4 + c] - dx[2 * 4 + c];
+      t[1 * 4 + c] = dx[1 * 4 + c] + dx[2 * 4 + c];
+      t[2 * 4 + c] = dx[2 * 4 + c] - dx[1 * 4 + c];
+      t[3 * 4 + c] = dx[1 * 4 + c] - dx[3 * 4 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      V[(r * 4 + 0) * 512] = t[r * 4 + 0] - t[r * 4 + 2];
+      V[(r * 4 + 1) * 512] = t[r * 4 + 1] + t[r * 4 + 2];
+      V[(r * 4 + 2) * 512] = t[r * 4 + 2] - t[r * 4 + 1];
+      V[(r * 4 + 3) * 512] = t[r * 4 + 1] - t[r * 4 + 3];
+    }
+    // A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
+    const float r0[2] = {dd[0], dd[1]};
+    const float r1[2] = {dd[0] + dd[2], dd[1] + dd[3]};
+    const float r2[2] = {dd[0] - dd[2], dd[1] - dd[3]};
+    const float r3[2] = {-dd[2], -dd[3]};
+    const float* rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Z[(r * 4 + 0) * 512] = rr[r][0];
+      Z[(r * 4 + 1) * 512] = rr[r][0] + rr[r][1];
+      Z[(r * 4 + 2) * 512] = rr[r][0] - rr[r][1];
+      Z[(r * 4 + 3) * 512] = -rr[r][1];
+    }
+  };
+
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.f;
+  f32x4 af[2][2], bf[2][2];
+  auto read_frags = [&](int buf, int slot) {
+    const float* Z = lds + buf * 16384 + (2 * wave + slot) * 512 + lh * 256;
+    const float* V = Z + 8192;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[slot][i] = *reinterpret_cast<const f32x4*>(Z + (i * 32 + lr) * 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bf[slot][j] = *reinterpret_cast<const f32x4*>(V + (j * 32 + lr) * 4);
+  };
+  auto mfma_steps = [&](int slot, int e0, int e1) {
+#pragma unroll
+    for (int e = e0; e < e1; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[slot][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i][e], bf[slot][j][e], acc[slot][i][j], 0, 0, 0);
+  };
+
+  using T = std::true_type;
+  using F = std::false_type;
+  const int cls = wave >> 2;
+  if (nk > 0) {
+    load_chunk();
+    store_chunk(0);
+    __syncthreads();
+    read_frags(0, 0);
+    if (nk > 1) load_chunk();
+    auto iter = [&](int kc, auto c1, auto st, auto ld) {
+      constexpr bool C1 = decltype(c1)::value, ST = decltype(st)::value, LD = decltype(ld)::value;
+      const int cur = kc & 1;
+      read_frags(cur, 1);
+      if constexpr (C1) {
+        if constexpr (ST) {
+          store_chunk(cur ^ 1);
+          if constexpr (LD) load_chunk();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_steps(0, 0, 4);
+      } else {
+        mfma_steps(0, 0, 2);
+        if constexpr (ST) {
+          __builtin_amdgcn_sched_barrier(0);
+          store_chunk(cur ^ 1);
+          if constexpr (LD) load_chunk();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_steps(0, 2, 4);
+      }
+      mfma_steps(1, 0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      if constexpr (ST) read_frags(cur ^ 1, 0);
+      mfma_steps(1, 2, 4);
+    };
+    auto run = [&](auto c1) {
+      int kc = 0;
+      for (; kc + 2 < nk; ++kc) iter(kc, c1, T{}, T{});
+      if (nk >= 2) iter(nk - 2, c1, T{}, F{});
+      iter(nk - 1, c1, F{}, F{});
+    };
+    if (cls == 0) run(F{}); else run(T{});
+  }
+
+  // ---- epilogue: G^T dU G per (o, i), two halves of 32 input channels; slab[split][o][tap * C + i] ----
+  const int cl = tid & 31, tg = tid >> 5;
+  float* slab = p.slab + (size_t)split * p.Opad * (9 * p.C);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          lds[(2 * wave + a) * 2048 + row * 32 + lr] = acc[a][i][half][e];
+        }
+    __syncthreads();
+    const int ic = i_tile * 64 + half * 32 + cl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = tg + 16 * q;
+      const int oc = o_tile * 64 + row;
+      float u[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) u[k] = lds[k * 2048 + row * 32 + cl];
+      float h[3][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        h[0][c] = u[0 * 4 + c] + 0.5f * (u[1 * 4 + c] + u[2 * 4 + c]);
+        h[1][c] = 0.5f * (u[1 * 4 + c] - u[2 * 4 + c]);
+        h[2][c] = 0.5f * (u[1 * 4 + c] + u[2 * 4 + c]) + u[3 * 4 + c];
+      }
+      if (oc < p.O && ic < p.C) {
+        float* dst = slab + (size_t)oc * (9 * p.C) + ic;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          dst[(a * 3 + 0) * p.C] = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
+          dst[(a * 3 + 1) * p.C] = 0.5f * (h[a][1] - h[a][2]);
+          dst[(a * 3 + 2) * p.C] = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
+        }
+      }
+    }
+  }
+}
+
 // ---- filter transform: U[n_tile][chunk][pos][c/4][64][c%4] = (G g G^T)[pos], one thread per (n, c) pair ----
 // kind 0 (forward): g = w[n][c][ky][kx];  kind 1 (input gradient): g = w[c][n][2-ky][2-kx]
 struct WinoPackParams {
@@ -408,6 +659,52 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
   hipLaunchKernelGGL(wino_kernel, dim3((unsigned)grid), dim3(512), 0, st, p);
   prof_end(tok, st);
   return check_launch("wino_kernel");
+}
+
+// ---- weight gradient host side ----
+static bool wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
+  static const bool off = std::getenv("SRGAN_NO_WINOGRAD_WGRAD") != nullptr;
+  if (wino_disabled() || off) return false;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return false;
+  if (d->I % 64 != 0 || d->O % 64 != 0 || d->Hi < 3 || d->Wi < 3) return false;
+  if ((long long)d->N * d->Hi * d->Wi * d->I >= (1LL << 29) || (long long)d->N * d->Ho * d->Wo * d->O >= (1LL << 29)) return false;
+  p->NB = d->N; p->H = d->Hi; p->W = d->Wi; p->C = d->I; p->Ho = d->Ho; p->Wo = d->Wo; p->O = d->O;
+  p->pad = d->pad; p->reflect = d->pad_mode == SRGAN_PAD_REFLECT ? 1 : 0;
+  p->TH = (d->Ho + 1) / 2; p->TW = (d->Wo + 1) / 2;
+  p->groups = (int)ceil_div((long long)p->TH * p->TW, 8);
+  p->o_tiles = d->O / 64; p->i_tiles = d->I / 64; p->Opad = d->O;
+  const int tiles = p->o_tiles * p->i_tiles;
+  // one workgroup per CU (128 KB of LDS): fill whole rounds of 256; at least 16 chunks per workgroup
+  int splits = std::max(1, 256 / tiles);
+  splits = std::min(splits, p->groups);
+  p->groups_per_split = (int)ceil_div(p->groups, splits);
+  p->splits = (int)ceil_div(p->groups, p->groups_per_split);
+  if ((long long)tiles * p->splits < 16) return false;                        // too few workgroups: implicit GEMM instead
+  if ((long long)p->groups_per_split * d->N < 4) return false;                // too short a K range per workgroup
+  return true;
+}
+
+bool wino_wgrad_applicable(const srgan_conv_desc* d) {
+  WinoWgradParams p{};
+  return wino_wgrad_geometry(d, &p);
+}
+
+// slab geometry for wgrad_reduce_kernel: [splits][Cdpad = O][NNpad = 9 * I]
+void wino_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad) {
+  WinoWgradParams p{};
+  wino_wgrad_geometry(d, &p);
+  *splits = p.splits; *Cdpad = p.Opad; *NNpad = 9 * d->I;
+}
+
+int wino_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, hipStream_t st) {
+  WinoWgradParams p{};
+  SRGAN_REQUIRE(wino_wgrad_geometry(d, &p), "winograd wgrad: layer not applicable");
+  p.x = x; p.dy = dy; p.slab = slab;
+  const double T = (double)d->N * p.TH * p.TW;
+  ProfToken tok = prof_begin(15, 2.0 * 16.0 * T * d->I * d->O, st);     // executed MFMA FLOPs
+  hipLaunchKernelGGL(wino_wgrad_kernel, dim3((unsigned)(p.o_tiles * p.i_tiles * p.splits)), dim3(512), 0, st, p);
+  prof_end(tok, st);
+  return check_launch("wino_wgrad_kernel");
 }
 
 }  // namespace srgan

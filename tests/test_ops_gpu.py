@@ -59,6 +59,9 @@ CONV_CASES = [
     (3, 48, 7, 11, 40, 3, 1, 1, False, True),     # Winograd path: odd sizes, ragged tile / channel blocks, bias
     (2, 48, 5, 4, 72, 3, 1, 1, True, True),       # Winograd path: reflect padding, bias, 2 output-channel blocks
     (5, 64, 32, 32, 64, 3, 1, 1, False, False),   # Winograd path: tiles not a multiple of 64 per image boundary
+    (8, 64, 18, 14, 128, 3, 1, 1, False, True),   # Winograd weight gradient: 63 tile positions (ragged last group), bias
+    (4, 128, 17, 9, 128, 3, 1, 1, True, False),   # Winograd weight gradient: odd sizes (half tiles), reflect padding
+    (16, 256, 16, 16, 128, 3, 1, 1, False, False),# Winograd weight gradient: several groups per split
 ]
 
 
