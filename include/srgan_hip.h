@@ -177,6 +177,8 @@ int srgan_prof_enable(int on);
 int srgan_prof_num_kernels(void);
 const char* srgan_prof_kernel_name(int kid);
 int srgan_prof_collect(int kid, double* total_ms, long long* launches, double* total_flops);
+int srgan_prof_num_slots(void);
+int srgan_prof_slot(int index, int* kid, double* ms, double* flops);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,27 @@
+"""Per-(kernel, FLOP count) table of the GEMM launches of one train step: which layers run below the fleet average."""
+import sys, os, ctypes, collections
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "style-restricted_gan_amd"))
+import torch
+import bench
+from srgan_amd import _lib
+lib = _lib.load()
+B = 32
+sg = bench.build_trainer(128, B, 5, torch.device("cuda"))
+batches = []
+for s in range(2):
+    x, src, tgt = bench.synthetic_batch(B, 128, 4, seed=s)
+    batches.append((x.cuda(), {"source": src.cuda(), "target": tgt}))
+sg.train(*batches[0]); torch.cuda.synchronize()
+lib.srgan_prof_enable(1)
+sg.train(*batches[1]); torch.cuda.synchronize()
+lib.srgan_prof_enable(0)
+agg = collections.defaultdict(list)
+for i in range(lib.srgan_prof_num_slots()):
+    kid, ms, fl = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+    _lib.check(lib.srgan_prof_slot(i, ctypes.byref(kid), ctypes.byref(ms), ctypes.byref(fl)), "slot")
+    agg[(lib.srgan_prof_kernel_name(kid.value).decode(), round(fl.value / 1e9, 2))].append(ms.value)
+rows = sorted(agg.items(), key=lambda kv: -sum(kv[1]))
+tot = sum(sum(v) for v in agg.values())
+print(f"GEMM launches total {tot:.2f} ms")
+for (name, gf), v in rows[:60]:
+    print(f"{name:32s} {gf:8.2f} GF x{len(v):3d}  avg {1e3*sum(v)/len(v):8.1f} us  {gf/ (sum(v)/len(v)):7.1f} TF   total {sum(v):6.2f} ms")

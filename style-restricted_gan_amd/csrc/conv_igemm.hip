@@ -1080,7 +1080,20 @@ static int fwd_run(const srgan_conv_desc* d, const float* x, const float* wp, co
 }
 
 // ---- input gradient / transposed-conv forward ----
-struct DgradGeom { IgemmParams p; int phases; bool reflect, wino; int Hd, Wd; size_t packed_elems; };
+// Input gradient of a stride-1 zero-padded conv with <= 4 INPUT channels (the generator's 7x7 RGB layer inside the
+// cycle / identity passes) = a narrow-OUTPUT convolution of dy with the flipped, transposed filter.  The implicit
+// GEMM would pad those 3 channels to a 32-wide MFMA tile (9 % useful); conv_narrow.hip serves them directly.
+static bool narrow_dgrad_desc(const srgan_conv_desc* d, srgan_conv_desc* f, long long* w_off) {
+  if (d->stride != 1 || d->pad_mode != SRGAN_PAD_ZERO || d->I > 4 || d->kh != d->kw || d->kh - 1 - d->pad < 0) return false;
+  *f = *d;
+  f->Hi = d->Ho; f->Wi = d->Wo; f->Ho = d->Hi; f->Wo = d->Wi; f->I = d->O; f->O = d->I;
+  f->pad = d->kh - 1 - d->pad;
+  f->sO = d->sI; f->sI = d->sO; f->sH = -d->sH; f->sW = -d->sW;     // w'[i][o][ky][kx] = w[o][i][kh-1-ky][kw-1-kx]
+  *w_off = (long long)(d->kh - 1) * d->sH + (long long)(d->kw - 1) * d->sW;
+  return narrow_applicable(f);
+}
+
+struct DgradGeom { IgemmParams p; int phases; bool reflect, wino, narrow; int Hd, Wd; size_t packed_elems; };
 
 static DgradGeom dgrad_geometry(const srgan_conv_desc* d) {
   DgradGeom g{};
@@ -1104,12 +1117,22 @@ static DgradGeom dgrad_geometry(const srgan_conv_desc* d) {
   g.packed_elems = (size_t)g.phases * p.Npad * p.Kpad;
   g.wino = wino_applicable(d, 1);
   if (g.wino) g.packed_elems = wino_packed_bytes(d, 1) / sizeof(float);
+  srgan_conv_desc f;
+  long long w_off;
+  g.narrow = !g.wino && narrow_dgrad_desc(d, &f, &w_off);
+  if (g.narrow) g.packed_elems = (size_t)f.I * f.kh * f.kw * 4;
   return g;
 }
 
 static int dgrad_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st) {
   DgradGeom g = dgrad_geometry(d);
   if (g.wino) return wino_pack(d, 1, w, dst, st);
+  if (g.narrow) {
+    srgan_conv_desc f;
+    long long w_off;
+    narrow_dgrad_desc(d, &f, &w_off);
+    return narrow_pack(&f, w + w_off, dst, st);
+  }
   PackParams q{};
   q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
   q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 1; q.stride = d->stride; q.pad = g.p.pad;
@@ -1124,6 +1147,12 @@ static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp,
   DgradGeom g = dgrad_geometry(d);
   g.p.src = dy; g.p.wp = wp;
   g.p.dst = g.reflect ? scratch : dx;
+  if (g.narrow) {
+    srgan_conv_desc f;
+    long long w_off;
+    narrow_dgrad_desc(d, &f, &w_off);
+    return narrow_fwd_packed(&f, dy, wp, nullptr, dx, st);
+  }
   if (g.wino) {
     if (int e = wino_run(d, 1, dy, wp, nullptr, g.p.dst, st)) return e;
   } else if (int e = run_igemm(g.p, g.phases, st, conv_flops(d))) {
@@ -1273,6 +1302,18 @@ extern "C" int srgan_prof_enable(int on) {
 extern "C" int srgan_prof_num_kernels(void) { return kProfKernels; }
 extern "C" const char* srgan_prof_kernel_name(int kid) {
   return (kid >= 0 && kid < kProfKernels) ? kProfNames[kid] : "";
+}
+// One timed launch of the session (index < srgan_prof_num_slots()): kernel id, duration, algorithmic FLOPs.
+extern "C" int srgan_prof_num_slots(void) { return (int)g_prof_slots.size(); }
+extern "C" int srgan_prof_slot(int index, int* kid, double* ms, double* flops) {
+  SRGAN_REQUIRE(kid && ms && flops, "prof_slot: null pointer");
+  SRGAN_REQUIRE(index >= 0 && (size_t)index < g_prof_slots.size(), "prof_slot: index out of range");
+  const ProfSlot& s = g_prof_slots[index];
+  float t = 0.f;
+  hipError_t e = hipEventElapsedTime(&t, s.a, s.b);
+  if (e != hipSuccess) { set_error("prof_slot: %s", hipGetErrorString(e)); return (int)e; }
+  *kid = s.kid; *ms = t; *flops = s.flops;
+  return 0;
 }
 // Totals of the session for one kernel id; call after the streams have been synchronised.
 extern "C" int srgan_prof_collect(int kid, double* total_ms, long long* launches, double* total_flops) {

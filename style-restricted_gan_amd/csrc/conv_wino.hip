@@ -655,7 +655,8 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
   p.m_tiles = (int)ceil_div(T, WT);
   const long long grid = (long long)p.m_tiles * p.n_tiles;
   SRGAN_REQUIRE(grid < (1LL << 31), "winograd: grid too large");
-  ProfToken tok = prof_begin(14, 2.0 * 16.0 * (double)T * C * N, st);   // EXECUTED MFMA FLOPs (2.25x below the direct count)
+  // ALGORITHMIC FLOPs of the direct convolution; the kernel issues 2.25x fewer on the matrix pipe
+  ProfToken tok = prof_begin(14, 2.0 * 9.0 * (double)p.NB * p.Ho * p.Wo * C * N, st);
   hipLaunchKernelGGL(wino_kernel, dim3((unsigned)grid), dim3(512), 0, st, p);
   prof_end(tok, st);
   return check_launch("wino_kernel");
@@ -700,8 +701,7 @@ int wino_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, fl
   WinoWgradParams p{};
   SRGAN_REQUIRE(wino_wgrad_geometry(d, &p), "winograd wgrad: layer not applicable");
   p.x = x; p.dy = dy; p.slab = slab;
-  const double T = (double)d->N * p.TH * p.TW;
-  ProfToken tok = prof_begin(15, 2.0 * 16.0 * T * d->I * d->O, st);     // executed MFMA FLOPs
+  ProfToken tok = prof_begin(15, 2.0 * 9.0 * (double)d->N * d->Ho * d->Wo * d->I * d->O, st);   // algorithmic FLOPs, as above
   hipLaunchKernelGGL(wino_wgrad_kernel, dim3((unsigned)(p.o_tiles * p.i_tiles * p.splits)), dim3(512), 0, st, p);
   prof_end(tok, st);
   return check_launch("wino_wgrad_kernel");

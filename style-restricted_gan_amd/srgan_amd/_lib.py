@@ -69,6 +69,8 @@ SIGNATURES = {
     "srgan_prof_num_kernels": (c_int, []),
     "srgan_prof_kernel_name": (ctypes.c_char_p, [c_int]),
     "srgan_prof_collect": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_longlong), POINTER(ctypes.c_double)]),
+    "srgan_prof_num_slots": (c_int, []),
+    "srgan_prof_slot": (c_int, [c_int, POINTER(c_int), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "srgan_adam_step": (c_int, [P, P, P, P, c_longlong, c_float, c_float, c_float, c_float, c_int, P]),
 }
 

@@ -62,6 +62,8 @@ CONV_CASES = [
     (8, 64, 18, 14, 128, 3, 1, 1, False, True),   # Winograd weight gradient: 63 tile positions (ragged last group), bias
     (4, 128, 17, 9, 128, 3, 1, 1, True, False),   # Winograd weight gradient: odd sizes (half tiles), reflect padding
     (16, 256, 16, 16, 128, 3, 1, 1, False, False),# Winograd weight gradient: several groups per split
+    (2, 3, 24, 70, 64, 7, 1, 3, False, False),    # RGB 7x7 layer: input gradient through the narrow-output kernel (flipped filter)
+    (2, 3, 12, 13, 32, 5, 1, 2, False, True),     # same route, generic narrow kernel (5x5), bias
 ]
 
 
