@@ -1,0 +1,17 @@
+#!/bin/bash
+# One evidence run on the GPU box: un-profiled bench (with the CPU baseline), --stats run, FETCH_SIZE / WRITE_SIZE passes.
+R=$(cd "$(dirname "$0")/.." && pwd)
+E=$R/gpurun_out/ev
+rm -rf $E && mkdir -p $E
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py --steps 5 --warmup 2 > $E/bench_plain.json 2> $E/bench_plain.err || exit 1
+echo "plain done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $E/bench_under_rocprof.json 2> $E/stats.err || exit 1
+echo "stats done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $E/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $E/fetch.err || exit 1
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $E/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $E/write.err || exit 1
+echo "write done"
+# keep the merge-back small: counter CSVs only (traces of the PMC passes are large)
+find $E/fetch $E/write -name "*kernel_trace.csv" -delete
+find $E/stats -name "*kernel_trace.csv" -delete

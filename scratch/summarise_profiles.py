@@ -1,0 +1,54 @@
+"""Turns the rocprofv3 outputs of one evidence run (gpurun_out/ev/{stats,fetch,write}) into the files kept under
+profiles/: the kernel-stats CSV as is, and r<NN>_pmc_traffic.json = per-launch HBM bytes per GEMM kernel
+(2 * FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md's HBM section; separate PMC passes)."""
+import csv, glob, json, os, re, shutil, sys, collections
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ev = os.path.join(root, "gpurun_out", "ev")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+
+
+def prof_name(n):
+    n = n.replace("void ", "").replace("srgan::", "")
+    m = re.match(r"igemm_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)>", n)
+    if m:
+        return "igemm_kernel<%s,%s,%s,%s,%s>" % (*m.groups()[:4], "vec" if m.group(5) == "true" else "gen")
+    m = re.match(r"wgrad_kernel<\d+, \d+, \d+, \d+, (true|false)", n)
+    if m:
+        return "wgrad_kernel<%s>" % ("vec" if m.group(1) == "true" else "gen")
+    if n.startswith("wino_wgrad_kernel"):
+        return "wino_wgrad_kernel"
+    if n.startswith("wino_kernel"):
+        return "wino_kernel"
+    return None
+
+
+def counter(sub, name):
+    f = glob.glob(os.path.join(ev, sub, "*", "*counter_collection.csv"))
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        k = prof_name(r["Kernel_Name"])
+        if k and r["Counter_Name"] == name:
+            agg[k].append(float(r["Counter_Value"]))
+    return agg
+
+
+fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
+out = {"_doc": "Per-launch averages of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py "
+               "--steps 2 --warmup 1 --no-cpu-baseline`; hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (KB*1024): on gfx950 "
+               "FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact.",
+       "kernels": {}}
+for k in sorted(fetch):
+    f, w = sum(fetch[k]) / len(fetch[k]), sum(write[k]) / max(len(write[k]), 1)
+    out["kernels"][k] = {"launches": len(fetch[k]), "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
+                         "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+json.dump(out, open(os.path.join(root, "profiles", tag.split("_")[0] + "_pmc_traffic.json"), "w"), indent=1)
+stats = glob.glob(os.path.join(ev, "stats", "*", "*kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(root, "profiles", tag + "_bench_steps5_kernel_stats.csv"))
+for src, dst in (("bench_plain.json", tag + "_bench_steps5.json"), ("bench_under_rocprof.json", tag + "_bench_steps5_under_rocprof.json")):
+    p = os.path.join(ev, src)
+    if os.path.exists(p):
+        line = open(p).read().strip().splitlines()[-1]
+        json.loads(line)
+        open(os.path.join(root, "profiles", dst), "w").write(line + "\n")
+print("wrote profiles/", tag)
