@@ -40,8 +40,8 @@ static const char* const kProfNames[] = {
     "igemm_kernel<128,128,2,2,gen>", "igemm_kernel<128,128,2,2,vec>", "igemm_kernel<128,64,2,2,gen>", "igemm_kernel<128,64,2,2,vec>",
     "igemm_kernel<128,32,4,1,gen>",  "igemm_kernel<128,32,4,1,vec>",  "igemm_kernel<64,64,2,2,gen>",  "igemm_kernel<64,64,2,2,vec>",
     "wgrad_kernel<gen>", "wgrad_kernel<vec>", "igemm_kernel<256,128,4,2,gen>", "igemm_kernel<256,128,4,2,vec>",
-    "igemm_kernel<256,64,4,2,gen>", "igemm_kernel<256,64,4,2,vec>", "wino_kernel", "wino_wgrad_kernel"};
-constexpr int kProfKernels = 16;
+    "igemm_kernel<256,64,4,2,gen>", "igemm_kernel<256,64,4,2,vec>", "wino_kernel", "wino_wgrad_kernel", "wino_kernel<4x4s2>", "wino_wgrad_kernel<4x4s2>"};
+constexpr int kProfKernels = 18;
 
 struct ProfScope {
   bool on;
@@ -1027,8 +1027,8 @@ static FwdPath fwd_path(const srgan_conv_desc* d, int act) {
     if (dense_head_applicable(d)) return PATH_DENSE;
     if (narrow_wave_applicable(d)) return PATH_WAVE;
     if (narrow_applicable(d)) return PATH_NARROW;
-    if (wino_applicable(d, 0)) return PATH_WINO;
   }
+  if (wino_applicable(d, 0)) return PATH_WINO;      // bias / activation fused in its epilogue too
   return PATH_IGEMM;
 }
 
@@ -1070,7 +1070,7 @@ static int fwd_run(const srgan_conv_desc* d, const float* x, const float* wp, co
                    float slope, hipStream_t st) {
   const FwdPath path = fwd_path(d, act);
   if (path == PATH_NARROW) return narrow_fwd_packed(d, x, wp, bias, y, st);
-  if (path == PATH_WINO) return wino_run(d, 0, x, wp, bias, y, st);
+  if (path == PATH_WINO) return wino_run(d, 0, x, wp, bias, y, act, slope, st);
   IgemmParams p{};
   fwd_geometry(d, path, p);
   p.src = x; p.bias = bias; p.dst = y; p.act = act; p.slope = slope; p.wp = wp;
@@ -1154,7 +1154,7 @@ static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp,
     return narrow_fwd_packed(&f, dy, wp, nullptr, dx, st);
   }
   if (g.wino) {
-    if (int e = wino_run(d, 1, dy, wp, nullptr, g.p.dst, st)) return e;
+    if (int e = wino_run(d, 1, dy, wp, nullptr, g.p.dst, SRGAN_ACT_NONE, 0.f, st)) return e;
   } else if (int e = run_igemm(g.p, g.phases, st, conv_flops(d))) {
     return e;
   }

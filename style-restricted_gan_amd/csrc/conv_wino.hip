@@ -33,12 +33,25 @@ struct WinoParams {
   const float* u;     // [n_tiles][nchunk][16 pos][2 halves][64 couts][4 ch] transformed filters
   const float* bias;  // [Cd] or null
   float* dst;         // [NB][Ho][Wo][Cd]
-  int NB, H, W, C, Ho, Wo, Cd;
+  int NB, H, W, C, Ho, Wo, Cd;   // source tensor, destination tensor (Cd = its channels)
   int pad, reflect;
-  int TH, TW, T;      // tile grid per image, tiles in total
+  int TH, TW, T;      // tile grid per image (of the phase image in mode 2), tiles in total
   int nchunk, n_tiles, m_tiles;
+  int cpp;            // mode 1: chunks per input phase (C / 8)
+  int act;            // fused activation of the epilogue (SRGAN_ACT_*)
+  float slope;
 };
 
+// MODE 0: 3x3 stride-1 conv, F(2x2,3x3): 2x2 output tile from a 4x4 patch, Y = A^T M A.
+// MODE 1: 4x4 stride-2 pad-1 conv = sum over the 4 input phases I_pq[u][v] = in[2u+p-1][2v+q-1] of a 2x2 stride-1
+//         correlation; F(3x3,2x2) -- the transpose of F(2x2,3x3): 3x3 output tile from a 4x4 patch of the phase image,
+//         U = A g A^T, V = B^T d B, Y = G^T M G, 16 multiplies per 9 outputs instead of 36; the reduce index is
+//         (phase, channel), chunks are phase-major.
+// MODE 2: the transposed form (input gradient of MODE 1's conv / ConvTranspose2d forward): output phase (r,s) =
+//         blockIdx.y is a 2x2 stride-1 correlation over dy with taps w[3-2a-r][3-2b-s]; F(3x3,2x2) on the phase image,
+//         outputs scattered with pixel stride 2.
+
+template <int MODE>
 __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   // V image, double-buffered: [buf][16 pos][2 channel halves][64 tiles x 4 ch + 16 pad] (+32 pad per position).
   // A lane's MFMA fragment (4 channels of one tile) is one 16-B slot and a 16-lane read group covers 256 contiguous
@@ -50,7 +63,10 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   static_assert(2 * VSZ <= 32768, "V buffers must fit the epilogue image");
   __shared__ __attribute__((aligned(16))) float lds[32768];
   __shared__ int tile_o[WT];      // destination pixel index of the tile's (0,0) output, or -1
-  __shared__ int tile_f[WT];      // bit0: column 1 inside, bit1: row 1 inside
+  __shared__ int tile_f[WT];      // valid output rows | valid output columns << 4 (of the OT x OT tile)
+  constexpr int OT = MODE == 0 ? 2 : 3;            // output tile edge
+  constexpr int PS = MODE == 2 ? 2 : 1;            // pixel stride of the outputs in the destination
+  const int ph_r = MODE == 2 ? (int)blockIdx.y >> 1 : 0, ph_s = MODE == 2 ? (int)blockIdx.y & 1 : 0;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -66,24 +82,34 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   const int tl = tid >> 3, ch = tid & 7;
   constexpr unsigned kOutside = 0x80000000u;
   unsigned off[16];
+  int g_b, g_ty, g_tx;
+  bool g_tv;
   {
     const int t = m_tile * WT + tl;
-    const bool tv = t < p.T;
-    const int tt = tv ? t : 0;
+    g_tv = t < p.T;
+    const int tt = g_tv ? t : 0;
     const int per = p.TH * p.TW;
-    const int b = tt / per;
-    const int r = tt - b * per;
-    const int ty = r / p.TW, tx = r - ty * p.TW;
+    g_b = tt / per;
+    const int r = tt - g_b * per;
+    g_ty = r / p.TW; g_tx = r - g_ty * p.TW;
     if (ch == 0) {
-      const int oy = 2 * ty, ox = 2 * tx;
-      tile_o[tl] = tv ? (b * p.Ho + oy) * p.Wo + ox : -1;
-      tile_f[tl] = ((ox + 1 < p.Wo) ? 1 : 0) | ((oy + 1 < p.Ho) ? 2 : 0);
+      const int oy = PS * OT * g_ty + ph_r, ox = PS * OT * g_tx + ph_s;      // first output pixel of the tile
+      const int nr = min(OT, (p.Ho - oy + PS - 1) / PS), nc = min(OT, (p.Wo - ox + PS - 1) / PS);
+      tile_o[tl] = (g_tv && nr > 0 && nc > 0) ? (g_b * p.Ho + oy) * p.Wo + ox : -1;
+      tile_f[tl] = max(nr, 0) | (max(nc, 0) << 4);
     }
+  }
+  // patch element (i, j) of this thread's tile for input phase `phase` (MODE 1; ignored otherwise)
+  auto set_offsets = [&](int phase) {
+    int sy, dy_, oy0, ox0;
+    if (MODE == 0) { sy = 2; dy_ = 1; oy0 = -p.pad; ox0 = -p.pad; }
+    else if (MODE == 1) { sy = 6; dy_ = 2; oy0 = (phase >> 1) - p.pad; ox0 = (phase & 1) - p.pad; }
+    else { sy = 3; dy_ = 1; oy0 = ph_r - 1; ox0 = ph_s - 1; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int iy = 2 * ty - p.pad + i;
-      bool yok = tv;
-      if (p.reflect) {
+      int iy = sy * g_ty + dy_ * i + oy0;
+      bool yok = g_tv;
+      if (MODE == 0 && p.reflect) {
         iy = iy < 0 ? -iy : iy;
         iy = iy >= p.H ? 2 * p.H - 2 - iy : iy;
         iy = min(max(iy, 0), p.H - 1);
@@ -92,34 +118,43 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int ix = 2 * tx - p.pad + j;
+        int ix = sy * g_tx + dy_ * j + ox0;
         bool ok = yok;
-        if (p.reflect) {
+        if (MODE == 0 && p.reflect) {
           ix = ix < 0 ? -ix : ix;
           ix = ix >= p.W ? 2 * p.W - 2 - ix : ix;
           ix = min(max(ix, 0), p.W - 1);
         } else {
           ok = ok && (unsigned)ix < (unsigned)p.W;
         }
-        off[i * 4 + j] = ok ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.C + ch) * 4u : kOutside;
+        off[i * 4 + j] = ok ? (unsigned)(((g_b * p.H + iy) * p.W + ix) * p.C + ch) * 4u : kOutside;
       }
     }
-  }
+  };
+  set_offsets(0);
   // descriptors from wave-uniform values only; the per-chunk advance goes into the scalar offset
   const unsigned src_bytes = (unsigned)((size_t)p.NB * p.H * p.W * p.C * 4);
   const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, src_bytes, 0x00020000);
-  const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u) + (size_t)n_tile * p.nchunk * 8192, 0,
-                                                       (unsigned)p.nchunk * 32768u, 0x00020000);
+  const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.u) + ((size_t)(MODE == 2 ? blockIdx.y : 0) * p.n_tiles + n_tile) * p.nchunk * 8192, 0,
+      (unsigned)p.nchunk * 32768u, 0x00020000);
   // this lane's fragment of U inside a chunk image [16 pos][2 halves][64 couts][4]: position 2*wave + slot, column
   // tile j -> byte offset ubase + slot * 2048 + j * 512
   const unsigned ubase = (unsigned)((2 * wave) * 512 + lh * 256 + lr * 4) * 4u;
 
   float d[16];
   f32x4 bfr[2][2][2];      // [chunk parity][slot = position within the wave][column tile]
-  auto load_x = [&](int kc) {
+  int lc8 = 0, lphase = 0;      // load cursor: chunks are consumed strictly in order
+  auto load_x = [&]() {
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off[i], kc * (WC * 4), 0));
+      d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off[i], lc8 * (WC * 4), 0));
+    ++lc8;
+    if (MODE == 1 && lc8 == p.cpp) {      // next input phase: new patch origin and padding mask (wave-uniform, 3x per kernel)
+      lc8 = 0;
+      ++lphase;
+      set_offsets(lphase);
+    }
   };
   auto load_u = [&](int kc, auto par) {
     constexpr int P = decltype(par)::value;
@@ -191,12 +226,12 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   using F = std::false_type;
   const int cls = wave >> 2;
   const int nk = p.nchunk;
-  load_x(0);
+  load_x();
   load_u(0, I0{});
   store_v(0);
   __syncthreads();
   read_frags(0, 0);
-  if (nk > 1) load_x(1);
+  if (nk > 1) load_x();
   auto iter = [&](int kc, auto c1, auto par, auto st, auto ld) {
     constexpr bool C1 = decltype(c1)::value, ST = decltype(st)::value, LD = decltype(ld)::value;
     constexpr int P = decltype(par)::value;
@@ -208,7 +243,7 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
       if constexpr (ST) {
         load_u(kc + 1, NP{});              // fragments of chunk kc+1: wanted at the top of the next iteration
         store_v(1 - P);                    // chunk kc+1: its loads were issued a whole chunk ago
-        if constexpr (LD) load_x(kc + 2);
+        if constexpr (LD) load_x();
         __builtin_amdgcn_sched_barrier(0);
       }
       mfma_steps(par, 0, 0, 4);
@@ -218,7 +253,7 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
         __builtin_amdgcn_sched_barrier(0);
         load_u(kc + 1, NP{});
         store_v(1 - P);
-        if constexpr (LD) load_x(kc + 2);
+        if constexpr (LD) load_x();
         __builtin_amdgcn_sched_barrier(0);
       }
       mfma_steps(par, 0, 2, 4);
@@ -241,7 +276,7 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   };
   if (cls == 0) run(F{}); else run(T{});
 
-  // ---- epilogue: A^T M A, two halves of 32 output channels ----
+  // ---- epilogue: output transform (A^T M A: 2x2, or G^T M G: 3x3), two halves of 32 output channels ----
   const int cl = tid & 31, tg = tid >> 5;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -265,23 +300,40 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
       float m[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) m[k] = lds[k * 2048 + tile * 32 + cl];
-      float s0[4], s1[4];
+      float y[OT][OT];
+      if constexpr (MODE == 0) {
+        float s0[4], s1[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        s0[c] = m[0 * 4 + c] + m[1 * 4 + c] + m[2 * 4 + c];
-        s1[c] = m[1 * 4 + c] - m[2 * 4 + c] - m[3 * 4 + c];
+        for (int c = 0; c < 4; ++c) {
+          s0[c] = m[0 * 4 + c] + m[1 * 4 + c] + m[2 * 4 + c];
+          s1[c] = m[1 * 4 + c] - m[2 * 4 + c] - m[3 * 4 + c];
+        }
+        y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s0[1] - s0[2] - s0[3];
+        y[1][0] = s1[0] + s1[1] + s1[2]; y[1][1] = s1[1] - s1[2] - s1[3];
+      } else {
+        float h[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          h[0][c] = m[0 * 4 + c] + 0.5f * (m[1 * 4 + c] + m[2 * 4 + c]);
+          h[1][c] = 0.5f * (m[1 * 4 + c] - m[2 * 4 + c]);
+          h[2][c] = 0.5f * (m[1 * 4 + c] + m[2 * 4 + c]) + m[3 * 4 + c];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          y[a][0] = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
+          y[a][1] = 0.5f * (h[a][1] - h[a][2]);
+          y[a][2] = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
+        }
       }
-      const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
-      const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
       const int o = tile_o[tile], f = tile_f[tile];
       if (nok && o >= 0) {
+        const int nr = f & 15, nc = f >> 4;
         float* dp = p.dst + (size_t)o * p.Cd + n;
-        dp[0] = y00;
-        if (f & 1) dp[p.Cd] = y01;
-        if (f & 2) {
-          dp[(size_t)p.Wo * p.Cd] = y10;
-          if (f & 1) dp[(size_t)(p.Wo + 1) * p.Cd] = y11;
-        }
+#pragma unroll
+        for (int a = 0; a < OT; ++a)
+#pragma unroll
+          for (int b = 0; b < OT; ++b)
+            if (a < nr && b < nc) dp[(size_t)(a * p.Wo + b) * PS * p.Cd] = apply_act(y[a][b] + bv, p.act, p.slope);
       }
     }
   }
@@ -538,126 +590,210 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
   }
 }
 
-// ---- filter transform: U[n_tile][chunk][pos][c/4][64][c%4] = (G g G^T)[pos], one thread per (n, c) pair ----
-// kind 0 (forward): g = w[n][c][ky][kx];  kind 1 (input gradient): g = w[c][n][2-ky][2-kx]
+// ---- filter transform: U[(out phase)][n_tile][chunk][pos][c/4][64][c%4], one thread per (n, k) pair ----
+// variant 1, F(2x2,3x3):  U = G g G^T;  kind 0 (forward): g = w[n][c][ky][kx];  kind 1 (input gradient): g = w[c][n][2-ky][2-kx]
+// variant 2, F(3x3,2x2):  U = A g A^T;  kind 0 (4x4 stride-2 conv): reduce index k = (input phase pq, c),
+//   g[a][b] = w[n][c][2a+p][2b+q];  kind 1 (its transpose): one image per OUTPUT phase rs, g[a][b] = w[c][n][3-2a-r][3-2b-s]
 struct WinoPackParams {
   const float* w;
   float* dst;
   long long sO, sI, sH, sW;
-  int N, C, kind, nchunk, n_tiles;
+  int N, C, kind, nchunk, n_tiles, variant, phases;
 };
 
 __global__ void wino_pack_kernel(WinoPackParams p) {
-  const long long total = (long long)p.n_tiles * WNB * p.nchunk * WC;
+  const long long per_phase = (long long)p.n_tiles * WNB * p.nchunk * WC;
+  const long long total = per_phase * p.phases;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int cc = (int)(idx % WC);
     long long r = idx / WC;
     const int nl = (int)(r % WNB); r /= WNB;
-    const int chunk = (int)(r % p.nchunk);
-    const int ntile = (int)(r / p.nchunk);
-    const int n = ntile * WNB + nl, c = chunk * WC + cc;
-    float g[3][3];
-    const bool ok = n < p.N && c < p.C;
+    const int chunk = (int)(r % p.nchunk); r /= p.nchunk;
+    const int ntile = (int)(r % p.n_tiles);
+    const int ophase = (int)(r / p.n_tiles);
+    const int n = ntile * WNB + nl;
+    float u[4][4];
+    if (p.variant == 1) {
+      const int c = chunk * WC + cc;
+      float g[3][3];
+      const bool ok = n < p.N && c < p.C;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          float v = 0.f;
+          if (ok) v = p.kind == 0 ? p.w[n * p.sO + c * p.sI + ky * p.sH + kx * p.sW]
+                                  : p.w[c * p.sO + n * p.sI + (2 - ky) * p.sH + (2 - kx) * p.sW];
+          g[ky][kx] = v;
+        }
+      // G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+      float h[4][3];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        float v = 0.f;
-        if (ok) v = p.kind == 0 ? p.w[n * p.sO + c * p.sI + ky * p.sH + kx * p.sW]
-                                : p.w[c * p.sO + n * p.sI + (2 - ky) * p.sH + (2 - kx) * p.sW];
-        g[ky][kx] = v;
+        h[0][kx] = g[0][kx];
+        h[1][kx] = 0.5f * (g[0][kx] + g[1][kx] + g[2][kx]);
+        h[2][kx] = 0.5f * (g[0][kx] - g[1][kx] + g[2][kx]);
+        h[3][kx] = g[2][kx];
       }
-    // rows: G g  (4x3), G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
-    float h[4][3];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      h[0][kx] = g[0][kx];
-      h[1][kx] = 0.5f * (g[0][kx] + g[1][kx] + g[2][kx]);
-      h[2][kx] = 0.5f * (g[0][kx] - g[1][kx] + g[2][kx]);
-      h[3][kx] = g[2][kx];
-    }
-    // within a position: [channel half][cout][4 channels] -- the LDS image of the kernel, copied linearly
-    float* out = p.dst + (((size_t)ntile * p.nchunk + chunk) * 16) * (WNB * WC) + (cc >> 2) * (WNB * 4) + nl * 4 + (cc & 3);
+      for (int a = 0; a < 4; ++a) {
+        u[a][0] = h[a][0];
+        u[a][1] = 0.5f * (h[a][0] + h[a][1] + h[a][2]);
+        u[a][2] = 0.5f * (h[a][0] - h[a][1] + h[a][2]);
+        u[a][3] = h[a][2];
+      }
+    } else {
+      const int k = chunk * WC + cc;
+      int c, pp, qq;
+      if (p.kind == 0) { const int ph = k / p.C; c = k - ph * p.C; pp = ph >> 1; qq = ph & 1; }
+      else { c = k; pp = ophase >> 1; qq = ophase & 1; }
+      const bool ok = n < p.N && c < p.C && (p.kind == 1 || k < 4 * p.C);
+      float g[2][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      out[(a * 4 + 0) * (WNB * WC)] = h[a][0];
-      out[(a * 4 + 1) * (WNB * WC)] = 0.5f * (h[a][0] + h[a][1] + h[a][2]);
-      out[(a * 4 + 2) * (WNB * WC)] = 0.5f * (h[a][0] - h[a][1] + h[a][2]);
-      out[(a * 4 + 3) * (WNB * WC)] = h[a][2];
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float v = 0.f;
+          if (ok) v = p.kind == 0 ? p.w[n * p.sO + c * p.sI + (2 * a + pp) * p.sH + (2 * b + qq) * p.sW]
+                                  : p.w[c * p.sO + n * p.sI + (3 - 2 * a - pp) * p.sH + (3 - 2 * b - qq) * p.sW];
+          g[a][b] = v;
+        }
+      // A g A^T, A = [1 0; 1 1; 1 -1; 0 -1]
+      float h[4][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        h[0][b] = g[0][b];
+        h[1][b] = g[0][b] + g[1][b];
+        h[2][b] = g[0][b] - g[1][b];
+        h[3][b] = -g[1][b];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        u[a][0] = h[a][0];
+        u[a][1] = h[a][0] + h[a][1];
+        u[a][2] = h[a][0] - h[a][1];
+        u[a][3] = -h[a][1];
+      }
     }
+    // within a position: [channel half][cout][4 channels] -- the register image of the kernel
+    float* out = p.dst + ((((size_t)ophase * p.n_tiles + ntile) * p.nchunk + chunk) * 16) * (WNB * WC) + (cc >> 2) * (WNB * 4) +
+                 nl * 4 + (cc & 3);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) out[(a * 4 + b) * (WNB * WC)] = u[a][b];
   }
 }
 
+static double conv_flops_of(const srgan_conv_desc* d) {
+  return 2.0 * d->N * d->Ho * d->Wo * (double)d->O * d->kh * d->kw * d->I;
+}
+
 // ---- host side ----
-// kind 0: y = conv(x, w) ; kind 1: dx = conv(dy, flipped w^T) with pad' = 2 - pad (zero pad) or the full
+// variant 1: kind 0: y = conv(x, w); kind 1: dx = conv(dy, flipped w^T) with pad' = 2 - pad (zero pad) or the full
 // correlation onto the reflect-padded image (pad' = 2, output Hi+2p), folded by the caller.
+// variant 2: kind 0: the 4x4 stride-2 conv (MODE 1); kind 1: its input gradient / the transposed conv (MODE 2).
 static bool wino_disabled() {
   static const bool off = std::getenv("SRGAN_NO_WINOGRAD") != nullptr;
   return off;
 }
-
-bool wino_applicable(const srgan_conv_desc* d, int kind) {
-  if (wino_disabled()) return false;
-  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return false;
-  const int C = kind == 0 ? d->I : d->O, N = kind == 0 ? d->O : d->I;
-  if (C % (2 * WC) != 0 || C < 32 || N < 32) return false;   // an even number of 8-channel chunks
-  if (d->Hi < 3 || d->Wi < 3) return false;
-  // the gather's "outside" offset (2 GiB) must lie past the end of the source tensor
-  const long long src_elems = (long long)d->N * (kind == 0 ? (long long)d->Hi * d->Wi * d->I : (long long)d->Ho * d->Wo * d->O);
-  if (src_elems >= (1LL << 29)) return false;
-  return true;
+static bool wino_s2_disabled() {
+  static const bool off = std::getenv("SRGAN_NO_WINOGRAD_S2") != nullptr;
+  return off;
 }
 
-static void wino_dims(const srgan_conv_desc* d, int kind, int* C, int* N, int* n_tiles, int* nchunk) {
+// 0: none, 1: F(2x2,3x3) on a 3x3 stride-1 pad-1 layer, 2: F(3x3,2x2) on a 4x4 stride-2 pad-1 layer
+static int wino_variant(const srgan_conv_desc* d, int kind) {
+  if (wino_disabled()) return 0;
+  const int C = kind == 0 ? d->I : d->O, N = kind == 0 ? d->O : d->I;
+  if (C % (2 * WC) != 0 || C < 32 || N < 32) return 0;   // an even number of 8-channel chunks
+  // the gather's "outside" offset (2 GiB) must lie past the end of the source tensor
+  const long long src_elems = (long long)d->N * (kind == 0 ? (long long)d->Hi * d->Wi * d->I : (long long)d->Ho * d->Wo * d->O);
+  if (src_elems >= (1LL << 29)) return 0;
+  if (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1) return (d->Hi >= 3 && d->Wi >= 3) ? 1 : 0;
+  if (d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 1 && d->pad_mode == SRGAN_PAD_ZERO && !wino_s2_disabled()) {
+    if ((d->Hi & 1) || (d->Wi & 1)) return 0;
+    // 3x3 output tiles over Ho x Wo (= the phase image of the transposed form): skip maps the tiling wastes
+    const long long th = ceil_div(d->Ho, 3), tw = ceil_div(d->Wo, 3);
+    const double eff = (double)d->Ho * d->Wo / (9.0 * th * tw);
+    if (eff * 2.25 < 1.5) return 0;
+    // one workgroup per CU: below ~0.8 of a device round the long (4 C / 8 chunk) K loop loses to the implicit GEMM
+    const long long blocks = ceil_div((long long)d->N * th * tw, WT) * ceil_div(N, WNB) * (kind == 1 ? 4 : 1);
+    return blocks >= 200 ? 2 : 0;
+  }
+  return 0;
+}
+
+bool wino_applicable(const srgan_conv_desc* d, int kind) { return wino_variant(d, kind) != 0; }
+
+static void wino_dims(const srgan_conv_desc* d, int kind, int* C, int* N, int* n_tiles, int* nchunk, int* phases) {
+  const int v = wino_variant(d, kind);
   *C = kind == 0 ? d->I : d->O;
   *N = kind == 0 ? d->O : d->I;
   *n_tiles = (int)ceil_div(*N, WNB);
-  *nchunk = *C / WC;
+  *nchunk = (v == 2 && kind == 0 ? 4 : 1) * (*C / WC);      // MODE 1 reduces over (input phase, channel)
+  *phases = (v == 2 && kind == 1) ? 4 : 1;                  // MODE 2: one filter image per output phase
 }
 
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind) {
-  int C, N, n_tiles, nchunk;
-  wino_dims(d, kind, &C, &N, &n_tiles, &nchunk);
-  return (size_t)n_tiles * nchunk * 8192 * sizeof(float);
+  int C, N, n_tiles, nchunk, phases;
+  wino_dims(d, kind, &C, &N, &n_tiles, &nchunk, &phases);
+  return (size_t)phases * n_tiles * nchunk * 8192 * sizeof(float);
 }
 
 int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hipStream_t st) {
   WinoPackParams q{};
   int C, N;
-  wino_dims(d, kind, &C, &N, &q.n_tiles, &q.nchunk);
+  wino_dims(d, kind, &C, &N, &q.n_tiles, &q.nchunk, &q.phases);
+  q.variant = wino_variant(d, kind);
   q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW; q.N = N; q.C = C; q.kind = kind;
-  const long long total = (long long)q.n_tiles * WNB * q.nchunk * WC;
+  const long long total = (long long)q.phases * q.n_tiles * WNB * q.nchunk * WC;
   hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
   return check_launch("wino_pack_kernel");
 }
 
 // dst geometry: kind 0 -> [N][Ho][Wo][O]; kind 1 -> [N][Hd][Wd][I] with Hd = Hi (zero pad) or Hi + 2 (reflect scratch)
 int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst,
-             hipStream_t st) {
+             int act, float slope, hipStream_t st) {
   WinoParams p{};
-  int C, N;
-  wino_dims(d, kind, &C, &N, &p.n_tiles, &p.nchunk);
+  p.act = act; p.slope = slope;
+  int C, N, phases;
+  wino_dims(d, kind, &C, &N, &p.n_tiles, &p.nchunk, &phases);
+  const int variant = wino_variant(d, kind);
+  SRGAN_REQUIRE(variant != 0, "winograd: layer not applicable");
   const bool reflect = d->pad_mode == SRGAN_PAD_REFLECT;
   p.src = src; p.u = packed; p.bias = bias; p.dst = dst;
-  p.NB = d->N; p.C = C; p.Cd = N;
-  if (kind == 0) {
-    p.H = d->Hi; p.W = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo; p.pad = d->pad; p.reflect = reflect ? 1 : 0;
+  p.NB = d->N; p.C = C; p.Cd = N; p.cpp = C / WC;
+  int ot = 2;
+  if (variant == 1) {
+    if (kind == 0) {
+      p.H = d->Hi; p.W = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo; p.pad = d->pad; p.reflect = reflect ? 1 : 0;
+    } else {
+      p.H = d->Ho; p.W = d->Wo; p.reflect = 0;
+      p.pad = reflect ? 2 : 2 - d->pad;
+      p.Ho = d->Ho + 2 * p.pad - 2; p.Wo = d->Wo + 2 * p.pad - 2;
+    }
+    p.TH = (p.Ho + 1) / 2; p.TW = (p.Wo + 1) / 2;
   } else {
-    p.H = d->Ho; p.W = d->Wo; p.reflect = 0;
-    p.pad = reflect ? 2 : 2 - d->pad;
-    p.Ho = d->Ho + 2 * p.pad - 2; p.Wo = d->Wo + 2 * p.pad - 2;
+    ot = 3;
+    p.pad = d->pad; p.reflect = 0;
+    if (kind == 0) { p.H = d->Hi; p.W = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo; }
+    else { p.H = d->Ho; p.W = d->Wo; p.Ho = d->Hi; p.Wo = d->Wi; }
+    p.TH = (int)ceil_div(d->Ho, 3); p.TW = (int)ceil_div(d->Wo, 3);      // tiles over Ho x Wo (kind 1: the phase image)
   }
-  p.TH = (p.Ho + 1) / 2; p.TW = (p.Wo + 1) / 2;
+  (void)ot;
   const long long T = (long long)p.NB * p.TH * p.TW;
   SRGAN_REQUIRE(T < (1LL << 30), "winograd: too many tiles");
   p.T = (int)T;
   p.m_tiles = (int)ceil_div(T, WT);
   const long long grid = (long long)p.m_tiles * p.n_tiles;
   SRGAN_REQUIRE(grid < (1LL << 31), "winograd: grid too large");
-  // ALGORITHMIC FLOPs of the direct convolution; the kernel issues 2.25x fewer on the matrix pipe
-  ProfToken tok = prof_begin(14, 2.0 * 9.0 * (double)p.NB * p.Ho * p.Wo * C * N, st);
-  hipLaunchKernelGGL(wino_kernel, dim3((unsigned)grid), dim3(512), 0, st, p);
+  // ALGORITHMIC FLOPs of the direct convolution; the kernel issues ~2.25x fewer on the matrix pipe
+  ProfToken tok = prof_begin(variant == 1 ? 14 : 16, conv_flops_of(d), st);
+  if (variant == 1) hipLaunchKernelGGL(wino_kernel<0>, dim3((unsigned)grid), dim3(512), 0, st, p);
+  else if (kind == 0) hipLaunchKernelGGL(wino_kernel<1>, dim3((unsigned)grid), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL(wino_kernel<2>, dim3((unsigned)grid, 4), dim3(512), 0, st, p);
   prof_end(tok, st);
   return check_launch("wino_kernel");
 }
