@@ -28,6 +28,15 @@ constexpr int WT = 64;   // output tiles per workgroup
 constexpr int WNB = 64;  // output channels per workgroup
 constexpr int WC = 8;    // reduce channels per chunk
 
+// A buffer descriptor whose words are provably wave-uniform (readfirstlane of the base halves and the byte count):
+// otherwise the compiler may keep it in VGPRs and wrap every buffer load in a readfirstlane "waterfall" loop.
+__device__ __forceinline__ auto uniform_rsrc(const float* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  float* q = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 struct WinoParams {
   const float* src;   // [NB][H][W][C]
   const float* u;     // [n_tiles][nchunk][16 pos][2 halves][64 couts][4 ch] transformed filters
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
     }
   }
   // patch element (i, j) of this thread's tile for input phase `phase` (MODE 1; ignored otherwise)
-  auto set_offsets = [&](int phase) {
+  auto set_offsets = [&](int phase) __attribute__((always_inline)) {
     int sy, dy_, oy0, ox0;
     if (MODE == 0) { sy = 2; dy_ = 1; oy0 = -p.pad; ox0 = -p.pad; }
     else if (MODE == 1) { sy = 6; dy_ = 2; oy0 = (phase >> 1) - p.pad; ox0 = (phase & 1) - p.pad; }
@@ -134,10 +143,9 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   set_offsets(0);
   // descriptors from wave-uniform values only; the per-chunk advance goes into the scalar offset
   const unsigned src_bytes = (unsigned)((size_t)p.NB * p.H * p.W * p.C * 4);
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, src_bytes, 0x00020000);
-  const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.u) + ((size_t)(MODE == 2 ? blockIdx.y : 0) * p.n_tiles + n_tile) * p.nchunk * 8192, 0,
-      (unsigned)p.nchunk * 32768u, 0x00020000);
+  const auto rs_x = uniform_rsrc(p.src, src_bytes);
+  const auto rs_u = uniform_rsrc(p.u + ((size_t)(MODE == 2 ? blockIdx.y : 0) * p.n_tiles + n_tile) * p.nchunk * 8192,
+                                 (unsigned)p.nchunk * 32768u);
   // this lane's fragment of U inside a chunk image [16 pos][2 halves][64 couts][4]: position 2*wave + slot, column
   // tile j -> byte offset ubase + slot * 2048 + j * 512
   const unsigned ubase = (unsigned)((2 * wave) * 512 + lh * 256 + lr * 4) * 4u;
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   float d[16];
   f32x4 bfr[2][2][2];      // [chunk parity][slot = position within the wave][column tile]
   int lc8 = 0, lphase = 0;      // load cursor: chunks are consumed strictly in order
-  auto load_x = [&]() {
+  auto load_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 16; ++i)
       d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off[i], lc8 * (WC * 4), 0));
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
       set_offsets(lphase);
     }
   };
-  auto load_u = [&](int kc, auto par) {
+  auto load_u = [&](int kc, auto par) __attribute__((always_inline)) {
     constexpr int P = decltype(par)::value;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
         bfr[P][a][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ubase + a * 2048 + j * 512, kc * 32768, 0));
   };
   // B^T d B in registers, 16 results to V[pos][half][tile][ch & 3]
-  auto store_v = [&](int buf) {
+  auto store_v = [&](int buf) __attribute__((always_inline)) {
 #if WINO_EXP == 4
     return;
 #endif
@@ -199,12 +207,12 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
         for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.f;
 
   f32x4 af[2][2];   // [slot][row tile]
-  auto read_frags = [&](int buf, int slot) {
+  auto read_frags = [&](int buf, int slot) __attribute__((always_inline)) {
     const float* V = lds + buf * VSZ + (2 * wave + slot) * VP + lh * VH;
 #pragma unroll
     for (int i = 0; i < 2; ++i) af[slot][i] = *reinterpret_cast<const f32x4*>(V + (i * 32 + lr) * 4);
   };
-  auto mfma_steps = [&](auto par, int slot, int e0, int e1) {
+  auto mfma_steps = [&](auto par, int slot, int e0, int e1) __attribute__((always_inline)) {
     constexpr int P = decltype(par)::value;
 #pragma unroll
     for (int e = e0; e < e1; ++e)
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   __syncthreads();
   read_frags(0, 0);
   if (nk > 1) load_x();
-  auto iter = [&](int kc, auto c1, auto par, auto st, auto ld) {
+  auto iter = [&](int kc, auto c1, auto par, auto st, auto ld) __attribute__((always_inline)) {
     constexpr bool C1 = decltype(c1)::value, ST = decltype(st)::value, LD = decltype(ld)::value;
     constexpr int P = decltype(par)::value;
     using NP = std::integral_constant<int, 1 - P>;
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
     if constexpr (ST) read_frags(1 - P, 0);
     mfma_steps(par, 1, 2, 4);
   };
-  auto run = [&](auto c1) {
+  auto run = [&](auto c1) __attribute__((always_inline)) {
     int kc = 0;
     for (; kc + 3 < nk; kc += 2) {
       iter(kc, c1, I0{}, T{}, T{});
@@ -360,6 +368,11 @@ struct WinoWgradParams {
   int o_tiles, i_tiles, Opad;
 };
 
+// MODE 0: 3x3 stride-1 layer (above).  MODE 1: 4x4 stride-2 pad-1 layer, the transpose of wino_kernel<1>:
+//   dU[pos][o][(pq, c)] = sum_tiles (G dY G^T)[pos] * (B^T d_pq B)[pos] with dY the 3x3 output-gradient tile and d_pq the
+//   4x4 patch of input phase pq; dW[o][c][2a+p][2b+q] = (A^T dU_pq A)[a][b].  The 64-wide column tile of a workgroup
+//   lies inside one input phase (C % 64 == 0).
+template <int MODE>
 __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
   // [buf][ Z: 16 pos x 2 tile halves x 64 o x 4 tiles | V: same with 64 i ] = 2 x 64 KB, reused by the epilogue
   __shared__ __attribute__((aligned(16))) float lds[32768];
@@ -373,17 +386,23 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
   // gather role: tile of the chunk = 4 * (wave >> 2) + (lane & 3), channel = 16 * (wave & 3) + (lane >> 2)
   const int th = wave >> 2, tq = lane & 3;
   const int chl = (wave & 3) * 16 + (lane >> 2);
-  const int ci = i_tile * 64 + chl, co = o_tile * 64 + chl;
+  constexpr int ND = MODE == 0 ? 4 : 9;            // output-gradient elements per tile (2x2 or 3x3)
+  constexpr int OT = MODE == 0 ? 2 : 3;
+  const int phase = MODE == 1 ? (i_tile * 64) / p.C : 0;                  // input phase of this column tile
+  const int ph_p = phase >> 1, ph_q = phase & 1;
+  const int ci = i_tile * 64 - phase * p.C + chl, co = o_tile * 64 + chl;
   constexpr unsigned kOutside = 0x80000000u;
-  unsigned offx[16], offd[4];
-  auto set_group = [&](int g) {       // offsets of this thread's tile at tile-position group g (image 0)
+  unsigned offx[16], offd[ND];
+  auto set_group = [&](int g) __attribute__((always_inline)) {       // offsets of this thread's tile at tile-position group g (image 0)
     const int q = g * 8 + th * 4 + tq;
     const bool tv = q < p.TH * p.TW && g < p.groups;
     const int qq = tv ? q : 0;
     const int ty = qq / p.TW, tx = qq - ty * p.TW;
+    const int sy = MODE == 0 ? 2 : 6, dstep = MODE == 0 ? 1 : 2;
+    const int oy0 = (MODE == 0 ? 0 : ph_p) - p.pad, ox0 = (MODE == 0 ? 0 : ph_q) - p.pad;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int iy = 2 * ty - p.pad + i;
+      int iy = sy * ty + dstep * i + oy0;
       bool yok = tv && ci < p.C;
       if (p.reflect) {
         iy = iy < 0 ? -iy : iy;
@@ -394,7 +413,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int ix = 2 * tx - p.pad + j;
+        int ix = sy * tx + dstep * j + ox0;
         bool ok = yok;
         if (p.reflect) {
           ix = ix < 0 ? -ix : ix;
@@ -407,17 +426,17 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < OT; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int oy = 2 * ty + i, ox = 2 * tx + j;
+      for (int j = 0; j < OT; ++j) {
+        const int oy = OT * ty + i, ox = OT * tx + j;
         const bool ok = tv && co < p.O && oy < p.Ho && ox < p.Wo;
-        offd[i * 2 + j] = ok ? (unsigned)((oy * p.Wo + ox) * p.O + co) * 4u : kOutside;
+        offd[i * OT + j] = ok ? (unsigned)((oy * p.Wo + ox) * p.O + co) * 4u : kOutside;
       }
   };
   const unsigned x_img = (unsigned)(p.H * p.W * p.C) * 4u, d_img = (unsigned)(p.Ho * p.Wo * p.O) * 4u;
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, x_img * (unsigned)p.NB, 0x00020000);
-  const auto rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, d_img * (unsigned)p.NB, 0x00020000);
+  const auto rs_x = uniform_rsrc(p.x, x_img * (unsigned)p.NB);
+  const auto rs_d = uniform_rsrc(p.dy, d_img * (unsigned)p.NB);
 
   // load cursor (two chunks ahead of the multiply): group lg, image lb
   const int g0 = split * p.groups_per_split;
@@ -425,13 +444,13 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
   const int nk = max(g1 - g0, 0) * p.NB;
   int lg = g0, lb = 0;
   set_group(lg);
-  float dx[16], dd[4];
-  auto load_chunk = [&]() {
+  float dx[16], dd[ND];
+  auto load_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 16; ++i)
       dx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, offx[i], lb * x_img, 0));
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < ND; ++i)
       dd[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, offd[i], lb * d_img, 0));
     if (++lb == p.NB) {      // next tile-position group (wave-uniform, once per NB chunks)
       lb = 0;
@@ -440,7 +459,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
     }
   };
   const int wofs = th * 256 + (wave & 3) * 64 + lane;     // [half][channel][tile & 3], lane-linear
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf) __attribute__((always_inline)) {
     float* Z = lds + buf * 16384 + wofs;
     float* V = Z + 8192;
     float t[16];
@@ -458,18 +477,37 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
       V[(r * 4 + 2) * 512] = t[r * 4 + 2] - t[r * 4 + 1];
       V[(r * 4 + 3) * 512] = t[r * 4 + 1] - t[r * 4 + 3];
     }
-    // A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
-    const float r0[2] = {dd[0], dd[1]};
-    const float r1[2] = {dd[0] + dd[2], dd[1] + dd[3]};
-    const float r2[2] = {dd[0] - dd[2], dd[1] - dd[3]};
-    const float r3[2] = {-dd[2], -dd[3]};
-    const float* rr[4] = {r0, r1, r2, r3};
+    if constexpr (MODE == 0) {
+      // A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
+      const float r0[2] = {dd[0], dd[1]};
+      const float r1[2] = {dd[0] + dd[2], dd[1] + dd[3]};
+      const float r2[2] = {dd[0] - dd[2], dd[1] - dd[3]};
+      const float r3[2] = {-dd[2], -dd[3]};
+      const float* rr[4] = {r0, r1, r2, r3};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      Z[(r * 4 + 0) * 512] = rr[r][0];
-      Z[(r * 4 + 1) * 512] = rr[r][0] + rr[r][1];
-      Z[(r * 4 + 2) * 512] = rr[r][0] - rr[r][1];
-      Z[(r * 4 + 3) * 512] = -rr[r][1];
+      for (int r = 0; r < 4; ++r) {
+        Z[(r * 4 + 0) * 512] = rr[r][0];
+        Z[(r * 4 + 1) * 512] = rr[r][0] + rr[r][1];
+        Z[(r * 4 + 2) * 512] = rr[r][0] - rr[r][1];
+        Z[(r * 4 + 3) * 512] = -rr[r][1];
+      }
+    } else {
+      // G dY G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+      float zr[4][3];
+#pragma unroll
+      for (int l = 0; l < 3; ++l) {
+        zr[0][l] = dd[0 * 3 + l];
+        zr[1][l] = 0.5f * (dd[0 * 3 + l] + dd[1 * 3 + l] + dd[2 * 3 + l]);
+        zr[2][l] = 0.5f * (dd[0 * 3 + l] - dd[1 * 3 + l] + dd[2 * 3 + l]);
+        zr[3][l] = dd[2 * 3 + l];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Z[(r * 4 + 0) * 512] = zr[r][0];
+        Z[(r * 4 + 1) * 512] = 0.5f * (zr[r][0] + zr[r][1] + zr[r][2]);
+        Z[(r * 4 + 2) * 512] = 0.5f * (zr[r][0] - zr[r][1] + zr[r][2]);
+        Z[(r * 4 + 3) * 512] = zr[r][2];
+      }
     }
   };
 
@@ -483,7 +521,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.f;
   f32x4 af[2][2], bf[2][2];
-  auto read_frags = [&](int buf, int slot) {
+  auto read_frags = [&](int buf, int slot) __attribute__((always_inline)) {
     const float* Z = lds + buf * 16384 + (2 * wave + slot) * 512 + lh * 256;
     const float* V = Z + 8192;
 #pragma unroll
@@ -491,7 +529,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) bf[slot][j] = *reinterpret_cast<const f32x4*>(V + (j * 32 + lr) * 4);
   };
-  auto mfma_steps = [&](int slot, int e0, int e1) {
+  auto mfma_steps = [&](int slot, int e0, int e1) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = e0; e < e1; ++e)
 #pragma unroll
@@ -510,7 +548,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
     __syncthreads();
     read_frags(0, 0);
     if (nk > 1) load_chunk();
-    auto iter = [&](int kc, auto c1, auto st, auto ld) {
+    auto iter = [&](int kc, auto c1, auto st, auto ld) __attribute__((always_inline)) {
       constexpr bool C1 = decltype(c1)::value, ST = decltype(st)::value, LD = decltype(ld)::value;
       const int cur = kc & 1;
       read_frags(cur, 1);
@@ -537,7 +575,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
       if constexpr (ST) read_frags(cur ^ 1, 0);
       mfma_steps(1, 2, 4);
     };
-    auto run = [&](auto c1) {
+    auto run = [&](auto c1) __attribute__((always_inline)) {
       int kc = 0;
       for (; kc + 2 < nk; ++kc) iter(kc, c1, T{}, T{});
       if (nk >= 2) iter(nk - 2, c1, T{}, F{});
@@ -546,9 +584,11 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
     if (cls == 0) run(F{}); else run(T{});
   }
 
-  // ---- epilogue: G^T dU G per (o, i), two halves of 32 input channels; slab[split][o][tap * C + i] ----
+  // ---- epilogue: G^T dU G (3x3 taps) or A^T dU A (the 2x2 taps of this input phase) per (o, i), two halves of 32
+  // input channels; slab[split][o][tap * C + i] ----
   const int cl = tid & 31, tg = tid >> 5;
-  float* slab = p.slab + (size_t)split * p.Opad * (9 * p.C);
+  constexpr int NT = MODE == 0 ? 9 : 16;
+  float* slab = p.slab + (size_t)split * p.Opad * (NT * p.C);
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();
@@ -562,7 +602,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
           lds[(2 * wave + a) * 2048 + row * 32 + lr] = acc[a][i][half][e];
         }
     __syncthreads();
-    const int ic = i_tile * 64 + half * 32 + cl;
+    const int ic = i_tile * 64 - phase * p.C + half * 32 + cl;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = tg + 16 * q;
@@ -570,20 +610,35 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
       float u[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) u[k] = lds[k * 2048 + row * 32 + cl];
-      float h[3][4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        h[0][c] = u[0 * 4 + c] + 0.5f * (u[1 * 4 + c] + u[2 * 4 + c]);
-        h[1][c] = 0.5f * (u[1 * 4 + c] - u[2 * 4 + c]);
-        h[2][c] = 0.5f * (u[1 * 4 + c] + u[2 * 4 + c]) + u[3 * 4 + c];
-      }
       if (oc < p.O && ic < p.C) {
-        float* dst = slab + (size_t)oc * (9 * p.C) + ic;
+        float* dst = slab + (size_t)oc * (NT * p.C) + ic;
+        if constexpr (MODE == 0) {
+          float h[3][4];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          dst[(a * 3 + 0) * p.C] = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
-          dst[(a * 3 + 1) * p.C] = 0.5f * (h[a][1] - h[a][2]);
-          dst[(a * 3 + 2) * p.C] = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
+          for (int c = 0; c < 4; ++c) {
+            h[0][c] = u[0 * 4 + c] + 0.5f * (u[1 * 4 + c] + u[2 * 4 + c]);
+            h[1][c] = 0.5f * (u[1 * 4 + c] - u[2 * 4 + c]);
+            h[2][c] = 0.5f * (u[1 * 4 + c] + u[2 * 4 + c]) + u[3 * 4 + c];
+          }
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            dst[(a * 3 + 0) * p.C] = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
+            dst[(a * 3 + 1) * p.C] = 0.5f * (h[a][1] - h[a][2]);
+            dst[(a * 3 + 2) * p.C] = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
+          }
+        } else {
+          float h[2][4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            h[0][c] = u[0 * 4 + c] + u[1 * 4 + c] + u[2 * 4 + c];
+            h[1][c] = u[1 * 4 + c] - u[2 * 4 + c] - u[3 * 4 + c];
+          }
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const int ky = 2 * a + ph_p;
+            dst[(ky * 4 + 0 + ph_q) * p.C] = h[a][0] + h[a][1] + h[a][2];
+            dst[(ky * 4 + 2 + ph_q) * p.C] = h[a][1] - h[a][2] - h[a][3];
+          }
         }
       }
     }
@@ -799,46 +854,61 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
 }
 
 // ---- weight gradient host side ----
-static bool wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
+// returns 0 (not applicable), 1 (3x3 stride-1) or 2 (4x4 stride-2)
+static int wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
   static const bool off = std::getenv("SRGAN_NO_WINOGRAD_WGRAD") != nullptr;
-  if (wino_disabled() || off) return false;
-  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return false;
-  if (d->I % 64 != 0 || d->O % 64 != 0 || d->Hi < 3 || d->Wi < 3) return false;
-  if ((long long)d->N * d->Hi * d->Wi * d->I >= (1LL << 29) || (long long)d->N * d->Ho * d->Wo * d->O >= (1LL << 29)) return false;
+  if (wino_disabled() || off) return 0;
+  int variant = 0;
+  if (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1) variant = 1;
+  else if (d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 1 && d->pad_mode == SRGAN_PAD_ZERO && !(d->Hi & 1) &&
+           !(d->Wi & 1) && !wino_s2_disabled())
+    variant = 2;
+  if (variant == 0) return 0;
+  if (d->I % 64 != 0 || d->O % 64 != 0 || d->Hi < 3 || d->Wi < 3) return 0;
+  if ((long long)d->N * d->Hi * d->Wi * d->I >= (1LL << 29) || (long long)d->N * d->Ho * d->Wo * d->O >= (1LL << 29)) return 0;
+  const int ot = variant == 1 ? 2 : 3;
   p->NB = d->N; p->H = d->Hi; p->W = d->Wi; p->C = d->I; p->Ho = d->Ho; p->Wo = d->Wo; p->O = d->O;
   p->pad = d->pad; p->reflect = d->pad_mode == SRGAN_PAD_REFLECT ? 1 : 0;
-  p->TH = (d->Ho + 1) / 2; p->TW = (d->Wo + 1) / 2;
+  p->TH = (int)ceil_div(d->Ho, ot); p->TW = (int)ceil_div(d->Wo, ot);
+  if (variant == 2 && (double)d->Ho * d->Wo / ((double)ot * ot * p->TH * p->TW) * 2.25 < 1.5) return 0;   // tiling waste
   p->groups = (int)ceil_div((long long)p->TH * p->TW, 8);
-  p->o_tiles = d->O / 64; p->i_tiles = d->I / 64; p->Opad = d->O;
+  p->o_tiles = d->O / 64; p->i_tiles = (variant == 2 ? 4 : 1) * d->I / 64; p->Opad = d->O;
   const int tiles = p->o_tiles * p->i_tiles;
-  // one workgroup per CU (128 KB of LDS): fill whole rounds of 256; at least 16 chunks per workgroup
+  // one workgroup per CU (128 KB of LDS): fill whole rounds of 256
   int splits = std::max(1, 256 / tiles);
   splits = std::min(splits, p->groups);
   p->groups_per_split = (int)ceil_div(p->groups, splits);
   p->splits = (int)ceil_div(p->groups, p->groups_per_split);
-  if ((long long)tiles * p->splits < 16) return false;                        // too few workgroups: implicit GEMM instead
-  if ((long long)p->groups_per_split * d->N < 4) return false;                // too short a K range per workgroup
-  return true;
+  const long long blocks = (long long)tiles * p->splits, chunks = (long long)p->groups_per_split * d->N;
+  if (variant == 1) {
+    if (blocks < 16 || chunks < 4) return 0;          // too few workgroups / too short a K range: implicit GEMM instead
+  } else {
+    if (blocks < 192 || chunks < 48) return 0;       // measured: the discriminator's small maps stay faster on the implicit GEMM
+  }
+  return variant;
 }
 
 bool wino_wgrad_applicable(const srgan_conv_desc* d) {
   WinoWgradParams p{};
-  return wino_wgrad_geometry(d, &p);
+  return wino_wgrad_geometry(d, &p) != 0;
 }
 
-// slab geometry for wgrad_reduce_kernel: [splits][Cdpad = O][NNpad = 9 * I]
+// slab geometry for wgrad_reduce_kernel: [splits][Cdpad = O][NNpad = kh * kw * I]
 void wino_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad) {
   WinoWgradParams p{};
   wino_wgrad_geometry(d, &p);
-  *splits = p.splits; *Cdpad = p.Opad; *NNpad = 9 * d->I;
+  *splits = p.splits; *Cdpad = p.Opad; *NNpad = d->kh * d->kw * d->I;
 }
 
 int wino_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, hipStream_t st) {
   WinoWgradParams p{};
-  SRGAN_REQUIRE(wino_wgrad_geometry(d, &p), "winograd wgrad: layer not applicable");
+  const int variant = wino_wgrad_geometry(d, &p);
+  SRGAN_REQUIRE(variant != 0, "winograd wgrad: layer not applicable");
   p.x = x; p.dy = dy; p.slab = slab;
-  ProfToken tok = prof_begin(15, 2.0 * 9.0 * (double)d->N * d->Ho * d->Wo * d->I * d->O, st);   // algorithmic FLOPs, as above
-  hipLaunchKernelGGL(wino_wgrad_kernel, dim3((unsigned)(p.o_tiles * p.i_tiles * p.splits)), dim3(512), 0, st, p);
+  ProfToken tok = prof_begin(variant == 1 ? 15 : 17, conv_flops_of(d), st);   // algorithmic FLOPs, as above
+  const dim3 grid((unsigned)(p.o_tiles * p.i_tiles * p.splits));
+  if (variant == 1) hipLaunchKernelGGL(wino_wgrad_kernel<0>, grid, dim3(512), 0, st, p);
+  else hipLaunchKernelGGL(wino_wgrad_kernel<1>, grid, dim3(512), 0, st, p);
   prof_end(tok, st);
   return check_launch("wino_wgrad_kernel");
 }

@@ -62,6 +62,9 @@ CONV_CASES = [
     (8, 64, 18, 14, 128, 3, 1, 1, False, True),   # Winograd weight gradient: 63 tile positions (ragged last group), bias
     (4, 128, 17, 9, 128, 3, 1, 1, True, False),   # Winograd weight gradient: odd sizes (half tiles), reflect padding
     (16, 256, 16, 16, 128, 3, 1, 1, False, False),# Winograd weight gradient: several groups per split
+    (8, 128, 40, 44, 128, 4, 2, 1, False, True),  # F(3x3,2x2) Winograd of a 4x4 stride-2 layer: fwd and input gradient, ragged 3x3 tiles
+    (48, 128, 58, 62, 128, 4, 2, 1, False, True), # same + its Winograd weight gradient (needs >= 192 workgroups, >= 48 chunks), ragged tiles
+    (32, 64, 32, 32, 64, 4, 2, 1, False, False),  # same, one cout tile, many images per tile-position group
     (2, 3, 24, 70, 64, 7, 1, 3, False, False),    # RGB 7x7 layer: input gradient through the narrow-output kernel (flipped filter)
     (2, 3, 12, 13, 32, 5, 1, 2, False, True),     # same route, generic narrow kernel (5x5), bias
 ]
