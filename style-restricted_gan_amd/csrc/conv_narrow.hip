@@ -120,25 +120,43 @@ __global__ __launch_bounds__(256) void narrow_conv_fwd4_kernel(NarrowParams p) {
     }
     __syncthreads();
     const float* wq = p.wp + (size_t)c0 * KW * WROW;          // [channel][ky][WROW]
-#pragma unroll 1
-    for (int c = 0; c < N2_CH; ++c) {
+    // Software pipeline over the (channel, ky) steps: the 3 LDS reads and the scalar weight burst of step s+1 are issued
+    // before the 84 FMAs of step s (scalar loads return out of order, so their wait is lgkmcnt(0): issued a whole step
+    // ahead, that wait is free; issued right before use it exposed the full scalar-cache latency at 2 waves per SIMD).
+    float xs[2][12], wv[2][WROW];
+    // `rel` = step relative to the bases (a compile-time constant after unrolling: immediate offsets, one base each)
+    auto fetch = [&](const float* rowb, const float* wb, int rel, int buf) __attribute__((always_inline)) {
+      const int c = rel / KW, ky = rel - c * KW;
+      const float* row = rowb + (c * TH + ky) * TWP;
+      *reinterpret_cast<f32x4*>(xs[buf]) = *reinterpret_cast<const f32x4*>(row);
+      *reinterpret_cast<f32x4*>(xs[buf] + 4) = *reinterpret_cast<const f32x4*>(row + 4);
+      *reinterpret_cast<f32x4*>(xs[buf] + 8) = *reinterpret_cast<const f32x4*>(row + 8);
+      const float* wt = wb + rel * WROW;                        // wave-uniform -> scalar loads
 #pragma unroll
-      for (int ky = 0; ky < KW; ++ky) {
-        const float* row = &tile[(c * TH + py + ky) * TWP + pg * 4];
-        float xs[12];
-        *reinterpret_cast<f32x4*>(xs) = *reinterpret_cast<const f32x4*>(row);
-        *reinterpret_cast<f32x4*>(xs + 4) = *reinterpret_cast<const f32x4*>(row + 4);
-        *reinterpret_cast<f32x4*>(xs + 8) = *reinterpret_cast<const f32x4*>(row + 8);
-        const float* wt = wq + (c * KW + ky) * WROW;            // wave-uniform -> scalar loads
+      for (int i = 0; i < WROW; ++i) wv[buf][i] = wt[i];
+    };
+    constexpr int STEPS = N2_CH * KW, UNR = 2 * KW;             // body = 2 channels, buffers alternate statically
+    static_assert(STEPS % UNR == 0, "N2_CH must be even");
+    const float* rowb = &tile[py * TWP + pg * 4];
+    const float* wb = wq;
+    fetch(rowb, wb, 0, 0);
+#pragma unroll 1
+    for (int s0 = 0; s0 < STEPS; s0 += UNR) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int cur = u & 1;
+        if (u + 1 < UNR || s0 + UNR < STEPS) fetch(rowb, wb, u + 1, cur ^ 1);    // u + 1 == UNR: first step of the next body
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
           for (int o = 0; o < CO; ++o) {
-            const float w = wt[kx * CO + o];
+            const float w = wv[cur][kx * CO + o];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q][o] = fmaf(xs[q + kx], w, acc[q][o]);
+            for (int q = 0; q < 4; ++q) acc[q][o] = fmaf(xs[cur][q + kx], w, acc[q][o]);
           }
       }
+      rowb += 2 * TH * TWP;
+      wb += UNR * WROW;
     }
   }
   const int oy = oy0 + py, ox = ox0 + pg * 4;

@@ -753,6 +753,12 @@ static bool wino_disabled() {
   static const bool off = std::getenv("SRGAN_NO_WINOGRAD") != nullptr;
   return off;
 }
+// Dispatch thresholds scale with this factor (default 1; 0 = take every geometrically valid layer).  Read on every call so
+// that the unit tests can drive small shapes through the Winograd kernels and through the default dispatch in one process.
+static double wino_threshold_scale() {
+  const char* e = std::getenv("SRGAN_WINOGRAD_THRESHOLD_SCALE");
+  return e ? std::atof(e) : 1.0;
+}
 static bool wino_s2_disabled() {
   static const bool off = std::getenv("SRGAN_NO_WINOGRAD_S2") != nullptr;
   return off;
@@ -766,7 +772,14 @@ static int wino_variant(const srgan_conv_desc* d, int kind) {
   // the gather's "outside" offset (2 GiB) must lie past the end of the source tensor
   const long long src_elems = (long long)d->N * (kind == 0 ? (long long)d->Hi * d->Wi * d->I : (long long)d->Ho * d->Wo * d->O);
   if (src_elems >= (1LL << 29)) return 0;
-  if (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1) return (d->Hi >= 3 && d->Wi >= 3) ? 1 : 0;
+  if (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1) {
+    if (d->Hi < 3 || d->Wi < 3) return 0;
+    // one workgroup per CU: maps too small to give ~0.4 of a device round (the encoder's 7x7 / 3x3 maps at batch 32) run a long
+    // serial chunk loop on a few CUs -- measured 52 TFLOP/s against ~80 on the implicit GEMM
+    const int ho = kind == 0 ? d->Ho : d->Hi, wo = kind == 0 ? d->Wo : d->Wi;
+    const long long blocks = ceil_div((long long)d->N * ceil_div(ho, 2) * ceil_div(wo, 2), WT) * ceil_div(N, WNB);
+    return blocks >= 100 * wino_threshold_scale() ? 1 : 0;
+  }
   if (d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 1 && d->pad_mode == SRGAN_PAD_ZERO && !wino_s2_disabled()) {
     if ((d->Hi & 1) || (d->Wi & 1)) return 0;
     // 3x3 output tiles over Ho x Wo (= the phase image of the transposed form): skip maps the tiling wastes
@@ -775,7 +788,7 @@ static int wino_variant(const srgan_conv_desc* d, int kind) {
     if (eff * 2.25 < 1.5) return 0;
     // one workgroup per CU: below ~0.8 of a device round the long (4 C / 8 chunk) K loop loses to the implicit GEMM
     const long long blocks = ceil_div((long long)d->N * th * tw, WT) * ceil_div(N, WNB) * (kind == 1 ? 4 : 1);
-    return blocks >= 200 ? 2 : 0;
+    return blocks >= 200 * wino_threshold_scale() ? 2 : 0;
   }
   return 0;
 }
@@ -872,6 +885,8 @@ static int wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
   p->TH = (int)ceil_div(d->Ho, ot); p->TW = (int)ceil_div(d->Wo, ot);
   if (variant == 2 && (double)d->Ho * d->Wo / ((double)ot * ot * p->TH * p->TW) * 2.25 < 1.5) return 0;   // tiling waste
   p->groups = (int)ceil_div((long long)p->TH * p->TW, 8);
+  // tile positions are consumed in groups of 8: a 3x3 grid of tiles (9 positions) would run 16 slots
+  if (variant == 2 && (double)d->Ho * d->Wo / ((double)ot * ot * 8 * p->groups) * 2.25 < 1.5) return 0;
   p->o_tiles = d->O / 64; p->i_tiles = (variant == 2 ? 4 : 1) * d->I / 64; p->Opad = d->O;
   const int tiles = p->o_tiles * p->i_tiles;
   // one workgroup per CU (128 KB of LDS): fill whole rounds of 256
@@ -880,10 +895,11 @@ static int wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
   p->groups_per_split = (int)ceil_div(p->groups, splits);
   p->splits = (int)ceil_div(p->groups, p->groups_per_split);
   const long long blocks = (long long)tiles * p->splits, chunks = (long long)p->groups_per_split * d->N;
+  const double ts = wino_threshold_scale();
   if (variant == 1) {
-    if (blocks < 16 || chunks < 4) return 0;          // too few workgroups / too short a K range: implicit GEMM instead
+    if (blocks < 16 * ts || chunks < 4 * ts) return 0;      // too few workgroups / too short a K range: implicit GEMM instead
   } else {
-    if (blocks < 192 || chunks < 48) return 0;       // measured: the discriminator's small maps stay faster on the implicit GEMM
+    if (blocks < 192 * ts || chunks < 48 * ts) return 0;    // measured: the discriminator's small maps stay faster on the implicit GEMM
   }
   return variant;
 }

@@ -70,8 +70,19 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=["default-dispatch", "winograd-forced"])
+def dispatch(request):
+    """Every conv case runs through the default kernel choice AND with the size thresholds of the Winograd kernels
+    switched off (SRGAN_WINOGRAD_THRESHOLD_SCALE=0, read per call), so that small shapes exercise those kernels too."""
+    import os
+    if request.param == "winograd-forced":
+        os.environ["SRGAN_WINOGRAD_THRESHOLD_SCALE"] = "0"
+    yield request.param
+    os.environ.pop("SRGAN_WINOGRAD_THRESHOLD_SCALE", None)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_fwd_bwd(ops, case):
+def test_conv2d_fwd_bwd(ops, case, dispatch):
     n, i, h, w, o, k, s, p, reflect, has_bias = case
     torch.set_num_threads(16)
     x = rnd(n, i, h, w, seed=1).requires_grad_(True)
@@ -97,7 +108,7 @@ def test_conv2d_fwd_bwd(ops, case):
         close(bd.grad, b.grad, 5e-5)
 
 
-def test_conv2d_fused_leaky_relu(ops):
+def test_conv2d_fused_leaky_relu(ops, dispatch):
     x = rnd(2, 32, 10, 10, seed=1).requires_grad_(True)
     wt = (rnd(64, 32, 4, 4, seed=2) / 20).requires_grad_(True)
     yr = F.leaky_relu(F.conv2d(x, wt, None, 2, 1), 0.01)
@@ -112,7 +123,7 @@ def test_conv2d_fused_leaky_relu(ops):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 8, 8, 32), (2, 8, 5, 5, 4), (1, 256, 4, 4, 128)])
-def test_conv_transpose2d(ops, case):
+def test_conv_transpose2d(ops, case, dispatch):
     n, ci, h, w, co = case
     x = rnd(n, ci, h, w, seed=1).requires_grad_(True)
     wt = (rnd(ci, co, 4, 4, seed=2) / np.sqrt(ci * 4)).requires_grad_(True)
