@@ -6,6 +6,7 @@
 // Reference: _CBINorm.forward (pyfiles/model.py:54-67), nn.InstanceNorm2d (model.py:178),
 // formulas of SURVEY.md Appendix F.1.
 #include <algorithm>
+#include <cstdlib>
 #include "common.h"
 
 namespace srgan {
@@ -389,6 +390,133 @@ __global__ __launch_bounds__(256) void cbin_affine_bwd_c(const float* W, const f
     }
 }
 
+
+// ---- single-pass variants: the (image, 32-channel) slab lives in registers --------------------------------------------
+// For maps of <= 1024 pixels (the generator's 32x32x256 trunk: 17 of its ~22 norm layers, and the deep encoder /
+// discriminator maps) one workgroup holds its whole slab -- HW x 32 channels, <= 128 KB -- in VGPRs: the statistics, the
+// normalisation and the activation (forward), or the two gradient sums and dx (backward) come out of ONE read of the
+// tensor(s) instead of two, and of one launch instead of three.  Lanes 0-7 of a row group cover the 32 channels of one
+// pixel (128 contiguous bytes); the row groups of a wave are summed with shuffles, the waves through LDS.
+template <int NW, int QL = 8>
+__device__ __forceinline__ f32x4 slab_sum(f32x4 v, f32x4 (*sh)[8], int q, int wave) {
+#pragma unroll
+  for (int o = QL; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
+  __syncthreads();                       // previous use of sh is over
+  if ((threadIdx.x & 63) < QL) sh[wave][q] = v;
+  __syncthreads();
+  f32x4 t = sh[0][q];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) t += sh[w][q];
+  return t;
+}
+
+template <int R>
+__global__ __launch_bounds__(512) void in_fwd_slab(const float* __restrict__ x, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, const float* __restrict__ res,
+                                                   float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                   int HW, int C, float eps, int act, float slope) {
+  __shared__ f32x4 sh[8][8];
+  const int q = threadIdx.x & 7, ty = threadIdx.x >> 3, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 32 + q * 4, n = blockIdx.y;
+  const size_t base = (size_t)n * HW * C + c;
+  f32x4 v[R];
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int r = ty + 64 * j;
+    v[j] = r < HW ? *reinterpret_cast<const f32x4*>(x + base + (size_t)r * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += v[j];
+  }
+  const float inv = 1.f / (float)HW;
+  const f32x4 mu = slab_sum<8>(s, sh, q, wave) * inv;
+  f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+    if (ty + 64 * j < HW) {
+      const f32x4 d = v[j] - mu;
+      m2 += d * d;
+    }
+  const f32x4 var = slab_sum<8>(m2, sh, q, wave) * inv;     // exact two-pass variance (biased), as instance_norm
+  f32x4 rs;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) rs[e] = 1.0f / sqrtf(var[e] + eps);
+  const int nc = n * C + c;
+  if (ty == 0) {
+    *reinterpret_cast<f32x4*>(mean + nc) = mu;
+    *reinterpret_cast<f32x4*>(rstd + nc) = rs;
+  }
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+  if (scale) {
+    sc = *reinterpret_cast<const f32x4*>(scale + nc);
+    sf = *reinterpret_cast<const f32x4*>(shift + nc);
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int r = ty + 64 * j;
+    if (r < HW) {
+      f32x4 o = ((v[j] - mu) * rs) * sc + sf;               // same expression as in_apply / the backward's mask recomputation
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = apply_act(o[e], act, slope);
+      if (res) o += *reinterpret_cast<const f32x4*>(res + base + (size_t)r * C);
+      *reinterpret_cast<f32x4*>(y + base + (size_t)r * C) = o;
+    }
+  }
+}
+
+// backward: x and dy both stay in registers, so the slab is HW x 16 channels (4 lanes per pixel, 64-byte segments) and
+// 1024 threads hold at most 4 + 4 float4 each -- 32 channels needed 128 VGPRs and spilled.
+template <int R>
+__global__ __launch_bounds__(1024) void in_bwd_slab(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    float* __restrict__ dx, float* __restrict__ dscale,
+                                                    float* __restrict__ dshift, int HW, int C, int act, float slope) {
+  __shared__ f32x4 sh[16][8];
+  const int q = threadIdx.x & 3, ty = threadIdx.x >> 2, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 16 + q * 4, n = blockIdx.y;
+  const int nc = n * C + c;
+  const size_t base = (size_t)n * HW * C + c;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + nc), rs = *reinterpret_cast<const f32x4*>(rstd + nc);
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+  if (scale) {
+    sc = *reinterpret_cast<const f32x4*>(scale + nc);
+    sf = *reinterpret_cast<const f32x4*>(shift + nc);
+  }
+  f32x4 xh[R], g[R];
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int r = ty + 256 * j;
+    if (r < HW) {
+      xh[j] = (*reinterpret_cast<const f32x4*>(x + base + (size_t)r * C) - mu) * rs;
+      g[j] = *reinterpret_cast<const f32x4*>(dy + base + (size_t)r * C);
+      const f32x4 z = xh[j] * sc + sf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[j][e] *= act_grad(z[e], act, slope);
+      a += g[j];
+      b += g[j] * xh[j];
+    } else {
+      xh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      g[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  a = slab_sum<16, 4>(a, sh, q, wave);
+  b = slab_sum<16, 4>(b, sh, q, wave);
+  if (ty == 0) {
+    *reinterpret_cast<f32x4*>(dshift + nc) = a;
+    *reinterpret_cast<f32x4*>(dscale + nc) = b;
+  }
+  const float inv_hw = 1.f / (float)HW;
+  const f32x4 mg = a * inv_hw, mgx = b * inv_hw, k = rs * sc;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int r = ty + 256 * j;
+    if (r < HW) *reinterpret_cast<f32x4*>(dx + base + (size_t)r * C) = k * (g[j] - mg - xh[j] * mgx);
+  }
+}
+
 namespace {
 // C divides 1024 (so 256 threads * 4 floats wrap onto the same channels) and every float4 stays inside one pixel
 bool pow2_fast(int C, int HW) { return C >= 4 && (1024 % C) == 0 && (long long)HW * C / 4 < (1LL << 30); }
@@ -396,6 +524,12 @@ int apply_grid(int hwc4, int N) {
   long long per_image = ceil_div(hwc4, 256);                 // blocks if one float4 per thread
   long long want = std::max<long long>(1, 2048 / std::max(1, N));
   return (int)std::max<long long>(1, std::min(per_image, want));
+}
+
+// single-pass kernels: whole 32-channel groups, a slab of <= 1024 pixels, enough workgroups to cover the device
+bool slab_fast(int N, int HW, int C) {
+  static const bool off = std::getenv("SRGAN_NO_NORM_SLAB") != nullptr;
+  return !off && (C % 32) == 0 && HW <= 1024 && (long long)N * (C / 32) >= 128;
 }
 
 void plan_split(int N, int HW, int C, int& S, int& rps) {
@@ -426,6 +560,18 @@ extern "C" int srgan_instnorm_fwd(const float* x, const float* scale, const floa
   int S, rps;
   plan_split(N, HW, C, S, rps);
   SRGAN_REQUIRE(ws && ws_bytes >= (size_t)N * S * C * sizeof(float2), "instnorm_fwd: workspace too small");
+  if (slab_fast(N, HW, C)) {
+    const dim3 gs((unsigned)(C / 32), (unsigned)N);
+    const int rows = (HW + 63) / 64;
+#define SRGAN_FWD_SLAB(R) hipLaunchKernelGGL(in_fwd_slab<R>, gs, dim3(512), 0, st, x, scale, shift, res, y, mean, rstd, HW, C, eps, act, slope)
+    if (rows <= 1) SRGAN_FWD_SLAB(1);
+    else if (rows <= 2) SRGAN_FWD_SLAB(2);
+    else if (rows <= 4) SRGAN_FWD_SLAB(4);
+    else if (rows <= 8) SRGAN_FWD_SLAB(8);
+    else SRGAN_FWD_SLAB(16);
+#undef SRGAN_FWD_SLAB
+    return check_launch("instnorm_fwd (slab)");
+  }
   float2* part = reinterpret_cast<float2*>(ws);
   dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
   if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4, g, dim3(256), 0, st, x, part, HW, C, S, rps);
@@ -455,6 +601,16 @@ extern "C" int srgan_instnorm_bwd(const float* x, const float* dy, const float* 
   int S, rps;
   plan_split(N, HW, C, S, rps);
   SRGAN_REQUIRE(ws && ws_bytes >= (size_t)N * S * C * sizeof(float2), "instnorm_bwd: workspace too small");
+  if (slab_fast(N, HW, C)) {
+    const dim3 gs((unsigned)(C / 16), (unsigned)N);
+    const int rows = (HW + 255) / 256;
+#define SRGAN_BWD_SLAB(R) hipLaunchKernelGGL(in_bwd_slab<R>, gs, dim3(1024), 0, st, x, dy, scale, shift, mean, rstd, dx, dscale, dshift, HW, C, act, slope)
+    if (rows <= 1) SRGAN_BWD_SLAB(1);
+    else if (rows <= 2) SRGAN_BWD_SLAB(2);
+    else SRGAN_BWD_SLAB(4);
+#undef SRGAN_BWD_SLAB
+    return check_launch("instnorm_bwd (slab)");
+  }
   float2* part = reinterpret_cast<float2*>(ws);
   dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
   if ((C & 3) == 0) hipLaunchKernelGGL(in_bwd_partial_v4, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);

@@ -151,7 +151,9 @@ def test_conv_weight_read_at_backward_time(ops):
     close(x.grad, ref)
 
 
-@pytest.mark.parametrize("shape,act", [((2, 16, 9, 9), 1), ((3, 64, 16, 16), 0), ((2, 8, 31, 31), 2), ((2, 6, 5, 5), 1)])
+@pytest.mark.parametrize("shape,act", [((2, 16, 9, 9), 1), ((3, 64, 16, 16), 0), ((2, 8, 31, 31), 2), ((2, 6, 5, 5), 1),
+                                       ((8, 512, 16, 16), 1), ((16, 256, 7, 9), 2), ((16, 256, 32, 32), 1),   # single-pass slab kernels
+                                       ((64, 64, 20, 20), 0)])
 @pytest.mark.parametrize("affine", [False, True])
 def test_instance_norm_act(ops, shape, act, affine):
     n, c, h, w = shape
