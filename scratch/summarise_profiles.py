@@ -16,17 +16,27 @@ def prof_name(n):
     m = re.match(r"wgrad_kernel<\d+, \d+, \d+, \d+, (true|false)", n)
     if m:
         return "wgrad_kernel<%s>" % ("vec" if m.group(1) == "true" else "gen")
-    if n.startswith("wino_wgrad_kernel"):
-        return "wino_wgrad_kernel"
-    if n.startswith("wino_kernel"):
-        return "wino_kernel"
+    m = re.match(r"wino_wgrad_kernel<(\d)>", n)
+    if m:
+        return "wino_wgrad_kernel" if m.group(1) == "0" else "wino_wgrad_kernel<4x4s2>"
+    m = re.match(r"wino_kernel<(\d)>", n)
+    if m:
+        return "wino_kernel" if m.group(1) == "0" else "wino_kernel<4x4s2>"
     return None
 
 
+def newest(pattern):
+    """gpurun merges every run's files into gpurun_out/: take the most recent match."""
+    f = sorted(glob.glob(pattern), key=os.path.getmtime)
+    if not f:
+        raise SystemExit("no file matches " + pattern)
+    return f[-1]
+
+
 def counter(sub, name):
-    f = glob.glob(os.path.join(ev, sub, "*", "*counter_collection.csv"))
+    f = newest(os.path.join(ev, sub, "*", "*counter_collection.csv"))
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(f)):
         k = prof_name(r["Kernel_Name"])
         if k and r["Counter_Name"] == name:
             agg[k].append(float(r["Counter_Value"]))
@@ -43,7 +53,7 @@ for k in sorted(fetch):
     out["kernels"][k] = {"launches": len(fetch[k]), "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
                          "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
 json.dump(out, open(os.path.join(root, "profiles", tag.split("_")[0] + "_pmc_traffic.json"), "w"), indent=1)
-stats = glob.glob(os.path.join(ev, "stats", "*", "*kernel_stats.csv"))[0]
+stats = newest(os.path.join(ev, "stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(root, "profiles", tag + "_bench_steps5_kernel_stats.csv"))
 for src, dst in (("bench_plain.json", tag + "_bench_steps5.json"), ("bench_under_rocprof.json", tag + "_bench_steps5_under_rocprof.json")):
     p = os.path.join(ev, src)
