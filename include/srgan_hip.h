@@ -170,6 +170,18 @@ int srgan_adam_step(float* p, const float* g, float* m, float* v, long long n, f
 int srgan_adam_multi(const void* table, int n_tensors, long long max_numel, float lr, float beta1, float beta2,
                      float eps, int step_count, void* stream);
 
+/* ---- input pipeline: transforms.CenterCrop((178,178)) -> Resize((128,128)) -> RandomHorizontalFlip ->
+ * ToTensor -> MinMax(True) of the training notebooks (05-train cell 9; MinMax: pyfiles/util.py:108-155) on a batch of decoded
+ * uint8 RGB images src[B][Hs][Ws][3] (device).  Resize is Pillow's antialiased BILINEAR resample: the caller passes the
+ * window / 22-bit fixed-point coefficient tables of its two passes (bounds[2*i] = first source index, bounds[2*i+1] = taps;
+ * coeffs[i*ksize + t]), built as Pillow's precompute_coeffs / normalize_coeffs_8bpc do -- the resized bytes are bit-exact.
+ * flip[b] != 0 mirrors image b; minmax / mean0 select the per-image scaling to [0,1] / [-1,1].  dst is NHWC fp32. */
+size_t srgan_preprocess_workspace(int B, int crop_h, int out_h, int out_w);
+int srgan_preprocess_u8(const unsigned char* src, int B, int Hs, int Ws, int top, int left, int crop_h, int crop_w,
+                        int out_h, int out_w, const int* h_bounds, const int* h_coeffs, int h_ksize,
+                        const int* v_bounds, const int* v_coeffs, int v_ksize, const unsigned char* flip,
+                        int minmax, int mean0, float* dst, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- launch timer for bench.py's roofline leg (no reference counterpart) ---------------------
  * While enabled every implicit-GEMM / weight-gradient launch is bracketed by HIP events on its own
  * stream and tagged with its algorithmic FLOPs (2*N*Ho*Wo*O*kh*kw*I).  Collect after a device sync. */

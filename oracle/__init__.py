@@ -6,7 +6,8 @@ restatement of the algorithm in the reference's ``pyfiles/model.py``,
 used as the parity checker by ``tests/``, by ``__graft_entry__.smoke()`` and as
 the ``cpu_baseline`` leg of ``bench.py`` -- and by nothing else.  The product
 package (``style-restricted_gan_amd/srgan_amd``) never imports it and has no CPU
-fallback: it raises if the HIP library is missing.
+fallback: it raises if the HIP library is missing.  ``oracle/preprocess.py`` restates the input transform
+through Pillow / numpy and is pinned by Pillow itself.
 
 Parity status: PINNED.  The reference itself ships no tests / golden vectors
 for this path, so the oracle is pinned against outputs of the

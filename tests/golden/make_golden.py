@@ -293,12 +293,55 @@ def golden_pretrain():
     np.savez_compressed(os.path.join(HERE, "pretrain_T_b8.npz"), **out)
 
 
+def golden_facedataset():
+    """File selection / split / label logic of FaceDataset (pyfiles/dataset.py:58-124) on a synthetic label set.
+    The reference class still uses ``np.int`` (removed from numpy): the alias is restored for the import only."""
+    import pickle
+    import tempfile
+    np.int = int
+    import dataset as ref_dataset
+    rng = np.random.default_rng(5)
+    files = []
+    for f in range(3):
+        n = 90
+        names = np.array(["%06d.jpg" % (f * 1000 + i) for i in rng.permutation(n)])
+        attrs = rng.choice(["1", "-1"], size=(n, 5))
+        files.append(np.concatenate([names[:, None], attrs], axis=1))
+    cases = [
+        dict(dataset_label={"class": [1, 2], "delete": [], "existed": []}, classes=(0, 1, 2, 3), train_num=20, val_num=5, test_num=5),
+        dict(dataset_label={"class": [3], "delete": [4], "existed": [5]}, classes=(0, 1), train_num=2000, val_num=4, test_num=3),
+        dict(dataset_label={"class": [2, 4], "delete": [1], "existed": []}, classes=(0, 1, 2, 3), train_num=7, val_num=2, test_num=6),
+    ]
+    out = {"label_files": [f.tolist() for f in files], "cases": []}
+    with tempfile.TemporaryDirectory() as tmp:
+        lab = os.path.join(tmp, "labels") + os.sep
+        os.makedirs(lab)
+        for i, f in enumerate(files):
+            with open(os.path.join(lab, "part%d.pkl" % i), "wb") as fh:
+                pickle.dump(f, fh)
+        for case in cases:
+            rec = {k: (list(v) if isinstance(v, tuple) else v) for k, v in case.items()}
+            rec["splits"] = {}
+            for dt in ("train", "val", "test"):
+                ds = ref_dataset.FaceDataset("IMG/", lab, None, case["dataset_label"], case["classes"], dt, case["train_num"],
+                                             case["val_num"], case["test_num"])
+                rec["splits"][dt] = {"images": list(ds.images), "labels": [int(v) for v in ds.labels]}
+            out["cases"].append(rec)
+    out["class_label_3"] = [list(t) for t in ref_dataset.get_class_label(3)]
+    with open(os.path.join(HERE, "facedataset.json"), "w") as fh:
+        json.dump(out, fh)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "facedataset":
+        golden_facedataset()
+        sys.exit(0)
     golden_shapes()
     golden_modules()
     golden_losses()
     golden_train()
     golden_singlegan()
     golden_pretrain()
+    golden_facedataset()
     print("golden fixtures written to", HERE)
