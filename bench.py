@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 (default, BASELINE configs[1]) or the bf16 MFMA compute mode of configs [2]-[4] (never the headline)")
     args = ap.parse_args()
 
     from srgan_amd import _lib, dp
@@ -127,6 +129,9 @@ def main():
     if device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     lib = _lib.load()
+    if args.dtype == "bf16":
+        from srgan_amd import ops as _ops
+        _ops.set_compute_dtype("bf16")
     B = args.batch_per_gpu
     sg = build_trainer(args.size, B * world, args.k, device)
     torch.manual_seed(1000 + rank)           # per-rank noise stream after identical construction
@@ -191,9 +196,10 @@ def main():
                       f"images/sec G+D+E train step, CelebA {args.size}x{args.size} bs={B}/GPU",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SRGAN-nopretrain (03-train) G+D+E train step, {args.size}x{args.size}, "
-                                   f"bs={B}/GPU, k={args.k}, fp32, E trainable (BASELINE configs[1])",
+                                   f"bs={B}/GPU, k={args.k}, " + ("fp32" if args.dtype == "f32" else "bf16 MFMA conv forward / input gradient, "
+                                   "fp32 storage, weight gradients, norms, losses, Adam") + ", E trainable (BASELINE configs[1])",
                        "global_batch": B * world, "unrolled_k": args.k, "parallelism": f"dp{world}",
                        "gflop_per_image_algorithmic": GFLOP_PER_IMAGE.get(args.size),
                        "step_tflops_algorithmic": round(value * GFLOP_PER_IMAGE.get(args.size, 0) / 1e3, 2),

@@ -170,6 +170,14 @@ int srgan_adam_step(float* p, const float* g, float* m, float* v, long long n, f
 int srgan_adam_multi(const void* table, int n_tensors, long long max_numel, float lr, float beta1, float beta2,
                      float eps, int step_count, void* stream);
 
+/* ---- compute mode.  0 (default): exact fp32 products on v_mfma_f32_32x32x2_f32 (BASELINE configs[0], [1]).
+ * 1: bf16 MFMA compute for configs [2]-[4]: conv operands are rounded to bf16 (nearest even) on their way into LDS and
+ * multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- torch.autocast(bfloat16) semantics for the convolutions;
+ * tensors in HBM, norms, losses and Adam stay fp32; the Winograd kernels are not used.  Process-wide; packed weights made
+ * under the other mode must be re-packed (srgan_amd.ops.set_compute_dtype does). */
+int srgan_set_compute_mode(int mode);
+int srgan_get_compute_mode(void);
+
 /* ---- input pipeline: transforms.CenterCrop((178,178)) -> Resize((128,128)) -> RandomHorizontalFlip ->
  * ToTensor -> MinMax(True) of the training notebooks (05-train cell 9; MinMax: pyfiles/util.py:108-155) on a batch of decoded
  * uint8 RGB images src[B][Hs][Ws][3] (device).  Resize is Pillow's antialiased BILINEAR resample: the caller passes the

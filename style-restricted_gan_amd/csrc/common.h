@@ -7,6 +7,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace srgan {
 
@@ -70,6 +72,9 @@ __device__ __forceinline__ float act_grad(float v, int act, float slope) {
   return 1.f;
 }
 
+
+// process-wide compute mode (conv_igemm.hip): true = bf16 MFMA operands, fp32 accumulate
+bool compute_bf16();
 
 // launch-timer bracket (conv_igemm.hip) usable from the other translation units
 struct ProfToken { size_t idx; bool on; };

@@ -84,6 +84,10 @@ void prof_end(ProfToken t, hipStream_t st) {
   if (t.on) (void)hipEventRecord(g_prof_slots[t.idx].b, st);
 }
 
+// ---- compute mode: 0 = exact fp32 (default), 1 = bf16 MFMA operands with fp32 accumulation ----
+static int g_compute_mode = 0;
+bool compute_bf16() { return g_compute_mode == 1; }
+
 struct IgemmParams {
   const float* src;
   const float* wp;    // packed weights [phases][Npad][Kpad]
@@ -105,8 +109,11 @@ struct IgemmParams {
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
 
-template <int BM, int BN, int WM, int WN, bool VEC>
+// BF = bf16 MFMA compute (BASELINE configs [2]-[4]): operands are rounded to bf16 (RNE) when the tile is written to LDS and
+// multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; HBM tensors, the gather and the epilogue stay fp32.
+template <int BM, int BN, int WM, int WN, bool VEC, bool BF = false>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
+  static_assert(!BF || VEC, "the bf16 variant rides on the vector gather");
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int NT = WM * WN * 64;        // threads per workgroup (4 or 8 waves)
   constexpr int RP = NT / 8;              // tile rows staged per pass of float4 loads (8 float4 = 32 floats per row)
@@ -295,9 +302,26 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     }
   };
 
+  constexpr int LDH = BK + 8;              // bf16 row stride (80 B): 16-lane ds_read_b128 groups land on distinct banks
   auto store_tiles = [&](int buf) {
     float* As = As2[buf];
     float* Bs = Bs2[buf];
+    if constexpr (BF) {
+      unsigned short* Ah = reinterpret_cast<unsigned short*>(As);
+      unsigned short* Bh = reinterpret_cast<unsigned short*>(Bs);
+      const int seg = tid & 7;
+#pragma unroll
+      for (int i = 0; i < A_VEC_IT; ++i) {
+        const int r = (tid >> 3) + RP * i;
+        *reinterpret_cast<bf16x4*>(&Ah[r * LDH + seg * 4]) = __builtin_convertvector(a_reg[i] * a_msk[i], bf16x4);
+      }
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int r = (tid >> 3) + RP * i;
+        *reinterpret_cast<bf16x4*>(&Bh[r * LDH + seg * 4]) = __builtin_convertvector(b_reg[i], bf16x4);
+      }
+      return;
+    }
     if constexpr (VEC) {
       const int seg = tid & 7;
 #pragma unroll
@@ -358,6 +382,39 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i][e], bf[slot][j][e], acc[i][j], 0, 0, 0);
   };
 
+  if constexpr (BF) {
+    // 8 MFMAs (2 K-steps of 16) per wave and K tile: 256 matrix cycles against ~1000 of loads / LDS / barrier -- the loop
+    // is bound by data movement, so it is kept simple: fragments of the whole tile first, then the next tile's stores
+    bf16x8 ah[2][TM], bh[2][TN];
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    if (nk > 1) load_tiles(1);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As2[cur]);
+      const unsigned short* Bh = reinterpret_cast<const unsigned short*>(Bs2[cur]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          ah[q][i] = *reinterpret_cast<const bf16x8*>(&Ah[(wm * TM * 32 + i * 32 + lr) * LDH + q * 16 + lh * 8]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bh[q][j] = *reinterpret_cast<const bf16x8*>(&Bh[(wn * TN * 32 + j * 32 + lr) * LDH + q * 16 + lh * 8]);
+      }
+      if (kt + 1 < nk) store_tiles(cur ^ 1);
+      if (kt + 2 < nk) load_tiles(kt + 2);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[q][i], bh[q][j], acc[i][j], 0, 0, 0);
+      __syncthreads();
+    }
+  } else {
   load_tiles(0);
   store_tiles(0);
   __syncthreads();
@@ -380,6 +437,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
       if (kt + 2 < nk) load_tiles(kt + 2);
     }
     mfma_step(1);
+  }
   }
 
   // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -832,7 +890,9 @@ int launch_igemm(const IgemmParams& p, int phases, bool vec, hipStream_t st, dou
   constexpr int tile_id = (BM == 256 && BN == 64) ? 6 : (BM == 256) ? 5 : (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 128 && BN == 32) ? 2 : 3;
   ProfScope scope(tile_id * 2 + (vec ? 1 : 0), flops, st);
   dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)phases, 1);
-  if (vec)
+  if (vec && compute_bf16())
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, true>), grid, dim3(WM * WN * 64), 0, st, p);
+  else if (vec)
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, st, p);
   else
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(WM * WN * 64), 0, st, p);
@@ -1289,6 +1349,14 @@ extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, cons
   if (e) return e;
   return finish_wgrad(d, w, dy, dw, dbias, ws, st);
 }
+
+// ---- compute mode (BASELINE configs [2]-[4] are bf16): process-wide, set between steps ----
+extern "C" int srgan_set_compute_mode(int mode) {
+  SRGAN_REQUIRE(mode == 0 || mode == 1, "set_compute_mode: 0 (fp32) or 1 (bf16 MFMA, fp32 accumulate)");
+  g_compute_mode = mode;
+  return 0;
+}
+extern "C" int srgan_get_compute_mode(void) { return g_compute_mode; }
 
 // ---- launch-timer API (used only by bench.py) ------------------------------------------------
 extern "C" int srgan_prof_enable(int on) {

@@ -766,7 +766,8 @@ static bool wino_s2_disabled() {
 
 // 0: none, 1: F(2x2,3x3) on a 3x3 stride-1 pad-1 layer, 2: F(3x3,2x2) on a 4x4 stride-2 pad-1 layer
 static int wino_variant(const srgan_conv_desc* d, int kind) {
-  if (wino_disabled()) return 0;
+  if (wino_disabled() || compute_bf16()) return 0;       // bf16 mode: the transforms would eat the 8-bit mantissa
+
   const int C = kind == 0 ? d->I : d->O, N = kind == 0 ? d->O : d->I;
   if (C % (2 * WC) != 0 || C < 32 || N < 32) return 0;   // an even number of 8-channel chunks
   // the gather's "outside" offset (2 GiB) must lie past the end of the source tensor
@@ -870,7 +871,7 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
 // returns 0 (not applicable), 1 (3x3 stride-1) or 2 (4x4 stride-2)
 static int wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
   static const bool off = std::getenv("SRGAN_NO_WINOGRAD_WGRAD") != nullptr;
-  if (wino_disabled() || off) return 0;
+  if (wino_disabled() || off) return 0;      // the weight gradient stays exact fp32 in bf16 mode as well
   int variant = 0;
   if (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1) variant = 1;
   else if (d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 1 && d->pad_mode == SRGAN_PAD_ZERO && !(d->Hi & 1) &&

@@ -144,6 +144,19 @@ class pack_cache:
         return False
 
 
+def set_compute_dtype(name):
+    """"fp32" (default: exact fp32 MFMA, Winograd where it applies) or "bf16" (BASELINE configs [2]-[4]: conv operands rounded
+    to bf16 on their way into LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulation; everything else stays fp32).
+    Process-wide; drops the packed-weight cache because the two modes use different kernels / layouts."""
+    mode = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[str(name).replace("torch.", "")]
+    _lib.check(_lib.load().srgan_set_compute_mode(mode), "set_compute_mode")
+    _pack_cache.clear()
+
+
+def get_compute_dtype():
+    return "bf16" if _lib.load().srgan_get_compute_mode() == 1 else "fp32"
+
+
 def invalidate_packed(params=None):
     if params is None:
         _pack_cache.clear()

@@ -108,6 +108,49 @@ def test_conv2d_fwd_bwd(ops, case, dispatch):
         close(bd.grad, b.grad, 5e-5)
 
 
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+# layers the bf16 kernels serve: vector-gather implicit GEMM (Cin % 32 == 0, Cout >= 32); RGB / 1-channel heads stay fp32
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] % 32 == 0 and c[4] >= 32 and c[0] * c[2] * c[3] <= 70000])
+def test_conv2d_bf16_compute_mode(ops, case):
+    """bf16 MFMA mode (BASELINE configs [2]-[4]): forward and input gradient multiply bf16(x) * bf16(w) (bf16(dy) * bf16(w))
+    with fp32 accumulation, so they equal an fp32 convolution of the bf16-ROUNDED operands up to summation order -- held at
+    the same 2e-5 as the fp32 kernels.  The weight gradient stays exact fp32 (of the unrounded x and dy)."""
+    n, i, h, w, o, k, s, p, reflect, has_bias = case
+    torch.set_num_threads(16)
+    x = rnd(n, i, h, w, seed=1)
+    wt = rnd(o, i, k, k, seed=2) / np.sqrt(i * k * k)
+    b = (rnd(o, seed=3) * 0.1) if has_bias else None
+
+    def ref(xv, wv, gyv=None):
+        xv, wv = xv.clone().requires_grad_(True), wv.clone().requires_grad_(True)
+        xin = F.pad(xv, (p, p, p, p), mode="reflect") if reflect else xv
+        yv = F.conv2d(xin, wv, b, s, 0 if reflect else p)
+        if gyv is not None:
+            yv.backward(gyv)
+        return yv.detach(), xv.grad, wv.grad
+
+    y_ref, _, _ = ref(_bf16_round(x), _bf16_round(wt))
+    gy = rnd(*y_ref.shape, seed=4)
+    _, dx_ref, _ = ref(x, _bf16_round(wt), _bf16_round(gy))          # dx = dgrad(bf16(dy), bf16(w))
+    _, _, dw_ref = ref(x, wt, gy)                                     # dw: exact fp32
+    ops.set_compute_dtype("bf16")
+    try:
+        assert ops.get_compute_dtype() == "bf16"
+        xd = x.cuda().requires_grad_(True)
+        wd = wt.cuda().requires_grad_(True)
+        bd = b.cuda().requires_grad_(True) if has_bias else None
+        y = ops.conv2d(xd, wd, bd, s, p, ops.PAD_REFLECT if reflect else ops.PAD_ZERO)
+        y.backward(gy.cuda())
+        close(y, y_ref)
+        close(xd.grad, dx_ref)
+        close(wd.grad, dw_ref)
+    finally:
+        ops.set_compute_dtype("fp32")
+
+
 def test_conv2d_fused_leaky_relu(ops, dispatch):
     x = rnd(2, 32, 10, 10, seed=1).requires_grad_(True)
     wt = (rnd(64, 32, 4, 4, seed=2) / 20).requires_grad_(True)
