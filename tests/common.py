@@ -12,8 +12,12 @@ TIER_F = dict(G=dict(nch_in=3, nch=64, reduce=2, num_cls=2, res_num=6, num_con=1
               E=dict(nch_in=3, nch_out=8, nch=64, num_cls=4, num_con=4))
 
 
+# tiny widths on the 256x256 geometry of BASELINE configs[4] (the discriminator gets a fifth down conv)
+TIER_T256 = dict(G=TIER_T["G"], D=dict(nch_in=3, nch=4, reduce=2, num_cls=5, n_class=4), E=TIER_T["E"])
+
+
 def tier(name):
-    return TIER_T if name == "T" else TIER_F
+    return {"T": TIER_T, "T256": TIER_T256}.get(name, TIER_F)
 
 
 def oracle_params(name, seed=0):

@@ -80,9 +80,9 @@ def pool8(t):
 
 
 def build_nets(tier, seed=0):
-    if tier == "T":      # tiny widths, real 128x128 geometry
+    if tier in ("T", "T256"):      # tiny widths, real 128x128 (256x256: D with num_cls=5, BASELINE configs[4]) geometry
         G = ref_model.SingleGenerator(3, 4, 2, 2, 1, "instance", num_con=12)
-        D = ref_model.SingleDiscriminator_solo_multi(3, 4, 2, 4, "instance", 4)
+        D = ref_model.SingleDiscriminator_solo_multi(3, 4, 2, 5 if tier == "T256" else 4, "instance", 4)
         E = ref_model.Encoder(3, 8, 4, 4, "instance", 4, "cpu")
     else:                # notebook configuration (05-train cell 13/20)
         G = ref_model.SingleGenerator(3, 64, 2, 2, 6, "instance", num_con=12)
@@ -201,7 +201,7 @@ def golden_losses():
     np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
 
 
-def run_train(tier, batch, k, steps, seed, pretrained_e=False):
+def run_train(tier, batch, k, steps, seed, pretrained_e=False, size=128):
     """Drive the reference SRGAN_training.train and record what it returns + final params."""
     G, D, E = build_nets(tier)
     optE = None
@@ -216,7 +216,6 @@ def run_train(tier, batch, k, steps, seed, pretrained_e=False):
                                            optE if optE is not None else LegacyAdam(E.parameters())],
                                [nn.MSELoss(), nn.MSELoss()], dict(LBD), k, "cpu", np.eye(4), batch, "mu", 8)
     sg.opt_sche_initialization()
-    size = 128
     losses = []
     for s in range(steps):
         x, label = synthetic_batch(batch, size, 4, seed=100 + s)
@@ -226,7 +225,7 @@ def run_train(tier, batch, k, steps, seed, pretrained_e=False):
     for name, net in (("G", sg.G), ("D", sg.D), ("E", sg.E)):
         for k_, v in net.state_dict().items():
             v = v.detach().double()
-            if tier == "T":
+            if tier in ("T", "T256"):
                 out[f"{name}.{k_}"] = v.float().numpy()
             else:
                 out[f"{name}_ck.{k_}"] = np.array([float(v.sum()), float(v.norm())] + v.flatten()[:8].tolist())
@@ -238,6 +237,11 @@ def golden_train():
     np.savez_compressed(os.path.join(HERE, "train_T_b4_k5.npz"), **run_train("T", 4, 5, 2, seed=0))
     np.savez_compressed(os.path.join(HERE, "train_T_b4_k2_pretrainedE.npz"), **run_train("T", 4, 2, 2, seed=0, pretrained_e=True))
     np.savez_compressed(os.path.join(HERE, "train_F_b2_k1.npz"), **run_train("F", 2, 1, 2, seed=0))
+    golden_train_256()
+
+
+def golden_train_256():
+    np.savez_compressed(os.path.join(HERE, "train_T256_b2_k2.npz"), **run_train("T256", 2, 2, 2, seed=0, size=256))
 
 
 def run_singlegan(k, steps, seed, lbd, batch=8):
@@ -336,6 +340,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "facedataset":
         golden_facedataset()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "train256":
+        golden_train_256()
         sys.exit(0)
     golden_shapes()
     golden_modules()

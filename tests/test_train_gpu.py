@@ -51,6 +51,16 @@ def test_train_trajectory_vs_reference_tier_T(golden_dir, name, k, steps, pre):
             close_params(v, gold[f"{net_name}.{key}"], lr, n_opt, what=f"{net_name}.{key}")
 
 
+def test_train_trajectory_vs_reference_256(golden_dir):
+    """BASELINE configs[4] geometry: 256x256 images, discriminator with five down convs (tiny widths)."""
+    gold = np.load(os.path.join(golden_dir, "train_T256_b2_k2.npz"))
+    sg, traj = run_hip("T256", 2, 2, 2, seed=0, size=256)
+    np.testing.assert_allclose(traj, gold["losses"], rtol=1e-3)
+    for net_name, net, lr, n_opt in (("G", sg.G, 1e-4, 4), ("D", sg.D, 1e-4, 4), ("E", sg.E, 1e-4, 2)):
+        for key, v in net.state_dict().items():
+            close_params(v, gold[f"{net_name}.{key}"], lr, n_opt, what=f"{net_name}.{key}")
+
+
 def test_train_trajectory_vs_reference_full_size(golden_dir):
     gold = np.load(os.path.join(golden_dir, "train_F_b2_k1.npz"))
     sg, traj = run_hip("F", 2, 1, 2, seed=0)
