@@ -297,6 +297,27 @@ def golden_pretrain():
     np.savez_compressed(os.path.join(HERE, "pretrain_T_b8.npz"), **out)
 
 
+def golden_inference():
+    """get_samples (pyfiles/util_notebook.py:858-949), the multimodal inference path: one source image, every target class,
+    a list of latent codes pushed through G in chunks of `batch`, E re-encoding each output.  Tier-T networks."""
+    G, _, E = build_nets("T")
+    torch.manual_seed(3)
+    dataset = [(torch.rand(3, 128, 128) * 2 - 1, int(i % 4)) for i in range(3)]
+    latent = np.random.RandomState(7).randn(5, 8).astype(np.float32)
+    data, label = ref_nb.get_samples(G, E, dataset, 1, latent=latent, classes=(0, 1, 2, 3), ref_label=np.eye(4), ndim=8,
+                                     image_type="tensor", batch=2, device="cpu")
+    out = {"latent": latent, "source": data["source"].numpy(), "source_label": np.asarray(label["source"]),
+           "images": np.stack([dataset[i][0].numpy() for i in range(3)]), "labels": np.array([d[1] for d in dataset])}
+    for c in range(4):
+        out[f"target.{c}"] = data["target"][c].numpy()
+        out[f"mu.{c}"] = np.concatenate(label["latent"][c], axis=0)
+    pil, _ = ref_nb.get_samples(G, E, dataset, 1, latent=latent[:2], classes=(0, 1), ref_label=np.eye(4), ndim=8,
+                                image_type="pil", batch=32, device="cpu")
+    out["pil.source"] = np.asarray(pil["source"])
+    out["pil.target.1"] = np.stack([np.asarray(im) for im in pil["target"][1]])
+    np.savez_compressed(os.path.join(HERE, "inference_T.npz"), **out)
+
+
 def golden_facedataset():
     """File selection / split / label logic of FaceDataset (pyfiles/dataset.py:58-124) on a synthetic label set.
     The reference class still uses ``np.int`` (removed from numpy): the alias is restored for the import only."""
@@ -341,6 +362,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "facedataset":
         golden_facedataset()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "inference":
+        golden_inference()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "train256":
         golden_train_256()
         sys.exit(0)
@@ -351,4 +375,5 @@ if __name__ == "__main__":
     golden_singlegan()
     golden_pretrain()
     golden_facedataset()
+    golden_inference()
     print("golden fixtures written to", HERE)

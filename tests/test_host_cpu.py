@@ -139,3 +139,12 @@ def test_singlegan_trainer_signature():
     sg = SingleGAN_training([G, D, E], [None, "ignored", None], [nn.MSELoss(), nn.MSELoss()], lbd, 1, "cpu", np.eye(2), 8, (0, 1))
     sg.opt_sche_initialization()
     assert isinstance(sg.optD, list) and len(sg.optD) == 2 and len(sg.scheD) == 2     # always rebuilt per domain
+
+
+def test_image_from_output_matches_reference(golden_dir):
+    """tensor -> PIL conversion of the inference helpers (util.py:157-188) against the reference's output."""
+    import os
+    from srgan_amd.inference import image_from_output
+    gold = np.load(os.path.join(golden_dir, "inference_T.npz"))
+    img = image_from_output(torch.from_numpy(gold["source"]))[0]
+    assert np.array_equal(np.asarray(img), gold["pil.source"])
