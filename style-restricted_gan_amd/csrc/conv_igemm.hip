@@ -540,8 +540,13 @@ struct WgradParams {
 
 // ROWS: every 32-pixel K tile lies inside one image row (Wg % 32 == 0, VEC only): the tile's (n, y) and the source row
 // base are wave-uniform scalars advanced with counters; a thread only adds its constant column offset.
-template <int BMc, int BNn, int WM, int WN, bool VEC, bool ROWS = false>
+// BF (bf16 compute mode): the 32-pixel tiles are written to LDS as bf16 [pixel][channel] rows (channel-contiguous, as they
+// come from NHWC memory) and the MFMA operands -- 8 consecutive PIXELS of one channel per lane -- are fetched with the
+// transposing read ds_read_b64_tr_b16 (a 16-lane group reads 4 pixel rows x 16 channels and receives them column-major).
+// Row stride = channels * 2 + 64 bytes: the four rows of a block start 16 banks apart, the two blocks of a half 8 banks.
+template <int BMc, int BNn, int WM, int WN, bool VEC, bool ROWS = false, bool BF = false>
 __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel(WgradParams p) {
+  static_assert(!BF || VEC, "the bf16 variant rides on the vector gather");
   constexpr int TM = BMc / (WM * 32), TN = BNn / (WN * 32);
   constexpr int NT = (WM * WN > 4 ? WM * WN : 4) * 64;   // threads: 4 waves (some idle for small tiles) or 8 waves
   constexpr int A_IT = 8 * BMc / NT, B_IT = 8 * BNn / NT;     // float4 per thread per 32-row tile
@@ -740,9 +745,27 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
     }
   };
 
+  constexpr int LDA = BMc + 32, LDB = BNn + 32;      // bf16 row strides (elements)
   auto store_tile = [&](int buf) {
     float* As = As2[buf];
     float* Bs = Bs2[buf];
+    if constexpr (BF) {
+      unsigned short* Ah = reinterpret_cast<unsigned short*>(As);
+      unsigned short* Bh = reinterpret_cast<unsigned short*>(Bs);
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int idx = tid + NT * i;
+        const int r = idx / A_PR, c4 = idx - r * A_PR;
+        *reinterpret_cast<bf16x4*>(&Ah[r * LDA + c4 * 4]) = __builtin_convertvector(a_reg[i], bf16x4);
+      }
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int idx = tid + NT * i;
+        const int r = idx / B_PR, c4 = idx - r * B_PR;
+        *reinterpret_cast<bf16x4*>(&Bh[r * LDB + c4 * 4]) = __builtin_convertvector(ROWS ? b_reg[i] * b_msk[i] : b_reg[i], bf16x4);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(&As[(tid + NT * i) * 4]) = a_reg[i];
 #pragma unroll
@@ -771,6 +794,40 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
     }
   };
 
+  // bf16: the 2 x 16-pixel K steps of a tile; lane = (channel lr, pixel half lh), group of 16 lanes = one transposed block
+  auto mfma_bf16 = [&](int buf) {
+    typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4;
+    const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As2[buf]);
+    const unsigned short* Bh = reinterpret_cast<const unsigned short*>(Bs2[buf]);
+    const int li = lane & 15, q = li >> 2, pq = li & 3, g1 = (lane >> 4) & 1;
+    bf16x8 af[2][TM], bfr[2][TN];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int px = 16 * s + 8 * lh + q;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const unsigned short* a0 = &Ah[px * LDA + wm * TM * 32 + i * 32 + 16 * g1 + 4 * pq];
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)a0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(a0 + 4 * LDA));
+        af[s][i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned short* b0 = &Bh[px * LDB + wn * TN * 32 + j * 32 + 16 * g1 + 4 * pq];
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)b0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(b0 + 4 * LDB));
+        bfr[s][j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
+  };
+
   if (ntiles > 0) {
     if (!ROWS && tid < 32) fill_rowtab(0);
     __syncthreads();
@@ -780,6 +837,18 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
     __syncthreads();                    // tile 0 in LDS, rowtab[1] visible
     if (ntiles > 1) load_tile(1);
   }
+  if constexpr (BF) {
+    // the transposing read needs EXEC all ones: every wave executes it (idle waves of small tiles read valid addresses
+    // and discard), no lane-dependent branch around it
+    for (int t = 0; t < ntiles; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < ntiles) store_tile(cur ^ 1);
+      if (!ROWS && t + 2 < ntiles && tid < 32) fill_rowtab(t + 2);
+      if (active) mfma_bf16(cur);
+      __syncthreads();
+      if (t + 2 < ntiles) load_tile(t + 2);
+    }
+  } else
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     if (active) mfma_range(cur, 0, 8);
@@ -950,8 +1019,10 @@ template <int BMc, int BNn, int WM, int WN>
 static WgradVariant wgrad_variant(bool vec, bool rows) {
   constexpr int NT = (WM * WN > 4 ? WM * WN : 4) * 64;
   if constexpr (BMc >= 64 && BNn >= 64) {
+    if (vec && rows && compute_bf16()) return {wgrad_kernel<BMc, BNn, WM, WN, true, true, true>, NT};
     if (vec && rows) return {wgrad_kernel<BMc, BNn, WM, WN, true, true>, NT};
   }
+  if (vec && compute_bf16()) return {wgrad_kernel<BMc, BNn, WM, WN, true, false, true>, NT};
   if (vec) return {wgrad_kernel<BMc, BNn, WM, WN, true>, NT};
   return {wgrad_kernel<BMc, BNn, WM, WN, false>, NT};
 }
@@ -978,7 +1049,7 @@ static bool wgrad_lookup(int BMc, int BNn, bool vec, bool rows, WgradVariant* k)
 static long long wgrad_round_slots(const WgradPlan& w) {
   static std::mutex mu;
   static std::map<int, long long> cache;
-  const int key = (w.BMc << 16) | (w.BNn << 4) | (w.vec ? 2 : 0) | (w.rows ? 1 : 0);
+  const int key = (w.BMc << 16) | (w.BNn << 4) | (compute_bf16() ? 4 : 0) | (w.vec ? 2 : 0) | (w.rows ? 1 : 0);
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;

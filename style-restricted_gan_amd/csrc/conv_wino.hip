@@ -871,7 +871,7 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
 // returns 0 (not applicable), 1 (3x3 stride-1) or 2 (4x4 stride-2)
 static int wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
   static const bool off = std::getenv("SRGAN_NO_WINOGRAD_WGRAD") != nullptr;
-  if (wino_disabled() || off) return 0;      // the weight gradient stays exact fp32 in bf16 mode as well
+  if (wino_disabled() || off || compute_bf16()) return 0;
   int variant = 0;
   if (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1) variant = 1;
   else if (d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 1 && d->pad_mode == SRGAN_PAD_ZERO && !(d->Hi & 1) &&

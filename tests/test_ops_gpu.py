@@ -115,9 +115,9 @@ def _bf16_round(t):
 # layers the bf16 kernels serve: vector-gather implicit GEMM (Cin % 32 == 0, Cout >= 32); RGB / 1-channel heads stay fp32
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] % 32 == 0 and c[4] >= 32 and c[0] * c[2] * c[3] <= 70000])
 def test_conv2d_bf16_compute_mode(ops, case):
-    """bf16 MFMA mode (BASELINE configs [2]-[4]): forward and input gradient multiply bf16(x) * bf16(w) (bf16(dy) * bf16(w))
-    with fp32 accumulation, so they equal an fp32 convolution of the bf16-ROUNDED operands up to summation order -- held at
-    the same 2e-5 as the fp32 kernels.  The weight gradient stays exact fp32 (of the unrounded x and dy)."""
+    """bf16 MFMA mode (BASELINE configs [2]-[4]): forward, input gradient and weight gradient multiply bf16-rounded operands
+    (x * w, dy * w, dy * x) with fp32 accumulation, so each equals the fp32 convolution of the bf16-ROUNDED operands up to
+    summation order -- held at the same 2e-5 as the fp32 kernels."""
     n, i, h, w, o, k, s, p, reflect, has_bias = case
     torch.set_num_threads(16)
     x = rnd(n, i, h, w, seed=1)
@@ -135,7 +135,7 @@ def test_conv2d_bf16_compute_mode(ops, case):
     y_ref, _, _ = ref(_bf16_round(x), _bf16_round(wt))
     gy = rnd(*y_ref.shape, seed=4)
     _, dx_ref, _ = ref(x, _bf16_round(wt), _bf16_round(gy))          # dx = dgrad(bf16(dy), bf16(w))
-    _, _, dw_ref = ref(x, wt, gy)                                     # dw: exact fp32
+    _, _, dw_ref = ref(_bf16_round(x), wt, _bf16_round(gy))           # dw = wgrad(bf16(x), bf16(dy))
     ops.set_compute_dtype("bf16")
     try:
         assert ops.get_compute_dtype() == "bf16"
