@@ -29,7 +29,7 @@ import torch.nn as nn  # noqa: E402
 LBD = {"class": 1.0, "cycle": 5.0, "idt": 5.0, "reg": 0.5, "idt_reg": 0.5, "KL": 0.0,
        "batch_KL": 10.0, "corr_enc": 100.0, "hist": 100.0}          # 05-train cell 16
 GFLOP_PER_IMAGE = {128: 412.46, 256: 1677.69}                        # SURVEY.md 8d (k=5, E trainable)
-PEAK_TFLOPS = {"f32": 157.3}                                         # MI355X dense matrix peak, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2516.6}                                         # MI355X dense matrix peak, MI355X_MICROARCH.md
 
 
 def synthetic_batch(batch, size, n_class, seed):
@@ -184,7 +184,7 @@ def main():
     if rank == 0:
         images = B * world * args.steps
         value = images / elapsed
-        peak = PEAK_TFLOPS["f32"]
+        peak = PEAK_TFLOPS["f32" if args.dtype == "f32" else "bf16"]
         name, ms, n, fl = best
         achieved = fl / (ms * 1e-3) / 1e12
         # Winograd F(2x2,3x3) kernels issue 16 multiplies per 36 algorithmic ones: the algorithmic rate can exceed the
@@ -207,7 +207,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(name),
                          "executed_mfma_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4),
-                         "algorithm": "Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs than the algorithmic count" if wino
+                         "algorithm": "Winograd F(2x2,3x3) / F(3x3,2x2): 2.25x fewer MFMA FLOPs than the algorithmic count, so the "
+                                      "ALGORITHMIC rate asked for in `achieved` can exceed the MFMA peak (frac > 1); "
+                                      "executed_frac is the utilisation of the matrix pipe" if wino
                                       else "implicit GEMM: executed = algorithmic FLOPs",
                          "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
                          "traffic_note": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, profiles/r*_pmc_traffic.json)",

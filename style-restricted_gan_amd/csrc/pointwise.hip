@@ -197,21 +197,42 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 // multi-tensor Adam: one launch for a whole parameter list.  `table` holds n_tensors records of 5 x 8 bytes:
 // {p, g, m, v, numel}; blockIdx.y selects the tensor, blockIdx.x grid-strides over its elements.
-__global__ void adam_multi_kernel(const unsigned long long* __restrict__ table, float step_size, float beta1, float beta2,
-                                  float eps, float inv_sqrt_bc2) {
+__global__ __launch_bounds__(256) void adam_multi_kernel(const unsigned long long* __restrict__ table, float step_size,
+                                                         float beta1, float beta2, float eps, float inv_sqrt_bc2) {
   const unsigned long long* rec = table + (size_t)blockIdx.y * 5;
   float* __restrict__ p = reinterpret_cast<float*>(rec[0]);
   const float* __restrict__ g = reinterpret_cast<const float*>(rec[1]);
   float* __restrict__ m = reinterpret_cast<float*>(rec[2]);
   float* __restrict__ v = reinterpret_cast<float*>(rec[3]);
   const long long n = (long long)rec[4];
-  GRID_STRIDE(i, n) {
-    const float gi = g[i];
-    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  // a block owns chunks of 4096 elements (blockIdx.x, then a grid stride); blocks past a small tensor's end leave at once
+  const bool vec = ((rec[0] | rec[1] | rec[2] | rec[3]) & 15) == 0;
+  for (long long c0 = (long long)blockIdx.x * 4096; c0 < n; c0 += (long long)gridDim.x * 4096) {
+    if (vec && c0 + 4096 <= n) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long long i = c0 + (j * 256 + threadIdx.x) * 4;
+        const f32x4 gi = *reinterpret_cast<const f32x4*>(g + i);
+        const f32x4 mi = beta1 * *reinterpret_cast<const f32x4*>(m + i) + (1.f - beta1) * gi;
+        const f32x4 vi = beta2 * *reinterpret_cast<const f32x4*>(v + i) + (1.f - beta2) * gi * gi;
+        f32x4 pi = *reinterpret_cast<const f32x4*>(p + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pi[e] = pi[e] - step_size * (mi[e] / (sqrtf(vi[e]) * inv_sqrt_bc2 + eps));
+        *reinterpret_cast<f32x4*>(m + i) = mi;
+        *reinterpret_cast<f32x4*>(v + i) = vi;
+        *reinterpret_cast<f32x4*>(p + i) = pi;
+      }
+    } else {
+      const long long end = c0 + 4096 < n ? c0 + 4096 : n;
+      for (long long i = c0 + threadIdx.x; i < end; i += 256) {
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+      }
+    }
   }
 }
 
@@ -327,7 +348,7 @@ extern "C" int srgan_adam_multi(const void* table, int n_tensors, long long max_
   const double bc2 = 1.0 - std::pow((double)beta2, step_count);
   const float step_size = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
-  const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>(ceil_div(max_numel, 256 * 4), 64));
+  const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>(ceil_div(max_numel, 4096), 2048));
   hipLaunchKernelGGL(adam_multi_kernel, dim3(bx, (unsigned)n_tensors), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const unsigned long long*>(table), step_size, beta1, beta2, eps, inv_sqrt_bc2);
   return check_launch("adam_multi_kernel");
