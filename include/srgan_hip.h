@@ -68,6 +68,14 @@ int srgan_conv2d_fwd_packed(const srgan_conv_desc* d, const float* x, const void
 int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* dy, const void* packed, float* dx,
                               void* ws, size_t ws_bytes, void* stream);
 
+/* Many packs in one launch (after an optimiser step every cached operand of the network is stale at once):
+ * srgan_conv2d_pack_entry writes one host record (srgan_pack_entry_bytes() bytes) per operand -- it returns 1 for the few
+ * layers whose operand is made by another kernel (narrow-output layers; use srgan_conv2d_pack) -- the caller copies the array
+ * of records to the device and srgan_conv2d_pack_multi repacks them all. */
+size_t srgan_pack_entry_bytes(void);
+int srgan_conv2d_pack_entry(const srgan_conv_desc* d, int kind, int act, const float* w, void* packed, void* entry);
+int srgan_conv2d_pack_multi(const void* entries_dev, int n_entries, void* stream);
+
 /* Gradient w.r.t. the conv weight, written through (sO,sI,sH,sW) (overwrites, no accumulate);
  * dbias[O] (may be NULL) = column sums of dy. */
 int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, const float* dy, float* dw,

@@ -20,11 +20,13 @@
 // MFMA k-slots {8q+4h+e} so that A and B fragments come from single ds_read_b128's.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
 #include <vector>
 #include "common.h"
+#include "pack_device.h"
 
 namespace srgan {
 
@@ -463,38 +465,26 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 }
 
 // ---- weight repack ------------------------------------------------------------------------
-// dst[phase][n][ (ty*Tx+tx)*Cs + c ], zero padded to [Npad][Kpad].
-//   mode 0: n = O index, c = I index, (ky,kx) = (ty,tx)
-//   mode 1: n = I index, c = O index, ky = (py+pad)%s + s*ty (zero if >= kh)
-struct PackParams {
-  const float* w;
-  float* dst;
-  long long sO, sI, sH, sW;
-  int O, I, kh, kw, mode, stride, pad, Ty, Tx, Cs, N, K, Kpad, Npad, phases;
-};
-
 __global__ void pack_weights_kernel(PackParams p) {
-  const long long total = (long long)p.phases * p.Npad * p.Kpad;
+  const long long total = pack_weights_total(p);
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(idx % p.Kpad);
-    const long long rest = idx / p.Kpad;
-    const int n = (int)(rest % p.Npad);
-    const int phase = (int)(rest / p.Npad);
-    float v = 0.f;
-    if (n < p.N && k < p.K) {
-      const int t = k / p.Cs, c = k - t * p.Cs;
-      const int ty = t / p.Tx, tx = t - ty * p.Tx;
-      if (p.mode == 0) {
-        v = p.w[n * p.sO + c * p.sI + ty * p.sH + tx * p.sW];
-      } else {
-        const int py = phase / p.stride, px = phase % p.stride;
-        const int ky = (py + p.pad) % p.stride + p.stride * ty;
-        const int kx = (px + p.pad) % p.stride + p.stride * tx;
-        if (ky < p.kh && kx < p.kw) v = p.w[c * p.sO + n * p.sI + ky * p.sH + kx * p.sW];
-      }
-    }
-    p.dst[idx] = v;
+       idx += (long long)gridDim.x * blockDim.x)
+    pack_weights_item(p, idx);
+}
+
+// every cached operand of a network in one launch: blockIdx.y = entry, blockIdx.x grid-strides over its elements
+__global__ void pack_multi_kernel(const PackEntry* __restrict__ entries) {
+  const PackEntry& e = entries[blockIdx.y];
+  if (e.type == 0) {
+    const long long total = pack_weights_total(e.ig);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x)
+      pack_weights_item(e.ig, idx);
+  } else {
+    const long long total = wino_pack_total(e.wn);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x)
+      wino_pack_item(e.wn, idx);
   }
 }
 
@@ -1182,16 +1172,21 @@ static size_t fwd_packed_bytes(const srgan_conv_desc* d, int act) {
   return (size_t)p.Npad * p.Kpad * sizeof(float);
 }
 
-static int fwd_pack(const srgan_conv_desc* d, int act, const float* w, float* dst, hipStream_t st) {
-  const FwdPath path = fwd_path(d, act);
-  if (path == PATH_NARROW) return narrow_pack(d, w, dst, st);
-  if (path == PATH_WINO) return wino_pack(d, 0, w, dst, st);
+static PackParams fwd_pack_params(const srgan_conv_desc* d, FwdPath path, const float* w, float* dst) {
   IgemmParams p{};
   fwd_geometry(d, path, p);
   PackParams q{};
   q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
   q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 0; q.stride = d->stride; q.pad = d->pad;
   q.Ty = d->kh; q.Tx = d->kw; q.Cs = d->I; q.N = d->O; q.K = p.K; q.Kpad = p.Kpad; q.Npad = p.Npad; q.phases = 1;
+  return q;
+}
+
+static int fwd_pack(const srgan_conv_desc* d, int act, const float* w, float* dst, hipStream_t st) {
+  const FwdPath path = fwd_path(d, act);
+  if (path == PATH_NARROW) return narrow_pack(d, w, dst, st);
+  if (path == PATH_WINO) return wino_pack(d, 0, w, dst, st);
+  const PackParams q = fwd_pack_params(d, path, w, dst);
   long long total = (long long)q.Npad * q.Kpad;
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
   return check_launch("pack_weights_kernel");
@@ -1255,6 +1250,14 @@ static DgradGeom dgrad_geometry(const srgan_conv_desc* d) {
   return g;
 }
 
+static PackParams dgrad_pack_params(const srgan_conv_desc* d, const DgradGeom& g, const float* w, float* dst) {
+  PackParams q{};
+  q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
+  q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 1; q.stride = d->stride; q.pad = g.p.pad;
+  q.Ty = g.p.Ty; q.Tx = g.p.Tx; q.Cs = d->O; q.N = d->I; q.K = g.p.K; q.Kpad = g.p.Kpad; q.Npad = g.p.Npad; q.phases = g.phases;
+  return q;
+}
+
 static int dgrad_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st) {
   DgradGeom g = dgrad_geometry(d);
   if (g.wino) return wino_pack(d, 1, w, dst, st);
@@ -1264,10 +1267,7 @@ static int dgrad_pack(const srgan_conv_desc* d, const float* w, float* dst, hipS
     narrow_dgrad_desc(d, &f, &w_off);
     return narrow_pack(&f, w + w_off, dst, st);
   }
-  PackParams q{};
-  q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
-  q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 1; q.stride = d->stride; q.pad = g.p.pad;
-  q.Ty = g.p.Ty; q.Tx = g.p.Tx; q.Cs = d->O; q.N = d->I; q.K = g.p.K; q.Kpad = g.p.Kpad; q.Npad = g.p.Npad; q.phases = g.phases;
+  const PackParams q = dgrad_pack_params(d, g, w, dst);
   long long total = (long long)g.packed_elems;
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
   return check_launch("pack_weights_kernel");
@@ -1333,6 +1333,39 @@ extern "C" int srgan_conv2d_pack(const srgan_conv_desc* d, int kind, int act, co
   SRGAN_REQUIRE(kind == 0 || kind == 1, "conv2d_pack: kind must be 0 (forward) or 1 (input gradient)");
   SRGAN_REQUIRE(bytes >= srgan_conv2d_packed_bytes(d, kind, act), "conv2d_pack: destination too small");
   return kind == 0 ? fwd_pack(d, act, w, (float*)packed, as_stream(stream)) : dgrad_pack(d, w, (float*)packed, as_stream(stream));
+}
+
+// ---- one launch for many packs: the host collects one record per cached operand (srgan_conv2d_pack_entry), copies the
+// array to the device and calls srgan_conv2d_pack_multi after the optimiser step that changed those weights ----
+extern "C" size_t srgan_pack_entry_bytes(void) { return sizeof(PackEntry); }
+
+// fills `entry` (host memory, srgan_pack_entry_bytes() bytes).  Returns 0, or 1 when this layer's operand is produced by a
+// kernel outside the multi-pack launch (narrow-output layers): pack it with srgan_conv2d_pack.
+extern "C" int srgan_conv2d_pack_entry(const srgan_conv_desc* d, int kind, int act, const float* w, void* packed, void* entry) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(w && packed && entry, "conv2d_pack_entry: null pointer");
+  SRGAN_REQUIRE(kind == 0 || kind == 1, "conv2d_pack_entry: kind must be 0 (forward) or 1 (input gradient)");
+  PackEntry pe{};
+  if (kind == 0) {
+    const FwdPath path = fwd_path(d, act);
+    if (path == PATH_NARROW) return 1;
+    if (path == PATH_WINO) { pe.type = 1; wino_pack_params(d, 0, w, (float*)packed, &pe.wn); }
+    else { pe.type = 0; pe.ig = fwd_pack_params(d, path, w, (float*)packed); }
+  } else {
+    const DgradGeom g = dgrad_geometry(d);
+    if (g.narrow) return 1;
+    if (g.wino) { pe.type = 1; wino_pack_params(d, 1, w, (float*)packed, &pe.wn); }
+    else { pe.type = 0; pe.ig = dgrad_pack_params(d, g, w, (float*)packed); }
+  }
+  std::memcpy(entry, &pe, sizeof(pe));
+  return 0;
+}
+
+extern "C" int srgan_conv2d_pack_multi(const void* entries_dev, int n_entries, void* stream) {
+  SRGAN_REQUIRE(entries_dev && n_entries > 0, "conv2d_pack_multi: bad argument");
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(256, (unsigned)n_entries), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const PackEntry*>(entries_dev));
+  return check_launch("pack_multi_kernel");
 }
 
 extern "C" int srgan_conv2d_fwd_packed(const srgan_conv_desc* d, const float* x, const void* packed, const float* bias,

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
+#include "pack_device.h"
 
 #ifndef WINO_EXP
 #define WINO_EXP 0
@@ -649,96 +650,11 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
 // variant 1, F(2x2,3x3):  U = G g G^T;  kind 0 (forward): g = w[n][c][ky][kx];  kind 1 (input gradient): g = w[c][n][2-ky][2-kx]
 // variant 2, F(3x3,2x2):  U = A g A^T;  kind 0 (4x4 stride-2 conv): reduce index k = (input phase pq, c),
 //   g[a][b] = w[n][c][2a+p][2b+q];  kind 1 (its transpose): one image per OUTPUT phase rs, g[a][b] = w[c][n][3-2a-r][3-2b-s]
-struct WinoPackParams {
-  const float* w;
-  float* dst;
-  long long sO, sI, sH, sW;
-  int N, C, kind, nchunk, n_tiles, variant, phases;
-};
-
 __global__ void wino_pack_kernel(WinoPackParams p) {
-  const long long per_phase = (long long)p.n_tiles * WNB * p.nchunk * WC;
-  const long long total = per_phase * p.phases;
+  const long long total = wino_pack_total(p);
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int cc = (int)(idx % WC);
-    long long r = idx / WC;
-    const int nl = (int)(r % WNB); r /= WNB;
-    const int chunk = (int)(r % p.nchunk); r /= p.nchunk;
-    const int ntile = (int)(r % p.n_tiles);
-    const int ophase = (int)(r / p.n_tiles);
-    const int n = ntile * WNB + nl;
-    float u[4][4];
-    if (p.variant == 1) {
-      const int c = chunk * WC + cc;
-      float g[3][3];
-      const bool ok = n < p.N && c < p.C;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          float v = 0.f;
-          if (ok) v = p.kind == 0 ? p.w[n * p.sO + c * p.sI + ky * p.sH + kx * p.sW]
-                                  : p.w[c * p.sO + n * p.sI + (2 - ky) * p.sH + (2 - kx) * p.sW];
-          g[ky][kx] = v;
-        }
-      // G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
-      float h[4][3];
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        h[0][kx] = g[0][kx];
-        h[1][kx] = 0.5f * (g[0][kx] + g[1][kx] + g[2][kx]);
-        h[2][kx] = 0.5f * (g[0][kx] - g[1][kx] + g[2][kx]);
-        h[3][kx] = g[2][kx];
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        u[a][0] = h[a][0];
-        u[a][1] = 0.5f * (h[a][0] + h[a][1] + h[a][2]);
-        u[a][2] = 0.5f * (h[a][0] - h[a][1] + h[a][2]);
-        u[a][3] = h[a][2];
-      }
-    } else {
-      const int k = chunk * WC + cc;
-      int c, pp, qq;
-      if (p.kind == 0) { const int ph = k / p.C; c = k - ph * p.C; pp = ph >> 1; qq = ph & 1; }
-      else { c = k; pp = ophase >> 1; qq = ophase & 1; }
-      const bool ok = n < p.N && c < p.C && (p.kind == 1 || k < 4 * p.C);
-      float g[2][2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          float v = 0.f;
-          if (ok) v = p.kind == 0 ? p.w[n * p.sO + c * p.sI + (2 * a + pp) * p.sH + (2 * b + qq) * p.sW]
-                                  : p.w[c * p.sO + n * p.sI + (3 - 2 * a - pp) * p.sH + (3 - 2 * b - qq) * p.sW];
-          g[a][b] = v;
-        }
-      // A g A^T, A = [1 0; 1 1; 1 -1; 0 -1]
-      float h[4][2];
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        h[0][b] = g[0][b];
-        h[1][b] = g[0][b] + g[1][b];
-        h[2][b] = g[0][b] - g[1][b];
-        h[3][b] = -g[1][b];
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        u[a][0] = h[a][0];
-        u[a][1] = h[a][0] + h[a][1];
-        u[a][2] = h[a][0] - h[a][1];
-        u[a][3] = -h[a][1];
-      }
-    }
-    // within a position: [channel half][cout][4 channels] -- the register image of the kernel
-    float* out = p.dst + ((((size_t)ophase * p.n_tiles + ntile) * p.nchunk + chunk) * 16) * (WNB * WC) + (cc >> 2) * (WNB * 4) +
-                 nl * 4 + (cc & 3);
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) out[(a * 4 + b) * (WNB * WC)] = u[a][b];
-  }
+       idx += (long long)gridDim.x * blockDim.x)
+    wino_pack_item(p, idx);
 }
 
 static double conv_flops_of(const srgan_conv_desc* d) {
@@ -811,12 +727,18 @@ size_t wino_packed_bytes(const srgan_conv_desc* d, int kind) {
   return (size_t)phases * n_tiles * nchunk * 8192 * sizeof(float);
 }
 
-int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hipStream_t st) {
+void wino_pack_params(const srgan_conv_desc* d, int kind, const float* w, float* dst, WinoPackParams* out) {
   WinoPackParams q{};
   int C, N;
   wino_dims(d, kind, &C, &N, &q.n_tiles, &q.nchunk, &q.phases);
   q.variant = wino_variant(d, kind);
   q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW; q.N = N; q.C = C; q.kind = kind;
+  *out = q;
+}
+
+int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hipStream_t st) {
+  WinoPackParams q{};
+  wino_pack_params(d, kind, w, dst, &q);
   const long long total = (long long)q.phases * q.n_tiles * WNB * q.nchunk * WC;
   hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
   return check_launch("wino_pack_kernel");

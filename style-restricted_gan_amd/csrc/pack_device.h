@@ -1,0 +1,149 @@
+// Weight-repack bodies shared by the single-layer pack kernels and the multi-layer pack launch (one launch repacks every
+// cached operand of a network after its optimiser step).
+#pragma once
+#include "common.h"
+
+namespace srgan {
+
+// dst[phase][n][ (ty*Tx+tx)*Cs + c ], zero padded to [Npad][Kpad].
+//   mode 0: n = O index, c = I index, (ky,kx) = (ty,tx)
+//   mode 1: n = I index, c = O index, ky = (py+pad)%s + s*ty (zero if >= kh)
+struct PackParams {
+  const float* w;
+  float* dst;
+  long long sO, sI, sH, sW;
+  int O, I, kh, kw, mode, stride, pad, Ty, Tx, Cs, N, K, Kpad, Npad, phases;
+};
+
+__device__ __forceinline__ long long pack_weights_total(const PackParams& p) { return (long long)p.phases * p.Npad * p.Kpad; }
+
+__device__ __forceinline__ void pack_weights_item(const PackParams& p, long long idx) {
+  const int k = (int)(idx % p.Kpad);
+  const long long rest = idx / p.Kpad;
+  const int n = (int)(rest % p.Npad);
+  const int phase = (int)(rest / p.Npad);
+  float v = 0.f;
+  if (n < p.N && k < p.K) {
+    const int t = k / p.Cs, c = k - t * p.Cs;
+    const int ty = t / p.Tx, tx = t - ty * p.Tx;
+    if (p.mode == 0) {
+      v = p.w[n * p.sO + c * p.sI + ty * p.sH + tx * p.sW];
+    } else {
+      const int py = phase / p.stride, px = phase % p.stride;
+      const int ky = (py + p.pad) % p.stride + p.stride * ty;
+      const int kx = (px + p.pad) % p.stride + p.stride * tx;
+      if (ky < p.kh && kx < p.kw) v = p.w[c * p.sO + n * p.sI + ky * p.sH + kx * p.sW];
+    }
+  }
+  p.dst[idx] = v;
+}
+
+struct WinoPackParams {
+  const float* w;
+  float* dst;
+  long long sO, sI, sH, sW;
+  int N, C, kind, nchunk, n_tiles, variant, phases;
+};
+
+
+constexpr int WP_WNB = 64, WP_WC = 8;
+__device__ __forceinline__ long long wino_pack_total(const WinoPackParams& p) {
+  return (long long)p.n_tiles * WP_WNB * p.nchunk * WP_WC * p.phases;
+}
+
+__device__ __forceinline__ void wino_pack_item(const WinoPackParams& p, long long idx) {
+  constexpr int WNB = WP_WNB, WC = WP_WC;
+    // lanes run over (channel & 3, cout, channel half): the 16 stores of a wave-instruction are 256 contiguous bytes each
+    const int c4 = (int)(idx % 4);
+    long long r = idx / 4;
+    const int nl = (int)(r % WNB); r /= WNB;
+    const int cc = (int)(r % 2) * 4 + c4; r /= 2;
+    const int chunk = (int)(r % p.nchunk); r /= p.nchunk;
+    const int ntile = (int)(r % p.n_tiles);
+    const int ophase = (int)(r / p.n_tiles);
+    const int n = ntile * WNB + nl;
+    float u[4][4];
+    if (p.variant == 1) {
+      const int c = chunk * WC + cc;
+      float g[3][3];
+      const bool ok = n < p.N && c < p.C;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          float v = 0.f;
+          if (ok) v = p.kind == 0 ? p.w[n * p.sO + c * p.sI + ky * p.sH + kx * p.sW]
+                                  : p.w[c * p.sO + n * p.sI + (2 - ky) * p.sH + (2 - kx) * p.sW];
+          g[ky][kx] = v;
+        }
+      // G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+      float h[4][3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        h[0][kx] = g[0][kx];
+        h[1][kx] = 0.5f * (g[0][kx] + g[1][kx] + g[2][kx]);
+        h[2][kx] = 0.5f * (g[0][kx] - g[1][kx] + g[2][kx]);
+        h[3][kx] = g[2][kx];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        u[a][0] = h[a][0];
+        u[a][1] = 0.5f * (h[a][0] + h[a][1] + h[a][2]);
+        u[a][2] = 0.5f * (h[a][0] - h[a][1] + h[a][2]);
+        u[a][3] = h[a][2];
+      }
+    } else {
+      const int k = chunk * WC + cc;
+      int c, pp, qq;
+      if (p.kind == 0) { const int ph = k / p.C; c = k - ph * p.C; pp = ph >> 1; qq = ph & 1; }
+      else { c = k; pp = ophase >> 1; qq = ophase & 1; }
+      const bool ok = n < p.N && c < p.C && (p.kind == 1 || k < 4 * p.C);
+      float g[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float v = 0.f;
+          if (ok) v = p.kind == 0 ? p.w[n * p.sO + c * p.sI + (2 * a + pp) * p.sH + (2 * b + qq) * p.sW]
+                                  : p.w[c * p.sO + n * p.sI + (3 - 2 * a - pp) * p.sH + (3 - 2 * b - qq) * p.sW];
+          g[a][b] = v;
+        }
+      // A g A^T, A = [1 0; 1 1; 1 -1; 0 -1]
+      float h[4][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        h[0][b] = g[0][b];
+        h[1][b] = g[0][b] + g[1][b];
+        h[2][b] = g[0][b] - g[1][b];
+        h[3][b] = -g[1][b];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        u[a][0] = h[a][0];
+        u[a][1] = h[a][0] + h[a][1];
+        u[a][2] = h[a][0] - h[a][1];
+        u[a][3] = -h[a][1];
+      }
+    }
+    // within a position: [channel half][cout][4 channels] -- the register image of the kernel
+    float* out = p.dst + ((((size_t)ophase * p.n_tiles + ntile) * p.nchunk + chunk) * 16) * (WNB * WC) + (cc >> 2) * (WNB * 4) +
+                 nl * 4 + (cc & 3);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) out[(a * 4 + b) * (WNB * WC)] = u[a][b];
+}
+
+
+// one record of the multi-layer launch (host-built, copied to the device as an array)
+struct PackEntry {
+  int type;            // 0: implicit-GEMM operand, 1: Winograd filter transform
+  int reserved;
+  PackParams ig;
+  WinoPackParams wn;
+};
+
+// conv_wino.hip
+void wino_pack_params(const srgan_conv_desc* d, int kind, const float* w, float* dst, WinoPackParams* out);
+
+}  // namespace srgan

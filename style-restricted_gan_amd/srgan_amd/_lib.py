@@ -65,6 +65,9 @@ SIGNATURES = {
     "srgan_soft_histogram_fwd": (c_int, [P, c_longlong, c_int, c_float, c_float, c_float, P, P, c_size_t, P]),
     "srgan_soft_histogram_bwd": (c_int, [P, P, c_longlong, c_int, c_float, c_float, c_float, P, P]),
     "srgan_adam_multi": (c_int, [P, c_int, c_longlong, c_float, c_float, c_float, c_float, c_int, P]),
+    "srgan_pack_entry_bytes": (c_size_t, []),
+    "srgan_conv2d_pack_entry": (c_int, [POINTER(ConvDesc), c_int, c_int, P, P, P]),
+    "srgan_conv2d_pack_multi": (c_int, [P, c_int, P]),
     "srgan_set_compute_mode": (c_int, [c_int]),
     "srgan_get_compute_mode": (c_int, []),
     "srgan_preprocess_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -120,27 +120,35 @@ def _conv_ws(desc, device):
 
 # ---- packed-weight cache ---------------------------------------------------------------------------
 # The repacked weight operand of a conv depends only on (weight values, geometry, kind).  Inside a trainer step the
-# weights change only at optimiser steps, so the trainer turns the cache on for the duration of ``train()`` and
-# invalidates a network's entries after each of its optimiser steps.  Outside such a scope (plain module calls) every
-# call repacks: there is no way to see a raw-pointer or ``.data`` update of a parameter from here.
+# weights change only at optimiser steps, so the trainer turns the cache on for the duration of ``train()`` and, after
+# each optimiser step, re-packs every cached operand of that network in ONE launch (``refresh_packed``).  Entries persist
+# across ``train()`` calls; an entry is only trusted while the parameter's autograd version counter is unchanged (any
+# ordinary in-place update -- ``load_state_dict``, ``copy_`` -- bumps it; the raw-pointer Adam does not, which is why the
+# trainer refreshes explicitly).  Outside such a scope (plain module calls) every call repacks.
 _pack_cache_on = False
-_pack_cache = {}          # (id(weight), kind, act_flag, geometry) -> packed tensor
+_pack_cache = {}          # (id(weight), kind, act_flag, geometry) -> _Packed
+
+
+class _Packed:
+    __slots__ = ("buf", "weight", "desc", "kind", "act", "version", "fresh")
+
+    def __init__(self, buf, weight, desc, kind, act):
+        self.buf, self.weight, self.desc, self.kind, self.act = buf, weight, desc, kind, act
+        self.version, self.fresh = weight._version, True
 
 
 class pack_cache:
-    """Context manager: cache packed conv weights until ``invalidate_packed`` is called for their parameter."""
+    """Context manager: cache packed conv weights (see above)."""
 
     def __enter__(self):
         global _pack_cache_on
         self._prev = _pack_cache_on
         _pack_cache_on = True
-        _pack_cache.clear()
         return self
 
     def __exit__(self, *exc):
         global _pack_cache_on
         _pack_cache_on = self._prev
-        _pack_cache.clear()
         return False
 
 
@@ -151,6 +159,7 @@ def set_compute_dtype(name):
     mode = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[str(name).replace("torch.", "")]
     _lib.check(_lib.load().srgan_set_compute_mode(mode), "set_compute_mode")
     _pack_cache.clear()
+    _tables.clear()
 
 
 def get_compute_dtype():
@@ -158,28 +167,98 @@ def get_compute_dtype():
 
 
 def invalidate_packed(params=None):
+    """Forget cached operands (all, or those of ``params``): they are re-packed one by one at their next use."""
     if params is None:
         _pack_cache.clear()
+        _tables.clear()
         return
     ids = {id(p) for p in params}
     for key in [k for k in _pack_cache if k[0] in ids]:
         del _pack_cache[key]
+    _tables.clear()
+
+
+def mark_stale(params):
+    """The raw-pointer optimiser calls this after writing ``params``: their cached operands must be re-packed before the
+    next use (in one launch by ``refresh_packed``, else one by one)."""
+    if not _pack_cache:
+        return
+    ids = {id(p) for p in params}
+    for k, h in _pack_cache.items():
+        if k[0] in ids:
+            h.fresh = False
+
+
+def _pack_one(hit):
+    lib = _lib.load()
+    _lib.check(lib.srgan_conv2d_pack(ctypes.byref(hit.desc), hit.kind, hit.act, _ptr(hit.weight), _ptr(hit.buf), hit.buf.numel(),
+                                     _stream()), "conv2d_pack")
+    hit.version, hit.fresh = hit.weight._version, True
 
 
 def _packed(desc, weight, kind, act):
     key = (id(weight), kind, int(act != ACT_NONE), desc.N, desc.Hi, desc.Wi, desc.I, desc.O, desc.kh, desc.stride,
            desc.pad, desc.pad_mode)
     hit = _pack_cache.get(key)
-    if hit is None:
+    if hit is None or hit.weight is not weight:
         lib = _lib.load()
         nbytes = lib.srgan_conv2d_packed_bytes(ctypes.byref(desc), kind, act)
         if nbytes == 0:
             raise _lib.SrganHipError("conv2d pack: " + lib.srgan_last_error().decode())
-        hit = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-        _lib.check(lib.srgan_conv2d_pack(ctypes.byref(desc), kind, act, _ptr(weight), _ptr(hit), nbytes, _stream()),
-                   "conv2d_pack")
+        own = _lib.ConvDesc()
+        ctypes.memmove(ctypes.byref(own), ctypes.byref(desc), ctypes.sizeof(own))
+        hit = _Packed(torch.empty(nbytes, dtype=torch.uint8, device=weight.device), weight, own, kind, act)
         _pack_cache[key] = hit
-    return hit
+        _tables.clear()
+        _pack_one(hit)
+    elif not hit.fresh or hit.version != weight._version:
+        _pack_one(hit)
+    return hit.buf
+
+
+_tables = {}              # frozenset of parameter ids -> (entries, device table, singles)
+
+
+def refresh_packed(params):
+    """Re-pack every cached operand of ``params`` after their optimiser step: one multi-pack launch for the implicit-GEMM /
+    Winograd operands (device table built once per parameter set), single launches for the few narrow-output layers."""
+    if not _pack_cache_on:
+        return
+    params = list(params)
+    if not params:
+        return
+    lib = _lib.load()
+    tkey = frozenset(id(p) for p in params)
+    tab = _tables.get(tkey)
+    if tab is None:
+        ids = set(tkey)
+        hits = [h for k, h in _pack_cache.items() if k[0] in ids]
+        nb = lib.srgan_pack_entry_bytes()
+        multi, singles, blob = [], [], bytearray()
+        for h in hits:
+            rec = (ctypes.c_char * nb)()
+            rc = lib.srgan_conv2d_pack_entry(ctypes.byref(h.desc), h.kind, h.act, _ptr(h.weight), _ptr(h.buf), ctypes.byref(rec))
+            if rc == 0:
+                multi.append(h)
+                blob += bytes(rec)
+            elif rc == 1:
+                singles.append(h)
+            else:
+                _lib.check(rc, "conv2d_pack_entry")
+        dev = None
+        if multi:
+            host = torch.frombuffer(blob, dtype=torch.uint8).clone().pin_memory()
+            dev = host.to(params[0].device, non_blocking=True)
+            dev._srgan_host = host                 # keep the pinned source alive until the copy has run
+        tab = (multi, dev, singles)
+        _tables[tkey] = tab
+    multi, dev, singles = tab
+    if multi:
+        _lib.check(lib.srgan_conv2d_pack_multi(_ptr(dev), len(multi), _stream()), "conv2d_pack_multi")
+        for h in multi:
+            h.version, h.fresh = h.weight._version, True
+    for h in singles:
+        _pack_one(h)
 
 
 def _run_conv_fwd(desc, x, weight, bias, y, act, slope):

@@ -48,4 +48,5 @@ class Adam(torch.optim.Optimizer):
                 ops.adam_multi_step_(table, len(items), max(pd.numel() for pd, _, _, _ in items), group["lr"], b1, b2,
                                      group["eps"], step)
                 self._keep_alive = (host, table, items)     # until the next step: the launch reads them asynchronously
+            ops.mark_stale(group["params"])                  # parameters were written through raw pointers
         return loss

@@ -123,9 +123,9 @@ class SRGAN_training():
         return [p for g in opt.param_groups for p in g["params"]]
 
     def _step(self, opt):
-        """optimiser step + drop the packed copies of the weights it just changed"""
+        """optimiser step + one launch that re-packs the cached conv operands of the weights it just changed"""
         opt.step()
-        ops.invalidate_packed(self._opt_params(opt))
+        ops.refresh_packed(self._opt_params(opt))
 
     def _reduce_start(self, name, opt):
         if not dp.is_distributed():
