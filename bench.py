@@ -109,6 +109,59 @@ def pmc_traffic(kernel_name):
         return None
 
 
+GD_GFLOP_PER_IMAGE = {128: 60.54, 256: 243.86}        # (3 F_G - f_G) + (3 F_D - f_D), SURVEY.md 8d
+
+
+def micro_gd(args):
+    """One generator forward + full backward and one discriminator forward + full backward on a batch of 32 (inputs do not
+    require gradients, so the first-layer input gradients are skipped, as in the SURVEY formula).  Single GPU."""
+    from srgan_amd import _lib, model, ops
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    device = torch.device("cuda", 0)
+    _lib.load()
+    if args.dtype == "bf16":
+        ops.set_compute_dtype("bf16")
+    torch.manual_seed(0)
+    B, S = args.batch_per_gpu, args.size
+    G = model.SingleGenerator(3, 64, 2, 2, 6, "instance", num_con=12).to(device)
+    D = model.SingleDiscriminator_solo_multi(3, 64, 2, 4 if S == 128 else 5, "instance", 4).to(device)
+    x = (torch.rand(B, 3, S, S, device=device) * 2 - 1)
+    c = torch.cat([torch.eye(4, device=device)[torch.randint(0, 4, (B,), device=device)], torch.randn(B, 8, device=device)], 1)
+
+    def step():
+        for p in list(G.parameters()) + list(D.parameters()):
+            p.grad = None
+        with ops.pack_cache():
+            G(x, c).square().mean().backward()
+            outs, cls = D(x)
+            (sum(o.square().mean() for o in outs) + sum(q.square().mean() for q in cls)).backward()
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    gf = GD_GFLOP_PER_IMAGE.get(S)
+    value = B / dt
+    peak = PEAK_TFLOPS["f32" if args.dtype == "f32" else "bf16"]
+    tf = value * gf / 1e3 if gf else None
+    print(json.dumps({
+        "metric": f"images/sec G+D forward-backward, {S}x{S} bs={B} (micro-benchmark, SURVEY 8d)", "value": round(value, 2),
+        "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt, 3),
+        "higher_is_better": True, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "one G forward + backward and one D forward + backward (all parameter gradients), default PyTorch "
+                               "init, first-layer input gradients skipped", "gflop_per_image_algorithmic": gf},
+        "roofline": {"bound": "mfma", "achieved": round(tf, 2) if tf else None, "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(tf / peak, 4) if tf else None,
+                     "note": "whole micro-benchmark: algorithmic FLOPs (SURVEY 8d) x images/s against the dense MFMA peak of the "
+                             "dtype; includes norm / pointwise / reduction kernels; Winograd layers execute 2.25x fewer MFMA FLOPs "
+                             "than counted, so the algorithmic fraction can exceed 1"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,7 +173,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 (default, BASELINE configs[1]) or the bf16 MFMA compute mode of configs [2]-[4] (never the headline)")
+    ap.add_argument("--micro", choices=["gd"], default=None,
+                    help="gd: the 'G+D forward-backward' micro-benchmark of SURVEY.md 8d (north_star's >= 70 %% MFMA-roofline target) "
+                         "instead of the full train step")
     args = ap.parse_args()
+    if args.micro == "gd":
+        return micro_gd(args)
 
     from srgan_amd import _lib, dp
     rank, world, device = dp.init_from_env()
