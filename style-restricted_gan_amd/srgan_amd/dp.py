@@ -91,25 +91,42 @@ def all_gather_rows(x):
     return _AllGatherRows.apply(x) if is_distributed() else x
 
 
-BUCKET_BYTES = 64 << 20   # per all-reduce message; xGMI ring all-reduce is per-link bound (~153 GB/s)
+BUCKET_BYTES = 16 << 20   # per all-reduce message: several buckets per network, so the first ones run under the backward
 
 
 class GradReducer:
     """Averages ``.grad`` of a parameter list across ranks with bucketed all-reduce on a side stream.
 
-    ``start()`` enqueues the collectives (after the producing backward, in stream order) and returns
-    immediately; ``finish()`` makes the compute stream wait for them and scatters the averaged values back.
-    Parameters whose grad is None on this rank take part with zeros so every rank issues the same calls.
+    ``arm()`` before the backward: every parameter carries a post-accumulate-grad hook, and a bucket's all-reduce is
+    enqueued on the side stream the moment its last gradient is final -- so the collectives of the layers near the loss
+    run under the backward conv stack of the layers below them (buckets are filled in reverse parameter order, the order
+    in which autograd finishes them).  ``start()`` after the backward enqueues whatever is left (parameters without a
+    gradient take part with zeros so every rank issues the same calls) and returns immediately; ``finish()`` makes the
+    compute stream wait for the collectives and scatters the averaged values back.  Without ``arm()`` everything is
+    enqueued by ``start()``.
     """
 
     def __init__(self, params):
         self.params = [p for p in params]
         self._pending = None
         self._comm_stream = None
+        self._armed = False
+        self._buckets_cache = self._buckets()
+        self._where = {}
+        for b, bucket in enumerate(self._buckets_cache):
+            for p in bucket:
+                self._where[id(p)] = b
+        self._count = [0] * len(self._buckets_cache)
+        self._launched = [False] * len(self._buckets_cache)
+        self._work = []
+        if hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+            for p in self.params:
+                if p.requires_grad:
+                    p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _buckets(self):
         buckets, cur, size = [], [], 0
-        for p in self.params:
+        for p in reversed(self.params):               # gradients become final roughly in reverse parameter order
             nbytes = p.numel() * 4
             if cur and size + nbytes > BUCKET_BYTES:
                 buckets.append(cur)
@@ -120,27 +137,52 @@ class GradReducer:
             buckets.append(cur)
         return buckets
 
+    def arm(self):
+        if not is_distributed() or not self.params:
+            return
+        self._armed = True
+        self._count = [0] * len(self._buckets_cache)
+        self._launched = [False] * len(self._buckets_cache)
+        self._work = []
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        b = self._where[id(p)]
+        self._count[b] += 1
+        if self._count[b] == sum(1 for q in self._buckets_cache[b] if q.requires_grad) and not self._launched[b]:
+            self._launch(b)
+
+    def _launch(self, b):
+        bucket = self._buckets_cache[b]
+        on_gpu = self.params[0].is_cuda
+        if on_gpu and self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        if on_gpu:
+            # the side stream must see the flattened bucket (and the backward kernels that produced it) complete
+            self._comm_stream.wait_stream(torch.cuda.current_stream())
+            flat.record_stream(self._comm_stream)
+            with torch.cuda.stream(self._comm_stream):
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        self._launched[b] = True
+        self._work.append((bucket, flat))
+
     def start(self):
         if not is_distributed() or not self.params:
             return
-        ws = dist.get_world_size()
-        on_gpu = self.params[0].is_cuda
-        work = []
-        if on_gpu and self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream()
-        for bucket in self._buckets():
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            if on_gpu:
-                # the side stream must see the flattened bucket (and the backward that produced it) complete
-                self._comm_stream.wait_stream(torch.cuda.current_stream())
-                flat.record_stream(self._comm_stream)
-                with torch.cuda.stream(self._comm_stream):
-                    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            else:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            work.append((bucket, flat))
-        self._pending = (work, ws)
+        if not self._armed:
+            self._launched = [False] * len(self._buckets_cache)
+            self._work = []
+        self._armed = False
+        for b in range(len(self._buckets_cache)):      # same order on every rank
+            if not self._launched[b]:
+                self._launch(b)
+        self._pending = (self._work, dist.get_world_size())
+        self._work = []
 
     def finish(self):
         if self._pending is None:

@@ -127,12 +127,21 @@ class SRGAN_training():
         opt.step()
         ops.refresh_packed(self._opt_params(opt))
 
-    def _reduce_start(self, name, opt):
-        if not dp.is_distributed():
-            return None
+    def _reducer(self, name, opt):
         red = self._reducers.get(name)
         if red is None:
             red = self._reducers[name] = dp.GradReducer(self._opt_params(opt))
+        return red
+
+    def _reduce_arm(self, name, opt):
+        """before the backward whose gradients `opt` will consume: buckets are all-reduced as they complete"""
+        if dp.is_distributed():
+            self._reducer(name, opt).arm()
+
+    def _reduce_start(self, name, opt):
+        if not dp.is_distributed():
+            return None
+        red = self._reducer(name, opt)
         red.start()
         return red
 
@@ -220,6 +229,7 @@ class SRGAN_training():
             errD_real, errD_class = self._d_losses(self.source_image, 1., "source", True)
             errD_fake, _ = self._d_losses(self.target_image.detach(), 0., None, False)
         errD = errD_real + errD_class * self.lbd["class"] + errD_fake
+        self._reduce_arm("D", self.optD)
         errD.backward()
         red = self._reduce_start("D", self.optD)
         nxt = _next_fake() if _next_fake is not None else None      # optional work to overlap with the all-reduce
@@ -297,6 +307,8 @@ class SRGAN_training():
                 terms.update(errE_bKL=parts[0], errE_corr=parts[1], errE_hist=parts[2])
 
             total_p1 = errG + errE if torch.is_tensor(errE) else errG
+            self._reduce_arm("G", self.optG)
+            self._reduce_arm("E", self.optE)
             total_p1.backward(retain_graph=True)         # target_image's graph is needed again in phase 2
         redG = self._reduce_start("G", self.optG)
         redE = self._reduce_start("E", self.optE)
@@ -339,6 +351,7 @@ class SRGAN_training():
                     errG_idt_reg = ops.l1_mean(source_c_rand, idt_cenc_rand, 1.0)
                     errG_ex = errG_ex + errG_idt_reg * (L["idt_reg"] * (L["idt"] / L["cycle"]))
                     terms["errG_idt_reg"] = errG_idt_reg
+            self._reduce_arm("G", self.optG)
             errG_ex.backward()
         redG = self._reduce_start("G", self.optG)
         if redG is not None:

@@ -53,6 +53,23 @@ def _worker(rank, world, port, out):
     assert torch.allclose(params[1].grad, torch.arange(12.0).view(3, 4) * 1.5)
     assert torch.allclose(params[2].grad, torch.full((7,), 0.5))
 
+    # 1b. armed reducer: buckets are all-reduced from the post-accumulate-grad hooks DURING the backward (last layer first);
+    #     a parameter that gets no gradient leaves its bucket to start()
+    dp.BUCKET_BYTES = 64
+    w1, w2, w3, unused = (torch.nn.Parameter(torch.full((6,), 0.5)), torch.nn.Parameter(torch.full((20,), 0.25)),
+                          torch.nn.Parameter(torch.full((6,), 2.0)), torch.nn.Parameter(torch.ones(4)))
+    red = dp.GradReducer([w1, w2, w3, unused])
+    red.arm()
+    xin = torch.arange(6.0) * (rank + 1)
+    ((w1 * xin).sum() * w3.sum() + (w2 ** 2).sum() * (rank + 1)).backward()
+    assert len(red._work) >= 2 and not all(red._launched)       # w1/w2/w3 buckets went out from the hooks, `unused` did not
+    local = [p.grad.clone() if p.grad is not None else None for p in (w1, w2, w3)]
+    red.start()
+    red.finish()
+    assert torch.allclose(w1.grad, torch.arange(6.0) * 1.5 * 12.0) and torch.allclose(w2.grad, torch.full((20,), 0.5 * 1.5))
+    assert torch.allclose(w3.grad, torch.full((6,), 0.5 * 15.0 * 1.5)) and torch.allclose(unused.grad, torch.zeros(4))
+    assert not torch.allclose(local[0], w1.grad)
+
     # 2. all_gather_rows forward / backward
     x = (torch.arange(6.0).view(3, 2) + 10 * rank).requires_grad_(True)
     g = dp.all_gather_rows(x)
