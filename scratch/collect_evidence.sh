@@ -12,6 +12,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $E/fetch -- pyt
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $E/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $E/write.err || exit 1
 echo "write done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $E/mfma -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $E/mfma.err || exit 1
+echo "mfma done"
 # keep the merge-back small: counter CSVs only (traces of the PMC passes are large)
-find $E/fetch $E/write -name "*kernel_trace.csv" -delete
+find $E/fetch $E/write $E/mfma -name "*kernel_trace.csv" -delete
 find $E/stats -name "*kernel_trace.csv" -delete

@@ -10,7 +10,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 
 def prof_name(n):
     n = n.replace("void ", "").replace("srgan::", "")
-    m = re.match(r"igemm_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)>", n)
+    m = re.match(r"igemm_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (?:true|false))?>", n)
     if m:
         return "igemm_kernel<%s,%s,%s,%s,%s>" % (*m.groups()[:4], "vec" if m.group(5) == "true" else "gen")
     m = re.match(r"wgrad_kernel<\d+, \d+, \d+, \d+, (true|false)", n)
@@ -53,6 +53,20 @@ for k in sorted(fetch):
     out["kernels"][k] = {"launches": len(fetch[k]), "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
                          "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
 json.dump(out, open(os.path.join(root, "profiles", tag.split("_")[0] + "_pmc_traffic.json"), "w"), indent=1)
+
+# matrix-pipe utilisation per GEMM kernel: SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs (= 64 x #MFMA for the fp32
+# 32x32x2 instruction); GRBM_GUI_ACTIVE is summed over the 8 XCDs, so GUI/8 is the kernel's length in shader cycles
+if glob.glob(os.path.join(ev, "mfma", "*", "*counter_collection.csv")):
+    busy, gui = counter("mfma", "SQ_VALU_MFMA_BUSY_CYCLES"), counter("mfma", "GRBM_GUI_ACTIVE")
+    util = {"_doc": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over `python3 bench.py --steps 2 --warmup 1 "
+                    "--no-cpu-baseline`; per kernel: sum over launches of MFMA busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8). "
+                    "Launches shorter than ~0.3 ms over-count GUI cycles (MI355X_MICROARCH.md, DVFS), so small kernels read low.",
+            "kernels": {}}
+    for k in sorted(busy):
+        b, g = sum(busy[k]), sum(gui[k])
+        util["kernels"][k] = {"launches": len(busy[k]), "mfma_busy_cycles": int(b), "gui_active": int(g),
+                              "mfma_utilisation": round(b / (1024.0 * g / 8.0), 4) if g else None}
+    json.dump(util, open(os.path.join(root, "profiles", tag.split("_")[0] + "_pmc_mfma.json"), "w"), indent=1)
 stats = newest(os.path.join(ev, "stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(root, "profiles", tag + "_bench_steps5_kernel_stats.csv"))
 for src, dst in (("bench_plain.json", tag + "_bench_steps5.json"), ("bench_under_rocprof.json", tag + "_bench_steps5_under_rocprof.json")):
