@@ -124,17 +124,18 @@ def _conv_ws(desc, device):
 # each optimiser step, re-packs every cached operand of that network in ONE launch (``refresh_packed``).  Entries persist
 # across ``train()`` calls; an entry is only trusted while the parameter's autograd version counter is unchanged (any
 # ordinary in-place update -- ``load_state_dict``, ``copy_`` -- bumps it; the raw-pointer Adam does not, which is why the
-# trainer refreshes explicitly).  Outside such a scope (plain module calls) every call repacks.
+# trainer refreshes explicitly), and everything is re-packed once when a scope is entered.  Outside such a scope (plain
+# module calls) every call repacks.
 _pack_cache_on = False
 _pack_cache = {}          # (id(weight), kind, act_flag, geometry) -> _Packed
 
 
 class _Packed:
-    __slots__ = ("buf", "weight", "desc", "kind", "act", "version", "fresh")
+    __slots__ = ("buf", "weight", "desc", "kind", "act", "version", "fresh", "ptr")
 
     def __init__(self, buf, weight, desc, kind, act):
         self.buf, self.weight, self.desc, self.kind, self.act = buf, weight, desc, kind, act
-        self.version, self.fresh = weight._version, True
+        self.version, self.fresh, self.ptr = weight._version, True, weight.data_ptr()
 
 
 class pack_cache:
@@ -144,6 +145,10 @@ class pack_cache:
         global _pack_cache_on
         self._prev = _pack_cache_on
         _pack_cache_on = True
+        if not self._prev and _pack_cache:
+            # entries persist between scopes; a ``.data`` update made outside (no version bump) would go unseen, so the
+            # whole cache is re-packed on entry -- one multi-pack launch
+            refresh_packed([h.weight for h in _pack_cache.values()])
         return self
 
     def __exit__(self, *exc):
@@ -194,6 +199,9 @@ def _pack_one(hit):
     _lib.check(lib.srgan_conv2d_pack(ctypes.byref(hit.desc), hit.kind, hit.act, _ptr(hit.weight), _ptr(hit.buf), hit.buf.numel(),
                                      _stream()), "conv2d_pack")
     hit.version, hit.fresh = hit.weight._version, True
+    if hit.ptr != hit.weight.data_ptr():       # storage swapped under the parameter (``p.data = ...``): tables hold the old pointer
+        hit.ptr = hit.weight.data_ptr()
+        _tables.clear()
 
 
 def _packed(desc, weight, kind, act):
@@ -211,7 +219,7 @@ def _packed(desc, weight, kind, act):
         _pack_cache[key] = hit
         _tables.clear()
         _pack_one(hit)
-    elif not hit.fresh or hit.version != weight._version:
+    elif not hit.fresh or hit.version != weight._version or hit.ptr != weight.data_ptr():
         _pack_one(hit)
     return hit.buf
 
@@ -253,6 +261,11 @@ def refresh_packed(params):
         tab = (multi, dev, singles)
         _tables[tkey] = tab
     multi, dev, singles = tab
+    if any(h.ptr != h.weight.data_ptr() for h in multi):       # a parameter's storage moved: rebuild the table next time
+        _tables.pop(tkey, None)
+        for h in multi + singles:
+            _pack_one(h)
+        return
     if multi:
         _lib.check(lib.srgan_conv2d_pack_multi(_ptr(dev), len(multi), _stream()), "conv2d_pack_multi")
         for h in multi:

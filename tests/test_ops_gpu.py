@@ -412,3 +412,31 @@ def test_no_cpu_fallback(ops):
     from srgan_amd._lib import SrganHipError
     with pytest.raises(SrganHipError):
         ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))
+
+
+def test_pack_cache_never_serves_a_stale_operand(ops):
+    """The packed-weight cache persists between ``pack_cache`` scopes: version-bumping updates, raw ``.data`` updates made
+    outside a scope, swapped storage and an explicit ``refresh_packed`` must all be seen."""
+    x = rnd(2, 64, 12, 12, seed=1).cuda()
+    w = torch.nn.Parameter((rnd(64, 64, 3, 3, seed=2) / 24).cuda())
+
+    def conv():
+        with torch.no_grad():
+            return ops.conv2d(x, w, None, 1, 1).clone()
+
+    def ref():
+        return F.conv2d(x.cpu(), w.detach().cpu(), None, 1, 1)
+
+    with ops.pack_cache():
+        close(conv(), ref())
+        with torch.no_grad():
+            w.mul_(2.0)                      # version bump inside the scope
+        close(conv(), ref())
+        w.data.add_(0.01)                    # raw update: only an explicit refresh can see it
+        ops.refresh_packed([w])
+        close(conv(), ref())
+    w.data.mul_(0.5)                         # raw update between scopes: re-packed on entry
+    with ops.pack_cache():
+        close(conv(), ref())
+        w.data = (w.data * 3.0).clone()      # storage swapped under the parameter
+        close(conv(), ref())
