@@ -109,6 +109,47 @@ def test_dp_world_size_2_gloo():
         assert err <= 1e-5 * scale, (rank, err, scale)
 
 
+def _worker4(rank, world, port, out):
+    """world_size 4: the armed (backward-overlapped) reducer on the toy encoder, 2 of the 8 samples per rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from srgan_amd import dp
+    dp.init_from_env("gloo")
+    dp.BUCKET_BYTES = 64
+    gen = torch.Generator().manual_seed(0)
+    X = torch.randn(8, 5, generator=gen)
+    theta0, bias0 = torch.randn(5, 8, generator=gen) * 0.5, torch.randn(8, generator=gen) * 0.1
+    theta, bias = torch.nn.Parameter(theta0.clone()), torch.nn.Parameter(bias0.clone())
+    red = dp.GradReducer([theta, bias])
+    red.arm()
+    n = 8 // world
+    _toy_losses(theta, bias, X[n * rank:n * rank + n], 8, dp.all_gather_rows, float(world)).backward()
+    red.start()
+    red.finish()
+    t1, b1 = theta0.clone().requires_grad_(True), bias0.clone().requires_grad_(True)
+    _toy_losses(t1, b1, X, 8, lambda m: m, 1.0).backward()
+    err = max(float((theta.grad - t1.grad).abs().max()), float((bias.grad - b1.grad).abs().max()))
+    out.put((rank, err, float(t1.grad.abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_world_size_4_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, out)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in res) == [0, 1, 2, 3]
+    for rank, err, scale in res:
+        assert err <= 1e-5 * scale, (rank, err, scale)
+
+
 def test_single_process_is_a_no_op():
     from srgan_amd import dp
     assert not dp.is_distributed() and dp.world_size() == 1 and dp.rank() == 0
