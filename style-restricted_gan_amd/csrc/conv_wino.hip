@@ -1,18 +1,26 @@
-// Winograd F(2x2, 3x3) convolution for the 3x3 / stride-1 layers (the generator's residual trunk is 64 % of the
-// step's FLOPs: SURVEY.md section 8a row a2, reference pyfiles/model.py:196-201), fp32 on the exact-fp32 MFMA.
+// Winograd convolutions on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
 //
-//   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//   F(2x2,3x3) for the 3x3 / stride-1 layers (the generator's residual trunk is 64 % of the step's FLOPs: SURVEY.md
+//   section 8a row a2, reference pyfiles/model.py:196-201; the encoder's 3x3 convs, model.py:433-437):
+//       Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//   F(3x3,2x2), its transpose, for the 4x4 / stride-2 layers and their transposed convs (model.py:212-215, 227-230,
+//   302-309), written as sums over input phases / one problem per output phase (MODE 1 / 2 below):
+//       Y = G^T [ sum (A g A^T) .* (B^T d B) ] G        per 3x3 output tile, 4x4 patch of a phase image, 2x2 filter
+//   16 multiplies per 4 (9) outputs instead of 36: 2.25x fewer MFMA FLOPs than the implicit GEMM, every product still
+//   an exact fp32 product.
 //
-// 16 multiplies per 4 outputs instead of 36: 2.25x fewer MFMA FLOPs than the implicit GEMM.  One fused kernel:
-//   * the filter transform U = G g G^T is done once per optimiser step by the pack kernel (layout below),
-//   * a workgroup (8 waves) owns 64 output tiles x 64 output channels for ALL 16 transform positions;
-//     per 8-channel chunk each thread gathers one (tile, channel) 4x4 patch from NHWC global memory, transforms it
-//     in registers (32 adds) and writes the 16 results to LDS; the chunk of U (32 KB, contiguous) is copied to LDS,
-//   * wave w multiplies positions 2w, 2w+1: [64 tiles x 8] x [8 x 64 channels] on v_mfma_f32_32x32x2_f32,
-//     LDS double-buffered, one barrier per chunk, global loads issued two chunks ahead,
-//   * epilogue: the 16 position accumulators meet in LDS (two halves of 32 channels), each thread applies A^T . A
-//     and stores 2x2 pixels x 32 contiguous channels.
-// The same kernel serves the input gradient (flipped / transposed filter in the pack kernel, pad' = 2 - pad + ...).
+// One fused kernel per direction:
+//   * the filter transform is done once per optimiser step by the pack kernel (pack_device.h), laid out as the register
+//     image a wave loads: position p of U is consumed by exactly one wave, so U never touches LDS,
+//   * a workgroup (8 waves) owns 64 output tiles x 64 output channels for ALL 16 transform positions; per 8-channel chunk
+//     each thread gathers one (tile, channel) 4x4 patch with buffer loads (out-of-image taps point past the buffer: the
+//     range check supplies the zero padding), transforms it in registers (32 adds) and writes the 16 results to LDS,
+//   * wave w multiplies positions 2w, 2w+1: [64 tiles x 8] x [8 x 64 channels]; LDS double-buffered, one barrier per
+//     chunk, global loads a chunk ahead; the two waves of a SIMD run their non-MFMA work at different points of the
+//     iteration, in straight-line bodies (see the comment in the kernel),
+//   * epilogue: the 16 position accumulators meet in LDS (two halves of 32 channels), each thread applies the output
+//     transform and stores its tile x 32 contiguous channels (+ bias, activation).
+// wino_kernel<0/1/2>: forward and input gradient; wino_wgrad_kernel<0/1>: weight gradient (both operands transformed).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
