@@ -99,6 +99,7 @@ struct IgemmParams {
   int Hg, Wg;          // destination grid per phase
   int Hd, Wd, Cd;      // destination tensor
   int mode, stride, pad;
+  int xpad_off;        // mode 0: the column origin is b*stride - pad + xpad_off (0, or +pad for the 7x1 row convolution)
   int Ty, Tx;          // taps per phase
   int K, Kpad, Npad;
   int reflect;
@@ -110,6 +111,11 @@ struct IgemmParams {
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
+
+// defined with the forward / input-gradient dispatch below, needed by the workspace query
+static bool rowconv_applicable(const srgan_conv_desc* d);
+static size_t rowconv_packed_elems(const srgan_conv_desc* d);
+static bool narrow_dgrad_desc(const srgan_conv_desc* d, srgan_conv_desc* f, long long* w_off);
 
 // BF = bf16 MFMA compute (BASELINE configs [2]-[4]): operands are rounded to bf16 (RNE) when the tile is written to LDS and
 // multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; HBM tensors, the gather and the epilogue stay fp32.
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
       int rem = m - n * (p.Hg * p.Wg);
       int a = rem / p.Wg, b = rem - a * p.Wg;
       if (p.mode == 0) {
-        y0 = a * s - p.pad; x0 = b * s - p.pad;
+        y0 = a * s - p.pad; x0 = b * s - p.pad + p.xpad_off;
         o = (n * p.Hd + a) * p.Wd + b;
       } else {
         int oy = a * s + py, ox = b * s + px;
@@ -1114,6 +1120,12 @@ size_t pack_bytes(const srgan_conv_desc* d) {
   const long long Kd = round_up((long long)Ty * Tx * d->O, BK);
   const long long g = (long long)s * s * round_up(d->I, 128) * Kd;
   size_t bytes = (size_t)((f > g ? f : g) * sizeof(float));
+  if (rowconv_applicable(d)) bytes = std::max(bytes, rowconv_packed_elems(d) * sizeof(float));
+  {
+    srgan_conv_desc f;
+    long long w_off;
+    if (narrow_dgrad_desc(d, &f, &w_off) && rowconv_applicable(&f)) bytes = std::max(bytes, rowconv_packed_elems(&f) * sizeof(float));
+  }
   if (wino_applicable(d, 0)) bytes = std::max(bytes, wino_packed_bytes(d, 0));
   if (wino_applicable(d, 1)) bytes = std::max(bytes, wino_packed_bytes(d, 1));
   return bytes;
@@ -1141,12 +1153,76 @@ extern "C" size_t srgan_conv2d_workspace(const srgan_conv_desc* d) {
 
 namespace srgan {
 // ---- forward: which kernel family serves this layer, and the packed-weight layout it wants ----
-enum FwdPath { PATH_IGEMM = 0, PATH_NARROW = 1, PATH_WAVE = 2, PATH_DENSE = 3, PATH_WINO = 4 };
+enum FwdPath { PATH_IGEMM = 0, PATH_NARROW = 1, PATH_WAVE = 2, PATH_DENSE = 3, PATH_WINO = 4, PATH_ROWCONV = 5 };
+
+// ---- 3-channel 7x7 heads (the generator's RGB output layer, model.py:232, and the input gradient of its 7x7 RGB input
+// layer, model.py:212) on the matrix pipe.  With Cout = 3 a 32-wide MFMA tile would be 90 % padding, so the layer is split:
+//   P[b][y][x'][(co, kx)] = sum_{ky, c} x[b][y + ky - pad][x'][c] * w[co][c][ky][kx]     -- a 7x1 conv with 21 (-> 32) outputs
+//   y[b][y][x][co]        = bias[co] + sum_kx P[b][y][x + kx - pad][(co, kx)]             -- a shift-add over 7 columns
+// The first is the ordinary implicit GEMM (N tile 32, 66 % useful), the second a memory-bound pass over P (21 floats per pixel,
+// kept behind the packed weights).  1.3x faster than the VALU kernel of conv_narrow.hip on the 128x128 maps (230 vs 305 us at
+// batch 32; the N = 32 tile runs at 74 TFLOP/s executed -- a 256x32 tile with 64x32 wave tiles was tried and was slower).
+static bool rowconv_applicable(const srgan_conv_desc* d) {
+  static const bool off = std::getenv("SRGAN_NO_ROWCONV") != nullptr;
+  return !off && d->O == 3 && d->kh == 7 && d->kw == 7 && d->stride == 1 && d->pad_mode == SRGAN_PAD_ZERO && (d->I % BK) == 0 &&
+         d->Wo >= 64 && d->Ho >= 8 && (long long)d->N * d->Ho * d->Wi * 21 < (1LL << 30);
+}
+constexpr int RC_N = 21, RC_NPAD = 32;
+static size_t rowconv_weight_elems(const srgan_conv_desc* d) { return (size_t)RC_NPAD * d->kh * d->I; }
+static size_t rowconv_packed_elems(const srgan_conv_desc* d) {
+  return round_up((long long)rowconv_weight_elems(d), 64) + (size_t)d->N * d->Ho * d->Wi * RC_N;
+}
+
+// wp[n = co*7 + kx][k = ky*I + c] = w[co][c][ky][kx], rows 21..31 zero
+__global__ void rowconv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, long long sO, long long sI, long long sH,
+                                    long long sW, int I, int kh, int kw) {
+  const int K = kh * I, total = RC_NPAD * K;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int k = idx % K, n = idx / K;
+    const int ky = k / I, c = k - ky * I;
+    const int co = n / kw, kx = n - co * kw;
+    wp[idx] = n < RC_N ? w[co * sO + c * sI + ky * sH + kx * sW] : 0.f;
+  }
+}
+
+// y[pix][co] = bias[co] + sum_kx P[row, x + kx - pad][co*7 + kx]
+__global__ void rowconv_shift_add_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ y,
+                                         long long rows, int Wi, int Wo, int pad) {
+  const long long total = rows * Wo;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % Wo);
+    const long long row = idx / Wo;
+    const float* pr = P + row * Wi * RC_N;
+    float a0 = bias ? bias[0] : 0.f, a1 = bias ? bias[1] : 0.f, a2 = bias ? bias[2] : 0.f;
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      const int xs = x + kx - pad;
+      if ((unsigned)xs < (unsigned)Wi) {
+        const float* q = pr + (size_t)xs * RC_N + kx;
+        a0 += q[0];
+        a1 += q[7];
+        a2 += q[14];
+      }
+    }
+    float* o = y + idx * 3;
+    o[0] = a0; o[1] = a1; o[2] = a2;
+  }
+}
+
+static int rowconv_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st) {
+  const int total = RC_NPAD * d->kh * d->I;
+  hipLaunchKernelGGL(rowconv_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, dst, d->sO, d->sI, d->sH, d->sW, d->I,
+                     d->kh, d->kw);
+  return check_launch("rowconv_pack_kernel");
+}
+
 
 static FwdPath fwd_path(const srgan_conv_desc* d, int act) {
   if (act == SRGAN_ACT_NONE) {
     if (dense_head_applicable(d)) return PATH_DENSE;
     if (narrow_wave_applicable(d)) return PATH_WAVE;
+    if (rowconv_applicable(d)) return PATH_ROWCONV;
     if (narrow_applicable(d)) return PATH_NARROW;
   }
   if (wino_applicable(d, 0)) return PATH_WINO;      // bias / activation fused in its epilogue too
@@ -1166,6 +1242,7 @@ static void fwd_geometry(const srgan_conv_desc* d, FwdPath path, IgemmParams& p)
 static size_t fwd_packed_bytes(const srgan_conv_desc* d, int act) {
   const FwdPath path = fwd_path(d, act);
   if (path == PATH_NARROW) return (size_t)d->I * d->kh * d->kw * 4 * sizeof(float);
+  if (path == PATH_ROWCONV) return rowconv_packed_elems(d) * sizeof(float);
   if (path == PATH_WINO) return wino_packed_bytes(d, 0);
   IgemmParams p{};
   fwd_geometry(d, path, p);
@@ -1185,6 +1262,7 @@ static PackParams fwd_pack_params(const srgan_conv_desc* d, FwdPath path, const 
 static int fwd_pack(const srgan_conv_desc* d, int act, const float* w, float* dst, hipStream_t st) {
   const FwdPath path = fwd_path(d, act);
   if (path == PATH_NARROW) return narrow_pack(d, w, dst, st);
+  if (path == PATH_ROWCONV) return rowconv_pack(d, w, dst, st);
   if (path == PATH_WINO) return wino_pack(d, 0, w, dst, st);
   const PackParams q = fwd_pack_params(d, path, w, dst);
   long long total = (long long)q.Npad * q.Kpad;
@@ -1192,9 +1270,29 @@ static int fwd_pack(const srgan_conv_desc* d, int act, const float* w, float* ds
   return check_launch("pack_weights_kernel");
 }
 
+// `packed` = [32 x 7*I weights | P scratch]
+static int rowconv_run(const srgan_conv_desc* d, const float* x, const float* packed, const float* bias, float* y, hipStream_t st) {
+  float* P = const_cast<float*>(packed) + round_up((long long)rowconv_weight_elems(d), 64);
+  IgemmParams p{};
+  p.src = x; p.wp = packed; p.bias = nullptr; p.dst = P;
+  p.NB = d->N; p.Hs = d->Hi; p.Ws = d->Wi; p.Cs = d->I;
+  p.Hg = d->Ho; p.Wg = d->Wi; p.Hd = d->Ho; p.Wd = d->Wi; p.Cd = RC_N;
+  p.mode = 0; p.stride = 1; p.pad = d->pad; p.xpad_off = d->pad;      // rows padded, columns not
+  p.Ty = d->kh; p.Tx = 1;
+  p.K = d->kh * d->I; p.Kpad = p.K; p.Npad = RC_NPAD;
+  p.M = d->N * d->Ho * d->Wi;
+  p.reflect = 0; p.act = SRGAN_ACT_NONE; p.slope = 0.f;
+  if (int e = run_igemm(p, 1, st, conv_flops(d))) return e;
+  const long long rows = (long long)d->N * d->Ho, total = rows * d->Wo;
+  hipLaunchKernelGGL(rowconv_shift_add_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 16384)), dim3(256), 0, st,
+                     (const float*)P, bias, y, rows, d->Wi, d->Wo, d->pad);
+  return check_launch("rowconv_shift_add_kernel");
+}
+
 static int fwd_run(const srgan_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act,
                    float slope, hipStream_t st) {
   const FwdPath path = fwd_path(d, act);
+  if (path == PATH_ROWCONV) return rowconv_run(d, x, wp, bias, y, st);
   if (path == PATH_NARROW) return narrow_fwd_packed(d, x, wp, bias, y, st);
   if (path == PATH_WINO) return wino_run(d, 0, x, wp, bias, y, act, slope, st);
   IgemmParams p{};
@@ -1246,7 +1344,7 @@ static DgradGeom dgrad_geometry(const srgan_conv_desc* d) {
   srgan_conv_desc f;
   long long w_off;
   g.narrow = !g.wino && narrow_dgrad_desc(d, &f, &w_off);
-  if (g.narrow) g.packed_elems = (size_t)f.I * f.kh * f.kw * 4;
+  if (g.narrow) g.packed_elems = rowconv_applicable(&f) ? rowconv_packed_elems(&f) : (size_t)f.I * f.kh * f.kw * 4;
   return g;
 }
 
@@ -1265,6 +1363,7 @@ static int dgrad_pack(const srgan_conv_desc* d, const float* w, float* dst, hipS
     srgan_conv_desc f;
     long long w_off;
     narrow_dgrad_desc(d, &f, &w_off);
+    if (rowconv_applicable(&f)) return rowconv_pack(&f, w + w_off, dst, st);
     return narrow_pack(&f, w + w_off, dst, st);
   }
   const PackParams q = dgrad_pack_params(d, g, w, dst);
@@ -1282,6 +1381,7 @@ static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp,
     srgan_conv_desc f;
     long long w_off;
     narrow_dgrad_desc(d, &f, &w_off);
+    if (rowconv_applicable(&f)) return rowconv_run(&f, dy, wp, nullptr, dx, st);
     return narrow_fwd_packed(&f, dy, wp, nullptr, dx, st);
   }
   if (g.wino) {
@@ -1348,7 +1448,7 @@ extern "C" int srgan_conv2d_pack_entry(const srgan_conv_desc* d, int kind, int a
   PackEntry pe{};
   if (kind == 0) {
     const FwdPath path = fwd_path(d, act);
-    if (path == PATH_NARROW) return 1;
+    if (path == PATH_NARROW || path == PATH_ROWCONV) return 1;
     if (path == PATH_WINO) { pe.type = 1; wino_pack_params(d, 0, w, (float*)packed, &pe.wn); }
     else { pe.type = 0; pe.ig = fwd_pack_params(d, path, w, (float*)packed); }
   } else {

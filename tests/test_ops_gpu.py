@@ -67,6 +67,7 @@ CONV_CASES = [
     (32, 64, 32, 32, 64, 4, 2, 1, False, False),  # same, one cout tile, many images per tile-position group
     (2, 3, 24, 70, 64, 7, 1, 3, False, False),    # RGB 7x7 layer: input gradient through the narrow-output kernel (flipped filter)
     (2, 3, 12, 13, 32, 5, 1, 2, False, True),     # same route, generic narrow kernel (5x5), bias
+    (2, 64, 20, 72, 3, 7, 1, 3, False, True),     # RGB head through the 7x1 row convolution + shift-add, bias, ragged rows
 ]
 
 
