@@ -250,7 +250,7 @@ def main():
         wino = name.startswith("wino")
         executed = achieved / 2.25 if wino else achieved
         out = {
-            "metric": "images/sec G+D+E train step, CelebA 128x128 bs=32/GPU" if args.size == 128 else
+            "metric": "images/sec G+D+E train step, CelebA 128x128 bs=32/GPU" if (args.size == 128 and B == 32) else
                       f"images/sec G+D+E train step, CelebA {args.size}x{args.size} bs={B}/GPU",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
