@@ -81,6 +81,24 @@ struct ProfToken { size_t idx; bool on; };
 ProfToken prof_begin(int kid, double flops, hipStream_t st);
 void prof_end(ProfToken t, hipStream_t st);
 
+// parameters of the fused Winograd forward / input-gradient kernels (conv_wino.hip, conv_wino43.hip)
+struct WinoParams {
+  const float* src;   // [NB][H][W][C]
+  const float* u;     // [n_tiles][nchunk][16 pos][2 halves][64 couts][4 ch] transformed filters
+  const float* bias;  // [Cd] or null
+  float* dst;         // [NB][Ho][Wo][Cd]
+  int NB, H, W, C, Ho, Wo, Cd;   // source tensor, destination tensor (Cd = its channels)
+  int pad, reflect;
+  int TH, TW, T;      // tile grid per image (of the phase image in mode 2), tiles in total
+  int nchunk, n_tiles, m_tiles;
+  int cpp;            // mode 1: chunks per input phase (C / 8)
+  int act;            // fused activation of the epilogue (SRGAN_ACT_*)
+  float slope;
+};
+
+// conv_wino43.hip: F(4x4,3x3) kernel behind wino_run
+size_t wino43_scratch_floats(long long T, int C);
+int wino43_launch(const WinoParams& p, float* vimg, long long grid, hipStream_t st);
 // conv_wino.hip: Winograd F(2x2,3x3) for 3x3 stride-1 pad-1 layers; kind 0 = forward, 1 = input gradient
 bool wino_applicable(const srgan_conv_desc* d, int kind);
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind);

@@ -46,19 +46,6 @@ __device__ __forceinline__ auto uniform_rsrc(const float* base, unsigned bytes) 
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-struct WinoParams {
-  const float* src;   // [NB][H][W][C]
-  const float* u;     // [n_tiles][nchunk][16 pos][2 halves][64 couts][4 ch] transformed filters
-  const float* bias;  // [Cd] or null
-  float* dst;         // [NB][Ho][Wo][Cd]
-  int NB, H, W, C, Ho, Wo, Cd;   // source tensor, destination tensor (Cd = its channels)
-  int pad, reflect;
-  int TH, TW, T;      // tile grid per image (of the phase image in mode 2), tiles in total
-  int nchunk, n_tiles, m_tiles;
-  int cpp;            // mode 1: chunks per input phase (C / 8)
-  int act;            // fused activation of the epilogue (SRGAN_ACT_*)
-  float slope;
-};
 
 // MODE 0: 3x3 stride-1 conv, F(2x2,3x3): 2x2 output tile from a 4x4 patch, Y = A^T M A.
 // MODE 1: 4x4 stride-2 pad-1 conv = sum over the 4 input phases I_pq[u][v] = in[2u+p-1][2v+q-1] of a 2x2 stride-1
@@ -683,12 +670,17 @@ static double wino_threshold_scale() {
   const char* e = std::getenv("SRGAN_WINOGRAD_THRESHOLD_SCALE");
   return e ? std::atof(e) : 1.0;
 }
+static bool wino43_disabled() {
+  static const bool off = std::getenv("SRGAN_NO_WINOGRAD43") != nullptr;
+  return off;
+}
 static bool wino_s2_disabled() {
   static const bool off = std::getenv("SRGAN_NO_WINOGRAD_S2") != nullptr;
   return off;
 }
 
-// 0: none, 1: F(2x2,3x3) on a 3x3 stride-1 pad-1 layer, 2: F(3x3,2x2) on a 4x4 stride-2 pad-1 layer
+// 0: none, 1: F(2x2,3x3) on a 3x3 stride-1 pad-1 layer, 2: F(3x3,2x2) on a 4x4 stride-2 pad-1 layer,
+// 3: F(4x4,3x3) (conv_wino43.hip) on a 3x3 stride-1 zero-pad-1 layer whose map is a multiple of 4 in both directions
 static int wino_variant(const srgan_conv_desc* d, int kind) {
   if (wino_disabled() || compute_bf16()) return 0;       // bf16 mode: the transforms would eat the 8-bit mantissa
 
@@ -702,6 +694,11 @@ static int wino_variant(const srgan_conv_desc* d, int kind) {
     // one workgroup per CU: maps too small to give ~0.4 of a device round (the encoder's 7x7 / 3x3 maps at batch 32) run a long
     // serial chunk loop on a few CUs -- measured 52 TFLOP/s against ~80 on the implicit GEMM
     const int ho = kind == 0 ? d->Ho : d->Hi, wo = kind == 0 ? d->Wo : d->Wi;
+    if (!wino43_disabled() && d->pad_mode == SRGAN_PAD_ZERO && ho % 4 == 0 && wo % 4 == 0 && N % 32 == 0 && C % 32 == 0) {
+      // 64 tiles x 32 channels per workgroup, one workgroup per CU: at least half a device round
+      const long long b43 = ceil_div((long long)d->N * (ho / 4) * (wo / 4), 64) * (N / 32);
+      if (b43 >= 128 * wino_threshold_scale()) return 3;
+    }
     const long long blocks = ceil_div((long long)d->N * ceil_div(ho, 2) * ceil_div(wo, 2), WT) * ceil_div(N, WNB);
     return blocks >= 100 * wino_threshold_scale() ? 1 : 0;
   }
@@ -724,7 +721,7 @@ static void wino_dims(const srgan_conv_desc* d, int kind, int* C, int* N, int* n
   const int v = wino_variant(d, kind);
   *C = kind == 0 ? d->I : d->O;
   *N = kind == 0 ? d->O : d->I;
-  *n_tiles = (int)ceil_div(*N, WNB);
+  *n_tiles = v == 3 ? *N / 32 : (int)ceil_div(*N, WNB);
   *nchunk = (v == 2 && kind == 0 ? 4 : 1) * (*C / WC);      // MODE 1 reduces over (input phase, channel)
   *phases = (v == 2 && kind == 1) ? 4 : 1;                  // MODE 2: one filter image per output phase
 }
@@ -732,6 +729,11 @@ static void wino_dims(const srgan_conv_desc* d, int kind, int* C, int* N, int* n
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind) {
   int C, N, n_tiles, nchunk, phases;
   wino_dims(d, kind, &C, &N, &n_tiles, &nchunk, &phases);
+  if (wino_variant(d, kind) == 3) {
+    // the transformed filters, then the scratch image of the transformed input (wino43_input_kernel -> wino43_kernel)
+    const int ho = kind == 0 ? d->Ho : d->Hi, wo = kind == 0 ? d->Wo : d->Wi;
+    return ((size_t)n_tiles * nchunk * (36 * 256) + wino43_scratch_floats((long long)d->N * (ho / 4) * (wo / 4), C)) * sizeof(float);
+  }
   return (size_t)phases * n_tiles * nchunk * 8192 * sizeof(float);
 }
 
@@ -747,7 +749,7 @@ void wino_pack_params(const srgan_conv_desc* d, int kind, const float* w, float*
 int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hipStream_t st) {
   WinoPackParams q{};
   wino_pack_params(d, kind, w, dst, &q);
-  const long long total = (long long)q.phases * q.n_tiles * WNB * q.nchunk * WC;
+  const long long total = wino_pack_total(q);
   hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
   return check_launch("wino_pack_kernel");
 }
@@ -765,7 +767,7 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
   p.src = src; p.u = packed; p.bias = bias; p.dst = dst;
   p.NB = d->N; p.C = C; p.Cd = N; p.cpp = C / WC;
   int ot = 2;
-  if (variant == 1) {
+  if (variant == 1 || variant == 3) {
     if (kind == 0) {
       p.H = d->Hi; p.W = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo; p.pad = d->pad; p.reflect = reflect ? 1 : 0;
     } else {
@@ -773,7 +775,8 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
       p.pad = reflect ? 2 : 2 - d->pad;
       p.Ho = d->Ho + 2 * p.pad - 2; p.Wo = d->Wo + 2 * p.pad - 2;
     }
-    p.TH = (p.Ho + 1) / 2; p.TW = (p.Wo + 1) / 2;
+    if (variant == 3) { ot = 4; p.TH = p.Ho / 4; p.TW = p.Wo / 4; }
+    else { p.TH = (p.Ho + 1) / 2; p.TW = (p.Wo + 1) / 2; }
   } else {
     ot = 3;
     p.pad = d->pad; p.reflect = 0;
@@ -789,8 +792,11 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
   const long long grid = (long long)p.m_tiles * p.n_tiles;
   SRGAN_REQUIRE(grid < (1LL << 31), "winograd: grid too large");
   // ALGORITHMIC FLOPs of the direct convolution; the kernel issues ~2.25x fewer on the matrix pipe
-  ProfToken tok = prof_begin(variant == 1 ? 14 : 16, conv_flops_of(d), st);
-  if (variant == 1) hipLaunchKernelGGL(wino_kernel<0>, dim3((unsigned)grid), dim3(512), 0, st, p);
+  ProfToken tok = prof_begin(variant == 1 ? 14 : (variant == 3 ? 18 : 16), conv_flops_of(d), st);
+  if (variant == 3) {
+    SRGAN_REQUIRE(p.pad == 1 && p.Ho == p.H && p.Wo == p.W && p.nchunk >= 2 && p.Cd % 32 == 0, "winograd F(4,3): geometry");
+    wino43_launch(p, const_cast<float*>(packed) + (size_t)p.n_tiles * p.nchunk * (36 * 256), grid, st);
+  } else if (variant == 1) hipLaunchKernelGGL(wino_kernel<0>, dim3((unsigned)grid), dim3(512), 0, st, p);
   else if (kind == 0) hipLaunchKernelGGL(wino_kernel<1>, dim3((unsigned)grid), dim3(512), 0, st, p);
   else hipLaunchKernelGGL(wino_kernel<2>, dim3((unsigned)grid, 4), dim3(512), 0, st, p);
   prof_end(tok, st);

@@ -1,0 +1,261 @@
+// Winograd F(4x4,3x3) for the 3x3 / stride-1 / zero-pad-1 layers whose maps are multiples of 4 (the generator's residual
+// trunk, reference pyfiles/model.py:188-201): 36 multiplies per 16 outputs instead of 144 -- 4x fewer MFMA FLOPs than the
+// implicit GEMM, 1.78x fewer than F(2x2,3x3) (conv_wino.hip), every product still an exact fp32 product on
+// v_mfma_f32_32x32x2_f32.       Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A,   4x4 output tile, 6x6 input patch.
+//
+// Two measured properties of the fp32 matrix path on gfx950 shape the design (scratch/coissue, scratch/shadow):
+//   * v_mfma_f32_32x32x2_f32 and the vector ALU do not overlap: a wave's own VALU instructions queue behind its MFMA, and
+//     a second wave on the SIMD issues nothing while the first issues MFMAs back to back (same 157 TFLOP/s peak for both:
+//     the fp32 MFMA runs on the vector lanes).  VALU work inside the multiply loop is therefore ADDED to the MFMA time;
+//   * the L1 takes one (instruction, 128-byte line) pair per ~4 cycles: gathering 6x6 patches of 8-channel (32-byte)
+//     pixels costs 2304 such pairs per chunk and 64 tiles -- twice the MFMA time of the chunk.
+// So the input transform is NOT fused: wino43_input_kernel (HBM-bound, full-line loads and stores) writes V = B^T d B once,
+// already in the LDS image order of the multiply kernel ([tile block][chunk][36 pos][2 channel quads][64 tiles][4]), and
+// wino43_kernel is a batched GEMM whose loop holds no vector arithmetic at all: per 8-channel chunk a workgroup copies one
+// contiguous 72 KB block into LDS (9 x 16 bytes per thread, double-buffered, one barrier per chunk), every wave multiplies
+// 9 of the 72 (position, tile half) units with A = U fragment (32 output channels x 2 reduce channels, straight from the
+// packed filter image into registers, reloaded in place one chunk ahead) and B = V fragment (one ds_read_b128).
+// An accumulator lane is a TILE and its 16 registers are output channels: the epilogue moves 8 output channels at a time
+// through LDS (double-buffered, one barrier per pass); each thread applies A^T . A to one (tile, channel), adds the bias,
+// applies the activation and stores 16 pixels.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+#include "pack_device.h"
+
+namespace srgan {
+
+// B^T of F(4,3) on a 6-vector, in place (12 operations per component):
+//   [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+__device__ __forceinline__ void bt6(f32x4& x0, f32x4& x1, f32x4& x2, f32x4& x3, f32x4& x4, f32x4& x5) {
+  const f32x4 a = x4 - 4.f * x2, b = x3 - 4.f * x1, c = x4 - x2, e = x3 - x1;
+  const f32x4 n0 = 4.f * x0 - 5.f * x2 + x4, n5 = 4.f * x1 - 5.f * x3 + x5;
+  x0 = n0; x1 = a + b; x2 = a - b; x3 = c + 2.f * e; x4 = c - 2.f * e; x5 = n5;
+}
+
+// A^T of F(4,3): [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+__device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float* y) {
+  const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+  y[0] = m0 + s1 + s2;
+  y[1] = d1 + 2.f * d2;
+  y[2] = s1 + 4.f * s2;
+  y[3] = d1 + 8.f * d2 + m5;
+}
+
+__device__ __forceinline__ auto uniform_rsrc43(const float* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  float* q = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+constexpr int W4T = 64;           // output tiles (4x4 pixels each) per workgroup
+constexpr int W4N = 32;           // output channels per workgroup
+constexpr int W4C = 8;            // reduce channels per chunk
+constexpr int W4BLK = 36 * 512;   // floats of one (tile block, chunk) image: [36 pos][2 quads][64 tiles][4]
+
+// ---- input transform: V[m_tile][chunk][pos][quad][tile][4] = B^T d B, one workgroup = 64 tiles x 32 channels ----
+// thread = (tile, 4 channels): a pixel's 32 channels are one 128-byte line read by 8 lanes, and the 8 tiles of a wave
+// write 128 contiguous bytes per (position, quad): every load and store instruction moves whole lines.
+__global__ __launch_bounds__(512) void wino43_input_kernel(WinoParams p, float* vimg) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cgs = p.C / 32;
+  const int m_tile = blockIdx.x / cgs, cg = blockIdx.x - m_tile * cgs;
+  const int quad = lane & 7, tl = wave * 8 + (lane >> 3);
+  const int t = m_tile * W4T + tl;
+  const bool tv = t < p.T;
+  const int tt = tv ? t : 0;
+  const int per = p.TH * p.TW;
+  const int nb = tt / per;
+  const int r0 = tt - nb * per;
+  const int ty = r0 / p.TW, tx = r0 - ty * p.TW;
+  const int Y = 4 * ty, X = 4 * tx;
+  const int RS = p.W * p.C * 4, CS = p.C * 4;      // byte strides of a row / a pixel of the source
+  const auto rs_x = uniform_rsrc43(p.src, (unsigned)((size_t)p.NB * p.H * p.W * p.C * 4));
+  constexpr unsigned kOutside = 0x80000000u;
+  // rows Y-1 .. Y+4: only the first can be above the image, only the last below it (H % 4 == 0); columns alike.
+  // The scalar offset of element (r, c) is clamp(r-1, 0, 3) * RS + clamp(c-1, 0, 3) * CS; the class adds the rest, or
+  // points past the buffer (the range check then returns the zero padding).
+  const unsigned base = (unsigned)(((nb * p.H + Y) * p.W + X) * p.C + cg * 32 + quad * 4) * 4u;
+  const bool rok[3] = {Y > 0, true, Y + 4 < p.H};
+  const bool cok[3] = {X > 0, true, X + 4 < p.W};
+  const int rdl[3] = {-RS, 0, RS}, cdl[3] = {-CS, 0, CS};
+  unsigned voff[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) voff[a][b] = (tv && rok[a] && cok[b]) ? (unsigned)((int)base + rdl[a] + cdl[b]) : kOutside;
+  f32x4 d[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int rc = r == 0 ? 0 : (r == 5 ? 2 : 1), cc = c == 0 ? 0 : (c == 5 ? 2 : 1);
+      const int rs = (r < 1 ? 0 : (r > 4 ? 3 : r - 1)), cs = (c < 1 ? 0 : (c > 4 ? 3 : c - 1));
+      d[r][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff[rc][cc], rs * RS + cs * CS, 0));
+    }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) bt6(d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], d[5][c]);
+  float* out = vimg + ((size_t)m_tile * p.nchunk + cg * 4 + (quad >> 1)) * W4BLK + (quad & 1) * 256 + tl * 4;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) *reinterpret_cast<f32x4*>(out + (r * 6 + c) * 512) = d[r][c];
+  }
+}
+
+// ---- multiply + output transform ----
+// WinoParams as in conv_wino.hip with TH = Ho / 4, TW = Wo / 4, n_tiles = Cd / 32, nchunk = C / 8, pad = 1;
+// u = [n_tiles][nchunk][36 pos][64 lanes][4]: lane (lr, lh) holds output channel lr, reduce channels 4 lh .. 4 lh + 3.
+__global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* vimg) {
+  // V image, double-buffered: [buf][36 pos][2 channel quads][64 tiles x 4 ch + 16 pad]: a lane's MFMA fragment is one 16-B
+  // slot, a 16-lane read group covers 256 contiguous bytes; the copy writes 1 KB per wave instruction.
+  constexpr int VH = 64 * 4 + 16, VP = 2 * VH, VSZ = 36 * VP;
+  constexpr int XP = 64 * 8;                       // epilogue image: [36 pos][64 tiles][8 channels], double-buffered
+  static_assert(2 * 36 * XP <= 2 * VSZ, "epilogue image must fit the V buffers");
+  __shared__ __attribute__((aligned(16))) float lds[2 * VSZ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);      // XCD-aware: see wino_kernel
+  const int m_tile = bid / p.n_tiles, n_tile = bid - m_tile * p.n_tiles;
+  const int nk = p.nchunk;
+
+  const auto rs_v = uniform_rsrc43(vimg + (size_t)m_tile * p.nchunk * W4BLK, (unsigned)p.nchunk * (W4BLK * 4u));
+  const auto rs_u = uniform_rsrc43(p.u + (size_t)n_tile * p.nchunk * (36 * 256), (unsigned)p.nchunk * (36u * 1024u));
+
+  // copy role: float4 j * 512 + tid of the chunk image -> position 4 j + tid / 128, quad (tid / 64) & 1, slot tid & 63
+  f32x4 stage[9];
+  const int vst = (tid >> 7) * VP + ((tid >> 6) & 1) * VH + (tid & 63) * 4;
+  auto load_v = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+      stage[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, tid * 16, kc * (W4BLK * 4) + j * 8192, 0));
+  };
+  auto store_v = [&](int buf) __attribute__((always_inline)) {
+    float* V = lds + buf * VSZ + vst;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) *reinterpret_cast<f32x4*>(V + j * 4 * VP) = stage[j];
+  };
+
+  // multiply role: units 9 wave .. 9 wave + 8 of the 72 (position, tile half) pairs
+  auto role = [&](auto odd_c) __attribute__((always_inline)) {
+    constexpr int ODD = decltype(odd_c)::value;   // parity of the first unit = first tile half
+    const int pbase = (9 * wave) >> 1;             // first of the 5 positions this wave touches
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    f32x4 ufr[5];
+    const unsigned ulane = (unsigned)(pbase * 256 + lane * 4) * 4u;
+    auto load_u = [&](int a, int kc) __attribute__((always_inline)) {
+      ufr[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ulane + a * 1024, kc * (36 * 1024), 0));
+    };
+    const int vrd = pbase * VP + lh * VH + lr * 4;
+    auto mma_chunk = [&](int kc, auto reload) __attribute__((always_inline)) {
+      constexpr bool RL = decltype(reload)::value;
+      const float* V = lds + (kc & 1) * VSZ + vrd;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int g = i + ODD, a = g >> 1, h = g & 1;
+        const f32x4 vf = *reinterpret_cast<const f32x4*>(V + a * VP + h * 128);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[a][s], vf[s], acc[i], 0, 0, 0);
+        // last unit of position a: reload its filter fragment in place for the next chunk (it lands a whole period later)
+        if (RL && (h == 1 || i == 8)) load_u(a, kc + 1);
+      }
+    };
+
+    using T = std::true_type;
+    using F = std::false_type;
+    // prologue: chunk 0 in LDS, chunk 1 in flight; filter loads AFTER the image loads, as in the loop, so that the
+    // vmcnt state the compiler merges at the loop header lets the copy wait for the image only
+    load_v(0);
+    store_v(0);
+    load_v(1);                                     // nk >= 2
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < 5; ++a) load_u(a, 0);
+    __syncthreads();
+    int kc = 0;
+    for (; kc + 2 < nk; ++kc) {
+      store_v((kc + 1) & 1);
+      load_v(kc + 2);
+      __builtin_amdgcn_sched_barrier(0);           // image loads go out before the multiplies, not after them
+      mma_chunk(kc, T{});
+      __syncthreads();
+    }
+    store_v((kc + 1) & 1);
+    mma_chunk(kc, T{});
+    __syncthreads();
+    mma_chunk(kc + 1, F{});
+    __syncthreads();                               // every wave is done with V: the epilogue image may overwrite it
+
+    // ---- epilogue: 8 output channels per pass meet in LDS as X[pos][tile][8]; thread = (tile, channel) ----
+    const int et = tid >> 3, ec = tid & 7;
+    int eo = -1;
+    {
+      const int t = m_tile * W4T + et;
+      if (t < p.T) {
+        const int per = p.TH * p.TW;
+        const int nb = t / per;
+        const int r0 = t - nb * per;
+        const int ty = r0 / p.TW, tx = r0 - ty * p.TW;
+        eo = (nb * p.Ho + 4 * ty) * p.Wo + 4 * tx;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float* X = lds + (q & 1) * (36 * XP);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int g = i + ODD, a = g >> 1, h = g & 1;
+        // register e of the accumulator is output channel 8 * (e / 4) + 4 * lh + e % 4 of tile 32 h + lr
+        const f32x4 v = {acc[i][4 * q + 0], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(X + (pbase + a) * XP + (h * 32 + lr) * 8 + lh * 4) = v;
+      }
+      __syncthreads();
+      const float* M = X + et * 8 + ec;
+      float hh[4][6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        float y[4];
+        at6(M[(0 * 6 + c) * XP], M[(1 * 6 + c) * XP], M[(2 * 6 + c) * XP], M[(3 * 6 + c) * XP], M[(4 * 6 + c) * XP],
+            M[(5 * 6 + c) * XP], y);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) hh[a][c] = y[a];
+      }
+      const int n = n_tile * W4N + q * 8 + ec;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+      if (eo >= 0) {
+        float* dp = p.dst + (size_t)eo * p.Cd + n;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          float y[4];
+          at6(hh[a][0], hh[a][1], hh[a][2], hh[a][3], hh[a][4], hh[a][5], y);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) dp[(size_t)(a * p.Wo + b) * p.Cd] = apply_act(y[b] + bv, p.act, p.slope);
+        }
+      }
+    }
+  };
+
+  if (wave & 1) role(std::integral_constant<int, 1>{});
+  else role(std::integral_constant<int, 0>{});
+}
+
+size_t wino43_scratch_floats(long long T, int C) { return (size_t)ceil_div(T, (long long)W4T) * (C / W4C) * W4BLK; }
+
+// `vimg`: wino43_scratch_floats(T, C) floats of scratch (the caller keeps them behind the packed filters)
+int wino43_launch(const WinoParams& p, float* vimg, long long grid, hipStream_t st) {
+  hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)(p.m_tiles * (p.C / 32))), dim3(512), 0, st, p, vimg);
+  hipLaunchKernelGGL(wino43_kernel, dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
+  return 0;
+}
+
+}  // namespace srgan

@@ -68,6 +68,8 @@ CONV_CASES = [
     (2, 3, 24, 70, 64, 7, 1, 3, False, False),    # RGB 7x7 layer: input gradient through the narrow-output kernel (flipped filter)
     (2, 3, 12, 13, 32, 5, 1, 2, False, True),     # same route, generic narrow kernel (5x5), bias
     (2, 64, 20, 72, 3, 7, 1, 3, False, True),     # RGB head through the 7x1 row convolution + shift-add, bias, ragged rows
+    (32, 64, 32, 32, 128, 3, 1, 1, False, True),  # F(4x4,3x3) Winograd by default dispatch (128 workgroups), bias
+    (3, 64, 8, 12, 96, 3, 1, 1, False, True),     # F(4x4,3x3) when forced: 18 tiles (ragged block), 8 chunks, 3 channel blocks
 ]
 
 
