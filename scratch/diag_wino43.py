@@ -12,7 +12,7 @@ for rep in range(3):
     y = ops.conv2d(x, w, None, 1, 1)
     torch.cuda.synchronize()
 v = y.permute(0, 2, 3, 1).reshape(-1)[:64].view(8, 8).cpu()
-print("wave role      loop  transform  x-loads  multiply  barrier | per chunk: loop transform x-loads multiply barrier")
+print("wave      loop      copy  multiply   barrier | per chunk: loop copy multiply barrier")
 for wv in range(8):
-    t = v[wv].tolist(); nk = t[5]
-    print(f"{wv} {'mult ' if t[6] else 'gather'} {t[0]:8.0f} {t[1]:8.0f} {t[2]:8.0f} {t[3]:8.0f} {t[4]:8.0f}   |" + " ".join(f"{a/nk:8.0f}" for a in t[:5]))
+    t = v[wv].tolist(); nk = t[4]
+    print(f"{wv} {t[0]:9.0f} {t[1]:9.0f} {t[2]:9.0f} {t[3]:9.0f}   |" + " ".join(f"{a/nk:8.0f}" for a in t[:4]))

@@ -131,15 +131,19 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
   // copy role: float4 j * 512 + tid of the chunk image -> position 4 j + tid / 128, quad (tid / 64) & 1, slot tid & 63
   f32x4 stage[9];
   const int vst = (tid >> 7) * VP + ((tid >> 6) & 1) * VH + (tid & 63) * 4;
+  auto load_v1 = [&](int kc, int j) __attribute__((always_inline)) {
+    stage[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, tid * 16, kc * (W4BLK * 4) + j * 8192, 0));
+  };
+  auto store_v1 = [&](int buf, int j) __attribute__((always_inline)) {
+    *reinterpret_cast<f32x4*>(lds + buf * VSZ + vst + j * 4 * VP) = stage[j];
+  };
   auto load_v = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j)
-      stage[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, tid * 16, kc * (W4BLK * 4) + j * 8192, 0));
+    for (int j = 0; j < 9; ++j) load_v1(kc, j);
   };
   auto store_v = [&](int buf) __attribute__((always_inline)) {
-    float* V = lds + buf * VSZ + vst;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) *reinterpret_cast<f32x4*>(V + j * 4 * VP) = stage[j];
+    for (int j = 0; j < 9; ++j) store_v1(buf, j);
   };
 
   // multiply role: units 9 wave .. 9 wave + 8 of the 72 (position, tile half) pairs
@@ -154,20 +158,30 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
     f32x4 ufr[5];
     const unsigned ulane = (unsigned)(pbase * 256 + lane * 4) * 4u;
     auto load_u = [&](int a, int kc) __attribute__((always_inline)) {
-      ufr[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ulane + a * 1024, kc * (36 * 1024), 0));
+      // position offset in the SCALAR offset: one address register for the five fragments
+      ufr[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ulane, kc * (36 * 1024) + a * 1024, 0));
     };
     const int vrd = pbase * VP + lh * VH + lr * 4;
-    auto mma_chunk = [&](int kc, auto reload) __attribute__((always_inline)) {
-      constexpr bool RL = decltype(reload)::value;
+    // The copy of the next chunk is spread over the nine units (one 16-byte slice each: LDS store of the slice loaded a
+    // chunk ago, then the load of the slice two chunks ahead): LDS and buffer instructions issue in the shadow of the
+    // wave's own MFMAs, whereas a separate copy phase would stall behind the MFMAs of the other wave of the SIMD.
+    auto mma_chunk = [&](int kc, auto reload, auto st_c, auto ld_c) __attribute__((always_inline)) {
+      constexpr bool RL = decltype(reload)::value, ST = decltype(st_c)::value, LD = decltype(ld_c)::value;
       const float* V = lds + (kc & 1) * VSZ + vrd;
+      f32x4 vf[2];
+      vf[0] = *reinterpret_cast<const f32x4*>(V + (ODD >> 1) * VP + (ODD & 1) * 128);
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int g = i + ODD, a = g >> 1, h = g & 1;
-        const f32x4 vf = *reinterpret_cast<const f32x4*>(V + a * VP + h * 128);
+        // fragment of the next unit first: its LDS latency hides behind this unit's four MFMAs
+        if (i + 1 < 9) vf[(i + 1) & 1] = *reinterpret_cast<const f32x4*>(V + ((g + 1) >> 1) * VP + ((g + 1) & 1) * 128);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[a][s], vf[s], acc[i], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[a][s], vf[i & 1][s], acc[i], 0, 0, 0);
         // last unit of position a: reload its filter fragment in place for the next chunk (it lands a whole period later)
         if (RL && (h == 1 || i == 8)) load_u(a, kc + 1);
+        if constexpr (ST) store_v1((kc + 1) & 1, i);
+        if constexpr (LD) load_v1(kc + 2, i);
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
 
@@ -183,17 +197,50 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
     for (int a = 0; a < 5; ++a) load_u(a, 0);
     __syncthreads();
     int kc = 0;
+#ifdef W43_DIAG
+    long long t_cp = 0, t_mm = 0, t_bar = 0;
+    const long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     for (; kc + 2 < nk; ++kc) {
-      store_v((kc + 1) & 1);
-      load_v(kc + 2);
-      __builtin_amdgcn_sched_barrier(0);           // image loads go out before the multiplies, not after them
-      mma_chunk(kc, T{});
+#ifdef W43_DIAG
+      __builtin_amdgcn_sched_barrier(0);
+      const long long q0 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef W43_DIAG
+      const long long q1 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      mma_chunk(kc, T{}, T{}, T{});
+#ifdef W43_DIAG
+      __builtin_amdgcn_sched_barrier(0);
+      const long long q2 = __builtin_amdgcn_s_memtime();
       __syncthreads();
+      const long long q3 = __builtin_amdgcn_s_memtime();
+      t_cp += q1 - q0; t_mm += q2 - q1; t_bar += q3 - q2;
+#else
+      __syncthreads();
+#endif
     }
-    store_v((kc + 1) & 1);
-    mma_chunk(kc, T{});
+#ifdef W43_DIAG
+    {
+      const long long t_loop = __builtin_amdgcn_s_memtime() - t_begin;
+      if (blockIdx.x == 17 && lane == 0) {
+        float* o = p.dst + wave * 8;
+        o[0] = (float)t_loop; o[1] = (float)t_cp; o[2] = (float)t_mm; o[3] = (float)t_bar; o[4] = (float)(nk - 2);
+      }
+      float keep = 0.f;
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) keep += acc[i][e];
+      p.dst[4096 + (size_t)blockIdx.x * 512 + tid] = keep;
+      return;
+    }
+#endif
+    mma_chunk(kc, T{}, T{}, F{});
     __syncthreads();
-    mma_chunk(kc + 1, F{});
+    mma_chunk(kc + 1, F{}, F{}, F{});
     __syncthreads();                               // every wave is done with V: the epilogue image may overwrite it
 
     // ---- epilogue: 8 output channels per pass meet in LDS as X[pos][tile][8]; thread = (tile, channel) ----
@@ -253,8 +300,10 @@ size_t wino43_scratch_floats(long long T, int C) { return (size_t)ceil_div(T, (l
 
 // `vimg`: wino43_scratch_floats(T, C) floats of scratch (the caller keeps them behind the packed filters)
 int wino43_launch(const WinoParams& p, float* vimg, long long grid, hipStream_t st) {
-  hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)(p.m_tiles * (p.C / 32))), dim3(512), 0, st, p, vimg);
-  hipLaunchKernelGGL(wino43_kernel, dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
+  // SRGAN_W43_ONLY=1 / 2 (timing experiments only): launch just the input transform / just the multiply kernel
+  static const int only = std::getenv("SRGAN_W43_ONLY") ? std::atoi(std::getenv("SRGAN_W43_ONLY")) : 0;
+  if (only != 2) hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)(p.m_tiles * (p.C / 32))), dim3(512), 0, st, p, vimg);
+  if (only != 1) hipLaunchKernelGGL(wino43_kernel, dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
   return 0;
 }
 
