@@ -695,9 +695,10 @@ static int wino_variant(const srgan_conv_desc* d, int kind) {
     // serial chunk loop on a few CUs -- measured 52 TFLOP/s against ~80 on the implicit GEMM
     const int ho = kind == 0 ? d->Ho : d->Hi, wo = kind == 0 ? d->Wo : d->Wi;
     if (!wino43_disabled() && d->pad_mode == SRGAN_PAD_ZERO && ho % 4 == 0 && wo % 4 == 0 && N % 32 == 0 && C % 32 == 0) {
-      // 64 tiles x 32 channels per workgroup, one workgroup per CU: at least half a device round
+      // 64 tiles x 32 channels per workgroup, one workgroup per CU; a round costs ~2/3 of wino_kernel's and holds half as
+      // many workgroups, so the same lower bound (100 of its workgroups = 50 of these) applies
       const long long b43 = ceil_div((long long)d->N * (ho / 4) * (wo / 4), 64) * (N / 32);
-      if (b43 >= 128 * wino_threshold_scale()) return 3;
+      if (b43 >= 50 * wino_threshold_scale()) return 3;
     }
     const long long blocks = ceil_div((long long)d->N * ceil_div(ho, 2) * ceil_div(wo, 2), WT) * ceil_div(N, WNB);
     return blocks >= 100 * wino_threshold_scale() ? 1 : 0;

@@ -113,9 +113,10 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
   // V image, double-buffered: [buf][36 pos][2 channel quads][64 tiles x 4 ch + 16 pad]: a lane's MFMA fragment is one 16-B
   // slot, a 16-lane read group covers 256 contiguous bytes; the copy writes 1 KB per wave instruction.
   constexpr int VH = 64 * 4 + 16, VP = 2 * VH, VSZ = 36 * VP;
-  constexpr int XP = 64 * 8;                       // epilogue image: [36 pos][64 tiles][8 channels], double-buffered
-  static_assert(2 * 36 * XP <= 2 * VSZ, "epilogue image must fit the V buffers");
+  constexpr int XT = 36, XP = 16 * XT;             // epilogue image: [36 pos][16 tiles][32 channels + 4 pad]
+  static_assert(36 * XP <= 2 * VSZ, "epilogue image must fit the V buffers");
   __shared__ __attribute__((aligned(16))) float lds[2 * VSZ];
+  __shared__ int tile_o[W4T];                      // destination pixel index of the tile's first output, or -1
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
@@ -128,6 +129,18 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
   const auto rs_v = uniform_rsrc43(vimg + (size_t)m_tile * p.nchunk * W4BLK, (unsigned)p.nchunk * (W4BLK * 4u));
   const auto rs_u = uniform_rsrc43(p.u + (size_t)n_tile * p.nchunk * (36 * 256), (unsigned)p.nchunk * (36u * 1024u));
 
+  if (tid < W4T) {
+    const int t = m_tile * W4T + tid;
+    int o = -1;
+    if (t < p.T) {
+      const int per = p.TH * p.TW;
+      const int nb = t / per;
+      const int r0 = t - nb * per;
+      const int ty = r0 / p.TW, tx = r0 - ty * p.TW;
+      o = (nb * p.Ho + 4 * ty) * p.Wo + 4 * tx;
+    }
+    tile_o[tid] = o;
+  }
   // copy role: float4 j * 512 + tid of the chunk image -> position 4 j + tid / 128, quad (tid / 64) & 1, slot tid & 63
   f32x4 stage[9];
   const int vst = (tid >> 7) * VP + ((tid >> 6) & 1) * VH + (tid & 63) * 4;
@@ -243,31 +256,29 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
     mma_chunk(kc + 1, F{}, F{}, F{});
     __syncthreads();                               // every wave is done with V: the epilogue image may overwrite it
 
-    // ---- epilogue: 8 output channels per pass meet in LDS as X[pos][tile][8]; thread = (tile, channel) ----
-    const int et = tid >> 3, ec = tid & 7;
-    int eo = -1;
-    {
-      const int t = m_tile * W4T + et;
-      if (t < p.T) {
-        const int per = p.TH * p.TW;
-        const int nb = t / per;
-        const int r0 = t - nb * per;
-        const int ty = r0 / p.TW, tx = r0 - ty * p.TW;
-        eo = (nb * p.Ho + 4 * ty) * p.Wo + 4 * tx;
-      }
-    }
+    // ---- epilogue: 16 tiles per pass meet in LDS as X[pos][tile][32 channels + 4 pad]; thread = (tile, channel): the 32
+    // lanes of a tile store one whole 128-byte line per pixel ----
+    const int ec = lane & 31, et = wave + 8 * (lane >> 5);      // tiles et, et + 8 of a wave: 288 floats apart, other banks
+    const int n = n_tile * W4N + ec;
+    const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float* X = lds + (q & 1) * (36 * XP);
+      if (q > 0) __syncthreads();                  // the previous pass has been read
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int g = i + ODD, a = g >> 1, h = g & 1;
-        // register e of the accumulator is output channel 8 * (e / 4) + 4 * lh + e % 4 of tile 32 h + lr
-        const f32x4 v = {acc[i][4 * q + 0], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
-        *reinterpret_cast<f32x4*>(X + (pbase + a) * XP + (h * 32 + lr) * 8 + lh * 4) = v;
+        // accumulator lane = tile 32 h + lr, register e = output channel 8 * (e / 4) + 4 * lh + e % 4
+        if (h == (q >> 1) && (lr >> 4) == (q & 1)) {
+          float* X = lds + (pbase + a) * XP + (lr & 15) * XT + lh * 4;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const f32x4 v = {acc[i][4 * k + 0], acc[i][4 * k + 1], acc[i][4 * k + 2], acc[i][4 * k + 3]};
+            *reinterpret_cast<f32x4*>(X + 8 * k) = v;
+          }
+        }
       }
       __syncthreads();
-      const float* M = X + et * 8 + ec;
+      const float* M = lds + et * XT + ec;
       float hh[4][6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
@@ -277,8 +288,7 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
 #pragma unroll
         for (int a = 0; a < 4; ++a) hh[a][c] = y[a];
       }
-      const int n = n_tile * W4N + q * 8 + ec;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+      const int eo = tile_o[16 * q + et];
       if (eo >= 0) {
         float* dp = p.dst + (size_t)eo * p.Cd + n;
 #pragma unroll
