@@ -98,7 +98,7 @@ struct WinoParams {
 
 // conv_wino43.hip: F(4x4,3x3) kernel behind wino_run
 size_t wino43_scratch_floats(long long T, int C);
-int wino43_launch(const WinoParams& p, float* vimg, long long grid, hipStream_t st);
+int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops, hipStream_t st);
 // conv_wino.hip: Winograd F(2x2,3x3) for 3x3 stride-1 pad-1 layers; kind 0 = forward, 1 = input gradient
 bool wino_applicable(const srgan_conv_desc* d, int kind);
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind);

@@ -793,11 +793,14 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
   const long long grid = (long long)p.m_tiles * p.n_tiles;
   SRGAN_REQUIRE(grid < (1LL << 31), "winograd: grid too large");
   // ALGORITHMIC FLOPs of the direct convolution; the kernel issues ~2.25x fewer on the matrix pipe
-  ProfToken tok = prof_begin(variant == 1 ? 14 : (variant == 3 ? 18 : 16), conv_flops_of(d), st);
   if (variant == 3) {
-    SRGAN_REQUIRE(p.pad == 1 && p.Ho == p.H && p.Wo == p.W && p.nchunk >= 2 && p.Cd % 32 == 0, "winograd F(4,3): geometry");
-    wino43_launch(p, const_cast<float*>(packed) + (size_t)p.n_tiles * p.nchunk * (36 * 256), grid, st);
-  } else if (variant == 1) hipLaunchKernelGGL(wino_kernel<0>, dim3((unsigned)grid), dim3(512), 0, st, p);
+    SRGAN_REQUIRE(p.pad == 1 && p.Ho == p.H && p.Wo == p.W && p.nchunk >= 2 && p.Cd % 32 == 0 && p.C % 32 == 0,
+                  "winograd F(4,3): geometry");
+    wino43_launch(p, const_cast<float*>(packed) + (size_t)p.n_tiles * p.nchunk * (36 * 256), grid, conv_flops_of(d), st);
+    return check_launch("wino43_kernel");
+  }
+  ProfToken tok = prof_begin(variant == 1 ? 14 : 16, conv_flops_of(d), st);
+  if (variant == 1) hipLaunchKernelGGL(wino_kernel<0>, dim3((unsigned)grid), dim3(512), 0, st, p);
   else if (kind == 0) hipLaunchKernelGGL(wino_kernel<1>, dim3((unsigned)grid), dim3(512), 0, st, p);
   else hipLaunchKernelGGL(wino_kernel<2>, dim3((unsigned)grid, 4), dim3(512), 0, st, p);
   prof_end(tok, st);

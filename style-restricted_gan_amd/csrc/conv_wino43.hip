@@ -309,11 +309,20 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
 size_t wino43_scratch_floats(long long T, int C) { return (size_t)ceil_div(T, (long long)W4T) * (C / W4C) * W4BLK; }
 
 // `vimg`: wino43_scratch_floats(T, C) floats of scratch (the caller keeps them behind the packed filters)
-int wino43_launch(const WinoParams& p, float* vimg, long long grid, hipStream_t st) {
+// (`flops`: the layer's ALGORITHMIC FLOPs, booked on the multiply kernel; the input transform is HBM-bound and has its own slot)
+int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops, hipStream_t st) {
   // SRGAN_W43_ONLY=1 / 2 (timing experiments only): launch just the input transform / just the multiply kernel
   static const int only = std::getenv("SRGAN_W43_ONLY") ? std::atoi(std::getenv("SRGAN_W43_ONLY")) : 0;
-  if (only != 2) hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)(p.m_tiles * (p.C / 32))), dim3(512), 0, st, p, vimg);
-  if (only != 1) hipLaunchKernelGGL(wino43_kernel, dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
+  if (only != 2) {
+    ProfToken tok = prof_begin(19, 0.0, st);
+    hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)(p.m_tiles * (p.C / 32))), dim3(512), 0, st, p, vimg);
+    prof_end(tok, st);
+  }
+  if (only != 1) {
+    ProfToken tok = prof_begin(18, flops, st);
+    hipLaunchKernelGGL(wino43_kernel, dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
+    prof_end(tok, st);
+  }
   return 0;
 }
 
