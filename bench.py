@@ -267,7 +267,7 @@ def main():
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(name),
                          "executed_mfma_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4),
                          "algorithm": ("Winograd F(4x4,3x3): the multiply kernel issues 4x fewer MFMA FLOPs than the algorithmic count "
-                                       "(its input transform is the separate HBM-bound wino43_input_kernel, listed in `kernels`), so the "
+                                       "(its input transform is the separate HBM-bound wino43_input_kernel, listed in all_gemm_kernels), so the "
                                        "ALGORITHMIC rate asked for in `achieved` exceeds the MFMA peak (frac > 1); executed_frac is the "
                                        "utilisation of the matrix pipe") if wino43 else
                                       ("Winograd F(2x2,3x3) / F(3x3,2x2): 2.25x fewer MFMA FLOPs than the algorithmic count, so the "
