@@ -441,39 +441,58 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
   int lg = g0, lb = 0;
   set_group(lg);
   float dx[16], dd[ND];
-  auto load_chunk = [&]() __attribute__((always_inline)) {
+  // (the loads of a chunk are issued in five parts: the texture path takes ~20 cycles per gather instruction of a CU, so
+  // twenty back-to-back loads per wave would hold all eight waves at the load for ~3000 cycles with the matrix pipe idle)
+  auto load_part = [&](auto part_c) __attribute__((always_inline)) {
+    constexpr int PART = decltype(part_c)::value;
+    if constexpr (PART < 4) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      dx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, offx[i], lb * x_img, 0));
+      for (int i = 4 * PART; i < 4 * PART + 4; ++i)
+        dx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, offx[i], lb * x_img, 0));
+    } else {
 #pragma unroll
-    for (int i = 0; i < ND; ++i)
-      dd[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, offd[i], lb * d_img, 0));
-    if (++lb == p.NB) {      // next tile-position group (wave-uniform, once per NB chunks)
-      lb = 0;
-      ++lg;
-      set_group(lg);
+      for (int i = 0; i < ND; ++i)
+        dd[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, offd[i], lb * d_img, 0));
+      if (++lb == p.NB) {      // next tile-position group (wave-uniform, once per NB chunks)
+        lb = 0;
+        ++lg;
+        set_group(lg);
+      }
     }
   };
+  auto load_chunk = [&]() __attribute__((always_inline)) {
+    load_part(std::integral_constant<int, 0>{});
+    load_part(std::integral_constant<int, 1>{});
+    load_part(std::integral_constant<int, 2>{});
+    load_part(std::integral_constant<int, 3>{});
+    load_part(std::integral_constant<int, 4>{});
+  };
   const int wofs = th * 256 + (wave & 3) * 64 + lane;     // [half][channel][tile & 3], lane-linear
-  auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+  // The transform + store of the next chunk is cut into four pieces that the main loop places between groups of four
+  // MFMAs: LDS stores and buffer loads issue in the shadow of the wave's own MFMAs, whereas a separate store phase would
+  // wait behind the back-to-back MFMAs of the other wave of the SIMD (scratch/coissue).
+  float tv[16];
+  auto store_piece = [&](int buf, auto piece_c) __attribute__((always_inline)) {
+    constexpr int PIECE = decltype(piece_c)::value;
     float* Z = lds + buf * 16384 + wofs;
     float* V = Z + 8192;
-    float t[16];
+    if constexpr (PIECE == 0) {                    // column pass of B^T d B
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      t[0 * 4 + c] = dx[0 * 4 + c] - dx[2 * 4 + c];
-      t[1 * 4 + c] = dx[1 * 4 + c] + dx[2 * 4 + c];
-      t[2 * 4 + c] = dx[2 * 4 + c] - dx[1 * 4 + c];
-      t[3 * 4 + c] = dx[1 * 4 + c] - dx[3 * 4 + c];
-    }
+      for (int c = 0; c < 4; ++c) {
+        tv[0 * 4 + c] = dx[0 * 4 + c] - dx[2 * 4 + c];
+        tv[1 * 4 + c] = dx[1 * 4 + c] + dx[2 * 4 + c];
+        tv[2 * 4 + c] = dx[2 * 4 + c] - dx[1 * 4 + c];
+        tv[3 * 4 + c] = dx[1 * 4 + c] - dx[3 * 4 + c];
+      }
+    } else if constexpr (PIECE == 1 || PIECE == 2) {      // row pass, two rows each
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      V[(r * 4 + 0) * 512] = t[r * 4 + 0] - t[r * 4 + 2];
-      V[(r * 4 + 1) * 512] = t[r * 4 + 1] + t[r * 4 + 2];
-      V[(r * 4 + 2) * 512] = t[r * 4 + 2] - t[r * 4 + 1];
-      V[(r * 4 + 3) * 512] = t[r * 4 + 1] - t[r * 4 + 3];
-    }
-    if constexpr (MODE == 0) {
+      for (int r = 2 * (PIECE - 1); r < 2 * PIECE; ++r) {
+        V[(r * 4 + 0) * 512] = tv[r * 4 + 0] - tv[r * 4 + 2];
+        V[(r * 4 + 1) * 512] = tv[r * 4 + 1] + tv[r * 4 + 2];
+        V[(r * 4 + 2) * 512] = tv[r * 4 + 2] - tv[r * 4 + 1];
+        V[(r * 4 + 3) * 512] = tv[r * 4 + 1] - tv[r * 4 + 3];
+      }
+    } else if constexpr (MODE == 0) {
       // A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
       const float r0[2] = {dd[0], dd[1]};
       const float r1[2] = {dd[0] + dd[2], dd[1] + dd[3]};
@@ -506,6 +525,12 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
       }
     }
   };
+  auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+    store_piece(buf, std::integral_constant<int, 0>{});
+    store_piece(buf, std::integral_constant<int, 1>{});
+    store_piece(buf, std::integral_constant<int, 2>{});
+    store_piece(buf, std::integral_constant<int, 3>{});
+  };
 
   f32x16 acc[2][2][2];
 #pragma unroll
@@ -537,47 +562,51 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
 
   using T = std::true_type;
   using F = std::false_type;
-  const int cls = wave >> 2;
   if (nk > 0) {
     load_chunk();
     store_chunk(0);
     __syncthreads();
     read_frags(0, 0);
     if (nk > 1) load_chunk();
-    auto iter = [&](int kc, auto c1, auto st, auto ld) __attribute__((always_inline)) {
-      constexpr bool C1 = decltype(c1)::value, ST = decltype(st)::value, LD = decltype(ld)::value;
+    // chunk kc: 8 groups of four MFMAs (one k-step of one position each); the pieces of the next chunk's transform and
+    // the loads of the chunk after it sit between the groups; one barrier, after every store and before the first read
+    // of the other buffer
+    auto iter = [&](int kc, auto st, auto ld) __attribute__((always_inline)) {
+      constexpr bool ST = decltype(st)::value, LD = decltype(ld)::value;
       const int cur = kc & 1;
+      auto sb = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
       read_frags(cur, 1);
-      if constexpr (C1) {
-        if constexpr (ST) {
-          store_chunk(cur ^ 1);
-          if constexpr (LD) load_chunk();
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        mfma_steps(0, 0, 4);
-      } else {
-        mfma_steps(0, 0, 2);
-        if constexpr (ST) {
-          __builtin_amdgcn_sched_barrier(0);
-          store_chunk(cur ^ 1);
-          if constexpr (LD) load_chunk();
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        mfma_steps(0, 2, 4);
-      }
-      mfma_steps(1, 0, 2);
-      __builtin_amdgcn_sched_barrier(0);
+      mfma_steps(0, 0, 1);
+      if constexpr (ST) store_piece(cur ^ 1, std::integral_constant<int, 0>{});      // frees dx
+      sb();
+      mfma_steps(0, 1, 2);
+      if constexpr (ST) store_piece(cur ^ 1, std::integral_constant<int, 1>{});
+      if constexpr (LD) load_part(std::integral_constant<int, 0>{});
+      sb();
+      mfma_steps(0, 2, 3);
+      if constexpr (ST) store_piece(cur ^ 1, std::integral_constant<int, 2>{});
+      if constexpr (LD) load_part(std::integral_constant<int, 1>{});
+      sb();
+      mfma_steps(0, 3, 4);
+      if constexpr (ST) store_piece(cur ^ 1, std::integral_constant<int, 3>{});      // frees dd
+      if constexpr (LD) load_part(std::integral_constant<int, 2>{});
+      sb();
+      mfma_steps(1, 0, 1);
+      if constexpr (LD) load_part(std::integral_constant<int, 3>{});
+      sb();
+      mfma_steps(1, 1, 2);
+      if constexpr (LD) load_part(std::integral_constant<int, 4>{});
+      sb();
+      mfma_steps(1, 2, 3);
+      sb();
       __syncthreads();
       if constexpr (ST) read_frags(cur ^ 1, 0);
-      mfma_steps(1, 2, 4);
+      mfma_steps(1, 3, 4);
     };
-    auto run = [&](auto c1) __attribute__((always_inline)) {
-      int kc = 0;
-      for (; kc + 2 < nk; ++kc) iter(kc, c1, T{}, T{});
-      if (nk >= 2) iter(nk - 2, c1, T{}, F{});
-      iter(nk - 1, c1, F{}, F{});
-    };
-    if (cls == 0) run(F{}); else run(T{});
+    int kc = 0;
+    for (; kc + 2 < nk; ++kc) iter(kc, T{}, T{});
+    if (nk >= 2) iter(nk - 2, T{}, F{});
+    iter(nk - 1, F{}, F{});
   }
 
   // ---- epilogue: G^T dU G (3x3 taps) or A^T dU A (the 2x2 taps of this input phase) per (o, i), two halves of 32
