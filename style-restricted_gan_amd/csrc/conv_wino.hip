@@ -149,46 +149,69 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   float d[16];
   f32x4 bfr[2][2][2];      // [chunk parity][slot = position within the wave][column tile]
   int lc8 = 0, lphase = 0;      // load cursor: chunks are consumed strictly in order
-  auto load_x = [&]() __attribute__((always_inline)) {
+  // (issued in four parts between groups of MFMAs: the texture path takes ~20 cycles per gather instruction of a CU, so
+  // sixteen back-to-back loads per wave would hold all eight waves at the load with the matrix pipe idle)
+  auto load_x_part = [&](auto part_c) __attribute__((always_inline)) {
+    constexpr int PART = decltype(part_c)::value;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 4 * PART; i < 4 * PART + 4; ++i)
       d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off[i], lc8 * (WC * 4), 0));
-    ++lc8;
-    if (MODE == 1 && lc8 == p.cpp) {      // next input phase: new patch origin and padding mask (wave-uniform, 3x per kernel)
-      lc8 = 0;
-      ++lphase;
-      set_offsets(lphase);
+    if constexpr (PART == 3) {
+      ++lc8;
+      if (MODE == 1 && lc8 == p.cpp) {      // next input phase: new patch origin and padding mask (wave-uniform, 3x per kernel)
+        lc8 = 0;
+        ++lphase;
+        set_offsets(lphase);
+      }
     }
   };
-  auto load_u = [&](int kc, auto par) __attribute__((always_inline)) {
+  auto load_x = [&]() __attribute__((always_inline)) {
+    load_x_part(std::integral_constant<int, 0>{});
+    load_x_part(std::integral_constant<int, 1>{});
+    load_x_part(std::integral_constant<int, 2>{});
+    load_x_part(std::integral_constant<int, 3>{});
+  };
+  auto load_u1 = [&](int kc, auto par, int a, int j) __attribute__((always_inline)) {
     constexpr int P = decltype(par)::value;
+    bfr[P][a][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ubase + a * 2048 + j * 512, kc * 32768, 0));
+  };
+  auto load_u = [&](int kc, auto par) __attribute__((always_inline)) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        bfr[P][a][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ubase + a * 2048 + j * 512, kc * 32768, 0));
+      for (int j = 0; j < 2; ++j) load_u1(kc, par, a, j);
   };
-  // B^T d B in registers, 16 results to V[pos][half][tile][ch & 3]
-  auto store_v = [&](int buf) __attribute__((always_inline)) {
+  // B^T d B in registers, 16 results to V[pos][half][tile][ch & 3]; three pieces (column pass, rows 0-1, rows 2-3) that the
+  // main loop places between groups of MFMAs
+  float tv[16];
+  auto store_piece = [&](int buf, auto piece_c) __attribute__((always_inline)) {
+    constexpr int PIECE = decltype(piece_c)::value;
 #if WINO_EXP == 4
     return;
 #endif
     float* V = lds + buf * VSZ + (ch >> 2) * VH + tl * 4 + (ch & 3);
-    float t[16];
+    if constexpr (PIECE == 0) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      t[0 * 4 + c] = d[0 * 4 + c] - d[2 * 4 + c];
-      t[1 * 4 + c] = d[1 * 4 + c] + d[2 * 4 + c];
-      t[2 * 4 + c] = d[2 * 4 + c] - d[1 * 4 + c];
-      t[3 * 4 + c] = d[1 * 4 + c] - d[3 * 4 + c];
-    }
+      for (int c = 0; c < 4; ++c) {
+        tv[0 * 4 + c] = d[0 * 4 + c] - d[2 * 4 + c];
+        tv[1 * 4 + c] = d[1 * 4 + c] + d[2 * 4 + c];
+        tv[2 * 4 + c] = d[2 * 4 + c] - d[1 * 4 + c];
+        tv[3 * 4 + c] = d[1 * 4 + c] - d[3 * 4 + c];
+      }
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      V[(r * 4 + 0) * VP] = t[r * 4 + 0] - t[r * 4 + 2];
-      V[(r * 4 + 1) * VP] = t[r * 4 + 1] + t[r * 4 + 2];
-      V[(r * 4 + 2) * VP] = t[r * 4 + 2] - t[r * 4 + 1];
-      V[(r * 4 + 3) * VP] = t[r * 4 + 1] - t[r * 4 + 3];
+      for (int r = 2 * (PIECE - 1); r < 2 * PIECE; ++r) {
+        V[(r * 4 + 0) * VP] = tv[r * 4 + 0] - tv[r * 4 + 2];
+        V[(r * 4 + 1) * VP] = tv[r * 4 + 1] + tv[r * 4 + 2];
+        V[(r * 4 + 2) * VP] = tv[r * 4 + 2] - tv[r * 4 + 1];
+        V[(r * 4 + 3) * VP] = tv[r * 4 + 1] - tv[r * 4 + 3];
+      }
     }
+  };
+  auto store_v = [&](int buf) __attribute__((always_inline)) {
+    store_piece(buf, std::integral_constant<int, 0>{});
+    store_piece(buf, std::integral_constant<int, 1>{});
+    store_piece(buf, std::integral_constant<int, 2>{});
   };
 
   // ---- multiply role: wave = positions 2*wave, 2*wave+1 over the whole 64 x 64 tile ----
@@ -219,16 +242,20 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
           acc[slot][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i][e], bfr[P][slot][j][e], acc[slot][i][j], 0, 0, 0);
   };
 
-  // Two waves share a SIMD (wave w and w + 4).  They run the chunk's non-MFMA work (patch transform, LDS stores, the
-  // next global loads) at DIFFERENT points of the iteration -- class 0 between its MFMA groups, class 1 in front
-  // of them.  The LDS / memory counters are in-order and the compiler merges their state at every control-flow
-  // join, so the steady-state loop holds one straight-line body per (class, chunk parity); the tail iterations
-  // (no store / no load) are separate instantiations.
+  // Chunk kc = 8 groups of four MFMAs (one k-step of one position).  The vector work of the NEXT chunk (patch transform),
+  // its LDS stores, the patch loads of the chunk after it and the filter fragments of the next chunk sit between the groups
+  // of the SAME wave: LDS and buffer instructions issue in the shadow of the wave's own MFMAs, whereas a separate store
+  // phase waits behind the back-to-back MFMAs of the other wave of the SIMD, and a block of gather loads holds every wave at
+  // the texture path (~20 cycles per instruction) with the matrix pipe idle (scratch/coissue, scratch/shadow).
+  // The LDS / memory counters are in-order and the compiler merges their state at every control-flow join, so the
+  // steady-state loop holds one straight-line body per chunk parity; the tail iterations (no store / no load) are
+  // separate instantiations.
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
   using T = std::true_type;
   using F = std::false_type;
-  const int cls = wave >> 2;
   const int nk = p.nchunk;
   load_x();
   load_u(0, I0{});
@@ -236,49 +263,50 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   __syncthreads();
   read_frags(0, 0);
   if (nk > 1) load_x();
-  auto iter = [&](int kc, auto c1, auto par, auto st, auto ld) __attribute__((always_inline)) {
-    constexpr bool C1 = decltype(c1)::value, ST = decltype(st)::value, LD = decltype(ld)::value;
+  auto iter = [&](int kc, auto par, auto st, auto ld) __attribute__((always_inline)) {
+    constexpr bool ST = decltype(st)::value, LD = decltype(ld)::value;
     constexpr int P = decltype(par)::value;
     using NP = std::integral_constant<int, 1 - P>;
+    auto sb = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
     read_frags(P, 1);
-    // the LDS stores must have drained when the wave reaches the barrier, or every wave waits for them with the
-    // matrix pipe idle: >= 16 MFMAs are kept between the stores and the barrier (sched_barrier pins the order)
-    if constexpr (C1) {
-      if constexpr (ST) {
-        load_u(kc + 1, NP{});              // fragments of chunk kc+1: wanted at the top of the next iteration
-        store_v(1 - P);                    // chunk kc+1: its loads were issued a whole chunk ago
-        if constexpr (LD) load_x();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      mfma_steps(par, 0, 0, 4);
-    } else {
-      mfma_steps(par, 0, 0, 2);
-      if constexpr (ST) {
-        __builtin_amdgcn_sched_barrier(0);
-        load_u(kc + 1, NP{});
-        store_v(1 - P);
-        if constexpr (LD) load_x();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      mfma_steps(par, 0, 2, 4);
-    }
-    mfma_steps(par, 1, 0, 2);
-    __builtin_amdgcn_sched_barrier(0);     // keep those MFMAs in front of the barrier
+    mfma_steps(par, 0, 0, 1);
+    if constexpr (ST) store_piece(1 - P, I0{});       // chunk kc+1 (its loads were issued a whole chunk ago); frees d
+    sb();
+    mfma_steps(par, 0, 1, 2);
+    if constexpr (ST) store_piece(1 - P, I1{});
+    if constexpr (LD) load_x_part(I0{});
+    sb();
+    mfma_steps(par, 0, 2, 3);
+    if constexpr (ST) store_piece(1 - P, I2{});
+    if constexpr (LD) load_x_part(I1{});
+    sb();
+    mfma_steps(par, 0, 3, 4);
+    if constexpr (ST) load_u1(kc + 1, NP{}, 0, 0);     // fragments of chunk kc+1: wanted at the top of the next iteration
+    if constexpr (LD) load_x_part(I2{});
+    sb();
+    mfma_steps(par, 1, 0, 1);
+    if constexpr (ST) load_u1(kc + 1, NP{}, 0, 1);
+    if constexpr (LD) load_x_part(I3{});
+    sb();
+    mfma_steps(par, 1, 1, 2);
+    if constexpr (ST) { load_u1(kc + 1, NP{}, 1, 0); load_u1(kc + 1, NP{}, 1, 1); }
+    sb();
+    mfma_steps(par, 1, 2, 3);
+    sb();
     __syncthreads();                       // chunk kc+1 visible; every wave holds its last fragments of chunk kc
     if constexpr (ST) read_frags(1 - P, 0);
-    mfma_steps(par, 1, 2, 4);
+    mfma_steps(par, 1, 3, 4);
   };
-  auto run = [&](auto c1) __attribute__((always_inline)) {
+  {
     int kc = 0;
     for (; kc + 3 < nk; kc += 2) {
-      iter(kc, c1, I0{}, T{}, T{});
-      iter(kc + 1, c1, I1{}, T{}, T{});
+      iter(kc, I0{}, T{}, T{});
+      iter(kc + 1, I1{}, T{}, T{});
     }
     // nchunk is even (wino_applicable): exactly two chunks are left
-    iter(kc, c1, I0{}, T{}, F{});
-    iter(kc + 1, c1, I1{}, F{}, F{});
-  };
-  if (cls == 0) run(F{}); else run(T{});
+    iter(kc, I0{}, T{}, F{});
+    iter(kc + 1, I1{}, F{}, F{});
+  }
 
   // ---- epilogue: output transform (A^T M A: 2x2, or G^T M G: 3x3), two halves of 32 output channels ----
   const int cl = tid & 31, tg = tid >> 5;
