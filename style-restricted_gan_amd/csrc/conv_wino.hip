@@ -766,9 +766,10 @@ static int wino_variant(const srgan_conv_desc* d, int kind) {
     const long long th = ceil_div(d->Ho, 3), tw = ceil_div(d->Wo, 3);
     const double eff = (double)d->Ho * d->Wo / (9.0 * th * tw);
     if (eff * 2.25 < 1.5) return 0;
-    // one workgroup per CU: below ~0.8 of a device round the long (4 C / 8 chunk) K loop loses to the implicit GEMM
+    // one workgroup per CU: below ~half a device round the long (4 C / 8 chunk) K loop loses to the implicit GEMM (measured:
+    // D.c2 at batch 32, 122 workgroups: 94 us against 107 us; D.c4, 16 workgroups: 277 us against 130 us)
     const long long blocks = ceil_div((long long)d->N * th * tw, WT) * ceil_div(N, WNB) * (kind == 1 ? 4 : 1);
-    return blocks >= 200 * wino_threshold_scale() ? 2 : 0;
+    return blocks >= 120 * wino_threshold_scale() ? 2 : 0;
   }
   return 0;
 }
