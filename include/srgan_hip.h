@@ -63,8 +63,12 @@ int srgan_conv2d_dgrad(const srgan_conv_desc* d, const float* dy, const float* w
  * (kind 1) of that step.  srgan_conv2d_fwd / _dgrad are exactly pack-into-workspace + the packed call. */
 size_t srgan_conv2d_packed_bytes(const srgan_conv_desc* d, int kind, int act);
 int srgan_conv2d_pack(const srgan_conv_desc* d, int kind, int act, const float* w, void* packed, size_t bytes, void* stream);
+/* Scratch the packed calls need beside the operand (0 for most layers): the transformed-input image of the F(4x4,3x3)
+ * Winograd layers (kind 0 and 1), the padded-gradient temp of a reflect-padded layer (kind 1).  Caller-owned like every
+ * workspace of this library; only live between the launches of one call, so one buffer serves every layer of a stream. */
+size_t srgan_conv2d_packed_scratch(const srgan_conv_desc* d, int kind);
 int srgan_conv2d_fwd_packed(const srgan_conv_desc* d, const float* x, const void* packed, const float* bias, float* y,
-                            int act, float slope, void* stream);
+                            int act, float slope, void* ws, size_t ws_bytes, void* stream);
 int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* dy, const void* packed, float* dx,
                               void* ws, size_t ws_bytes, void* stream);
 

@@ -103,7 +103,8 @@ int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops
 bool wino_applicable(const srgan_conv_desc* d, int kind);
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind);
 int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hipStream_t st);
-int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst, int act, float slope, hipStream_t st);
+size_t wino_scratch_bytes(const srgan_conv_desc* d, int kind);
+int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst, int act, float slope, float* scratch, hipStream_t st);
 bool wino_wgrad_applicable(const srgan_conv_desc* d);
 void wino_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad);
 int wino_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, hipStream_t st);

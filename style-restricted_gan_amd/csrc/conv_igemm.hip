@@ -1143,6 +1143,8 @@ extern "C" size_t srgan_conv2d_workspace(const srgan_conv_desc* d) {
   // reflect dgrad: padded-gradient temp
   if (d->pad_mode == SRGAN_PAD_REFLECT)
     bytes += (size_t)d->N * (d->Hi + 2 * d->pad) * (d->Wi + 2 * d->pad) * d->I * sizeof(float);
+  // F(4x4,3x3) layers: the transformed-input image, behind the packed operand (64-float aligned)
+  bytes = std::max(bytes, (size_t)round_up((long long)pack_bytes(d), 256) + std::max(wino_scratch_bytes(d, 0), wino_scratch_bytes(d, 1)));
   WgradPlan w = plan_wgrad(d);
   if (wino_wgrad_applicable(d)) wino_wgrad_slab(d, &w.splits, &w.Cdpad, &w.NNpad);
   size_t wg = (size_t)w.splits * w.Cdpad * w.NNpad * sizeof(float);
@@ -1291,11 +1293,11 @@ static int rowconv_run(const srgan_conv_desc* d, const float* x, const float* pa
 }
 
 static int fwd_run(const srgan_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act,
-                   float slope, hipStream_t st) {
+                   float slope, float* scratch, hipStream_t st) {
   const FwdPath path = fwd_path(d, act);
   if (path == PATH_ROWCONV) return rowconv_run(d, x, wp, bias, y, st);
   if (path == PATH_NARROW) return narrow_fwd_packed(d, x, wp, bias, y, st);
-  if (path == PATH_WINO) return wino_run(d, 0, x, wp, bias, y, act, slope, st);
+  if (path == PATH_WINO) return wino_run(d, 0, x, wp, bias, y, act, slope, scratch, st);
   IgemmParams p{};
   fwd_geometry(d, path, p);
   p.src = x; p.bias = bias; p.dst = y; p.act = act; p.slope = slope; p.wp = wp;
@@ -1386,7 +1388,8 @@ static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp,
     return narrow_fwd_packed(&f, dy, wp, nullptr, dx, st);
   }
   if (g.wino) {
-    if (int e = wino_run(d, 1, dy, wp, nullptr, g.p.dst, SRGAN_ACT_NONE, 0.f, st)) return e;
+    // (F(4,3) needs zero padding, the fold scratch needs reflect padding: the two uses of `scratch` never meet)
+    if (int e = wino_run(d, 1, dy, wp, nullptr, g.p.dst, SRGAN_ACT_NONE, 0.f, g.reflect ? nullptr : scratch, st)) return e;
   } else if (int e = run_igemm(g.p, g.phases, st, conv_flops(d))) {
     return e;
   }
@@ -1407,7 +1410,7 @@ extern "C" int srgan_conv2d_fwd(const srgan_conv_desc* d, const float* x, const 
   SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_fwd: workspace too small");
   hipStream_t st = as_stream(stream);
   if (int e = fwd_pack(d, act, w, (float*)ws, st)) return e;
-  return fwd_run(d, x, (const float*)ws, bias, y, act, slope, st);
+  return fwd_run(d, x, (const float*)ws, bias, y, act, slope, (float*)ws + round_up((long long)(pack_bytes(d) / sizeof(float)), 64), st);
 }
 
 extern "C" int srgan_conv2d_dgrad(const srgan_conv_desc* d, const float* dy, const float* w, float* dx,
@@ -1469,19 +1472,28 @@ extern "C" int srgan_conv2d_pack_multi(const void* entries_dev, int n_entries, v
   return check_launch("pack_multi_kernel");
 }
 
+extern "C" size_t srgan_conv2d_packed_scratch(const srgan_conv_desc* d, int kind) {
+  if (validate(d) != 0) return 0;
+  if (kind == 1 && d->pad_mode == SRGAN_PAD_REFLECT) return srgan_conv2d_workspace(d);      // padded-gradient temp
+  if (kind == 0 ? fwd_path(d, SRGAN_ACT_NONE) == PATH_WINO : dgrad_geometry(d).wino) return wino_scratch_bytes(d, kind);
+  return 0;
+}
+
 extern "C" int srgan_conv2d_fwd_packed(const srgan_conv_desc* d, const float* x, const void* packed, const float* bias,
-                                       float* y, int act, float slope, void* stream) {
+                                       float* y, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
   if (int e = validate(d)) return e;
   SRGAN_REQUIRE(x && packed && y, "conv2d_fwd_packed: null pointer");
-  return fwd_run(d, x, (const float*)packed, bias, y, act, slope, as_stream(stream));
+  const size_t need = srgan_conv2d_packed_scratch(d, 0);
+  SRGAN_REQUIRE(need == 0 || (ws && ws_bytes >= need), "conv2d_fwd_packed: workspace too small (srgan_conv2d_packed_scratch)");
+  return fwd_run(d, x, (const float*)packed, bias, y, act, slope, (float*)ws, as_stream(stream));
 }
 
 extern "C" int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* dy, const void* packed, float* dx,
                                          void* ws, size_t ws_bytes, void* stream) {
   if (int e = validate(d)) return e;
   SRGAN_REQUIRE(dy && packed && dx, "conv2d_dgrad_packed: null pointer");
-  if (d->pad_mode == SRGAN_PAD_REFLECT)
-    SRGAN_REQUIRE(ws && ws_bytes >= srgan_conv2d_workspace(d), "conv2d_dgrad_packed: workspace too small (reflect scratch)");
+  const size_t need = srgan_conv2d_packed_scratch(d, 1);
+  SRGAN_REQUIRE(need == 0 || (ws && ws_bytes >= need), "conv2d_dgrad_packed: workspace too small (srgan_conv2d_packed_scratch)");
   return dgrad_run(d, dy, (const float*)packed, dx, (float*)ws, as_stream(stream));
 }
 

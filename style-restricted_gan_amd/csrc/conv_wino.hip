@@ -788,12 +788,15 @@ static void wino_dims(const srgan_conv_desc* d, int kind, int* C, int* N, int* n
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind) {
   int C, N, n_tiles, nchunk, phases;
   wino_dims(d, kind, &C, &N, &n_tiles, &nchunk, &phases);
-  if (wino_variant(d, kind) == 3) {
-    // the transformed filters, then the scratch image of the transformed input (wino43_input_kernel -> wino43_kernel)
-    const int ho = kind == 0 ? d->Ho : d->Hi, wo = kind == 0 ? d->Wo : d->Wi;
-    return ((size_t)n_tiles * nchunk * (36 * 256) + wino43_scratch_floats((long long)d->N * (ho / 4) * (wo / 4), C)) * sizeof(float);
-  }
+  if (wino_variant(d, kind) == 3) return (size_t)n_tiles * nchunk * (36 * 256) * sizeof(float);
   return (size_t)phases * n_tiles * nchunk * 8192 * sizeof(float);
+}
+
+// scratch the run needs beside the packed filters: the transformed-input image of the F(4x4,3x3) pair of kernels
+size_t wino_scratch_bytes(const srgan_conv_desc* d, int kind) {
+  if (wino_variant(d, kind) != 3) return 0;
+  const int ho = kind == 0 ? d->Ho : d->Hi, wo = kind == 0 ? d->Wo : d->Wi;
+  return wino43_scratch_floats((long long)d->N * (ho / 4) * (wo / 4), kind == 0 ? d->I : d->O) * sizeof(float);
 }
 
 void wino_pack_params(const srgan_conv_desc* d, int kind, const float* w, float* dst, WinoPackParams* out) {
@@ -814,8 +817,9 @@ int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hi
 }
 
 // dst geometry: kind 0 -> [N][Ho][Wo][O]; kind 1 -> [N][Hd][Wd][I] with Hd = Hi (zero pad) or Hi + 2 (reflect scratch)
+// `scratch`: wino_scratch_bytes(d, kind) bytes (may be null when that is 0)
 int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst,
-             int act, float slope, hipStream_t st) {
+             int act, float slope, float* scratch, hipStream_t st) {
   WinoParams p{};
   p.act = act; p.slope = slope;
   int C, N, phases;
@@ -854,7 +858,8 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
   if (variant == 3) {
     SRGAN_REQUIRE(p.pad == 1 && p.Ho == p.H && p.Wo == p.W && p.nchunk >= 2 && p.Cd % 32 == 0 && p.C % 32 == 0,
                   "winograd F(4,3): geometry");
-    wino43_launch(p, const_cast<float*>(packed) + (size_t)p.n_tiles * p.nchunk * (36 * 256), grid, conv_flops_of(d), st);
+    SRGAN_REQUIRE(scratch, "winograd F(4,3): no scratch for the transformed input");
+    wino43_launch(p, scratch, grid, conv_flops_of(d), st);
     return check_launch("wino43_kernel");
   }
   ProfToken tok = prof_begin(variant == 1 ? 14 : 16, conv_flops_of(d), st);

@@ -131,10 +131,11 @@ _pack_cache = {}          # (id(weight), kind, act_flag, geometry) -> _Packed
 
 
 class _Packed:
-    __slots__ = ("buf", "weight", "desc", "kind", "act", "version", "fresh", "ptr")
+    __slots__ = ("buf", "weight", "desc", "kind", "act", "version", "fresh", "ptr", "scratch")
 
-    def __init__(self, buf, weight, desc, kind, act):
+    def __init__(self, buf, weight, desc, kind, act, scratch):
         self.buf, self.weight, self.desc, self.kind, self.act = buf, weight, desc, kind, act
+        self.scratch = scratch                 # bytes of per-call scratch the packed run wants (shared workspace)
         self.version, self.fresh, self.ptr = weight._version, True, weight.data_ptr()
 
 
@@ -215,13 +216,14 @@ def _packed(desc, weight, kind, act):
             raise _lib.SrganHipError("conv2d pack: " + lib.srgan_last_error().decode())
         own = _lib.ConvDesc()
         ctypes.memmove(ctypes.byref(own), ctypes.byref(desc), ctypes.sizeof(own))
-        hit = _Packed(torch.empty(nbytes, dtype=torch.uint8, device=weight.device), weight, own, kind, act)
+        hit = _Packed(torch.empty(nbytes, dtype=torch.uint8, device=weight.device), weight, own, kind, act,
+                      lib.srgan_conv2d_packed_scratch(ctypes.byref(desc), kind))
         _pack_cache[key] = hit
         _tables.clear()
         _pack_one(hit)
     elif not hit.fresh or hit.version != weight._version or hit.ptr != weight.data_ptr():
         _pack_one(hit)
-    return hit.buf
+    return hit
 
 
 _tables = {}              # frozenset of parameter ids -> (entries, device table, singles)
@@ -277,9 +279,10 @@ def refresh_packed(params):
 def _run_conv_fwd(desc, x, weight, bias, y, act, slope):
     lib = _lib.load()
     if _pack_cache_on:
-        wp = _packed(desc, weight, 0, act)
-        _lib.check(lib.srgan_conv2d_fwd_packed(ctypes.byref(desc), _ptr(x), _ptr(wp), _ptr(bias), _ptr(y), act,
-                                               float(slope), _stream()), "conv2d_fwd_packed")
+        hit = _packed(desc, weight, 0, act)
+        ws = workspace(x.device, hit.scratch) if hit.scratch else None
+        _lib.check(lib.srgan_conv2d_fwd_packed(ctypes.byref(desc), _ptr(x), _ptr(hit.buf), _ptr(bias), _ptr(y), act,
+                                               float(slope), _ptr(ws), hit.scratch, _stream()), "conv2d_fwd_packed")
         return
     ws, nb = _conv_ws(desc, x.device)
     _lib.check(lib.srgan_conv2d_fwd(ctypes.byref(desc), _ptr(x), _ptr(weight), _ptr(bias), _ptr(y), act,
@@ -289,9 +292,9 @@ def _run_conv_fwd(desc, x, weight, bias, y, act, slope):
 def _run_conv_dgrad(desc, dy, weight, dx):
     lib = _lib.load()
     if _pack_cache_on:
-        wp = _packed(desc, weight, 1, ACT_NONE)
-        ws, nb = (_conv_ws(desc, dy.device) if desc.pad_mode == PAD_REFLECT else (None, 0))
-        _lib.check(lib.srgan_conv2d_dgrad_packed(ctypes.byref(desc), _ptr(dy), _ptr(wp), _ptr(dx), _ptr(ws), nb,
+        hit = _packed(desc, weight, 1, ACT_NONE)
+        ws = workspace(dy.device, hit.scratch) if hit.scratch else None
+        _lib.check(lib.srgan_conv2d_dgrad_packed(ctypes.byref(desc), _ptr(dy), _ptr(hit.buf), _ptr(dx), _ptr(ws), hit.scratch,
                                                  _stream()), "conv2d_dgrad_packed")
         return
     ws, nb = _conv_ws(desc, dy.device)
