@@ -14,6 +14,8 @@ shapes = [  # name, Cin, H, Cout, k, s, p
     ("D.c4 256->512 k4s2 @16", 256, 16, 512, 4, 2, 1),
     ("E.l0 64->128 k3 @62", 64, 62, 128, 3, 1, 1),
     ("E.l2 256->512 k3 @15", 256, 15, 512, 3, 1, 1),
+    ("G.first 3->64 k7 @128", 3, 128, 64, 7, 1, 3),
+    ("G.last 64->3 k7 @128", 64, 128, 3, 7, 1, 3),
 ]
 only = os.environ.get("ONLY")
 def timeit(fn):

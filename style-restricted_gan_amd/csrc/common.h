@@ -109,6 +109,12 @@ bool wino_wgrad_applicable(const srgan_conv_desc* d);
 void wino_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad);
 int wino_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, hipStream_t st);
 
+// conv_rgbin.hip: 3-channel-input 7x7 stride-1 layers on the MFMA (LDS-staged halo)
+bool rgbin_applicable(const srgan_conv_desc* d);
+size_t rgbin_packed_elems(const srgan_conv_desc* d);
+int rgbin_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st);
+int rgbin_run(const srgan_conv_desc* d, const float* x, const float* packed, const float* bias, float* y, int act, float slope, hipStream_t st);
+
 // conv_narrow.hip: direct kernels for Cout <= 4, stride-1, zero-pad layers
 bool narrow_applicable(const srgan_conv_desc* d);
 size_t narrow_workspace(const srgan_conv_desc* d);

@@ -43,8 +43,8 @@ static const char* const kProfNames[] = {
     "igemm_kernel<128,32,4,1,gen>",  "igemm_kernel<128,32,4,1,vec>",  "igemm_kernel<64,64,2,2,gen>",  "igemm_kernel<64,64,2,2,vec>",
     "wgrad_kernel<gen>", "wgrad_kernel<vec>", "igemm_kernel<256,128,4,2,gen>", "igemm_kernel<256,128,4,2,vec>",
     "igemm_kernel<256,64,4,2,gen>", "igemm_kernel<256,64,4,2,vec>", "wino_kernel", "wino_wgrad_kernel", "wino_kernel<4x4s2>", "wino_wgrad_kernel<4x4s2>",
-    "wino43_kernel", "wino43_input_kernel"};
-constexpr int kProfKernels = 20;
+    "wino43_kernel", "wino43_input_kernel", "rgbin_conv_kernel"};
+constexpr int kProfKernels = 21;
 
 struct ProfScope {
   bool on;
@@ -1129,6 +1129,7 @@ size_t pack_bytes(const srgan_conv_desc* d) {
   }
   if (wino_applicable(d, 0)) bytes = std::max(bytes, wino_packed_bytes(d, 0));
   if (wino_applicable(d, 1)) bytes = std::max(bytes, wino_packed_bytes(d, 1));
+  if (d->I == 3 || d->O == 3) bytes = std::max(bytes, (size_t)d->kh * ((d->kw * 3 + 1) & ~1) * std::max(d->I, d->O) * sizeof(float));   // conv_rgbin.hip
   return bytes;
 }
 
@@ -1156,7 +1157,7 @@ extern "C" size_t srgan_conv2d_workspace(const srgan_conv_desc* d) {
 
 namespace srgan {
 // ---- forward: which kernel family serves this layer, and the packed-weight layout it wants ----
-enum FwdPath { PATH_IGEMM = 0, PATH_NARROW = 1, PATH_WAVE = 2, PATH_DENSE = 3, PATH_WINO = 4, PATH_ROWCONV = 5 };
+enum FwdPath { PATH_IGEMM = 0, PATH_NARROW = 1, PATH_WAVE = 2, PATH_DENSE = 3, PATH_WINO = 4, PATH_ROWCONV = 5, PATH_RGBIN = 6 };
 
 // ---- 3-channel 7x7 heads (the generator's RGB output layer, model.py:232, and the input gradient of its 7x7 RGB input
 // layer, model.py:212) on the matrix pipe.  With Cout = 3 a 32-wide MFMA tile would be 90 % padding, so the layer is split:
@@ -1228,6 +1229,7 @@ static FwdPath fwd_path(const srgan_conv_desc* d, int act) {
     if (rowconv_applicable(d)) return PATH_ROWCONV;
     if (narrow_applicable(d)) return PATH_NARROW;
   }
+  if (rgbin_applicable(d)) return PATH_RGBIN;       // 3-channel 7x7 input layer: LDS-staged halo on the MFMA (conv_rgbin.hip)
   if (wino_applicable(d, 0)) return PATH_WINO;      // bias / activation fused in its epilogue too
   return PATH_IGEMM;
 }
@@ -1246,6 +1248,7 @@ static size_t fwd_packed_bytes(const srgan_conv_desc* d, int act) {
   const FwdPath path = fwd_path(d, act);
   if (path == PATH_NARROW) return (size_t)d->I * d->kh * d->kw * 4 * sizeof(float);
   if (path == PATH_ROWCONV) return rowconv_packed_elems(d) * sizeof(float);
+  if (path == PATH_RGBIN) return rgbin_packed_elems(d) * sizeof(float);
   if (path == PATH_WINO) return wino_packed_bytes(d, 0);
   IgemmParams p{};
   fwd_geometry(d, path, p);
@@ -1266,6 +1269,7 @@ static int fwd_pack(const srgan_conv_desc* d, int act, const float* w, float* ds
   const FwdPath path = fwd_path(d, act);
   if (path == PATH_NARROW) return narrow_pack(d, w, dst, st);
   if (path == PATH_ROWCONV) return rowconv_pack(d, w, dst, st);
+  if (path == PATH_RGBIN) return rgbin_pack(d, w, dst, st);
   if (path == PATH_WINO) return wino_pack(d, 0, w, dst, st);
   const PackParams q = fwd_pack_params(d, path, w, dst);
   long long total = (long long)q.Npad * q.Kpad;
@@ -1297,6 +1301,7 @@ static int fwd_run(const srgan_conv_desc* d, const float* x, const float* wp, co
   const FwdPath path = fwd_path(d, act);
   if (path == PATH_ROWCONV) return rowconv_run(d, x, wp, bias, y, st);
   if (path == PATH_NARROW) return narrow_fwd_packed(d, x, wp, bias, y, st);
+  if (path == PATH_RGBIN) return rgbin_run(d, x, wp, bias, y, act, slope, st);
   if (path == PATH_WINO) return wino_run(d, 0, x, wp, bias, y, act, slope, scratch, st);
   IgemmParams p{};
   fwd_geometry(d, path, p);
@@ -1320,7 +1325,19 @@ static bool narrow_dgrad_desc(const srgan_conv_desc* d, srgan_conv_desc* f, long
   return narrow_applicable(f);
 }
 
-struct DgradGeom { IgemmParams p; int phases; bool reflect, wino, narrow; int Hd, Wd; size_t packed_elems; };
+// Input gradient of a stride-1 zero-padded conv with 3 OUTPUT channels (the generator's 7x7 RGB head) = a 3-channel-INPUT
+// convolution of dy with the flipped, transposed filter: conv_rgbin.hip.
+static bool rgbin_dgrad_desc(const srgan_conv_desc* d, srgan_conv_desc* f, long long* w_off) {
+  if (d->stride != 1 || d->pad_mode != SRGAN_PAD_ZERO || d->O != 3 || d->kh != d->kw || d->kh - 1 - d->pad < 0) return false;
+  *f = *d;
+  f->Hi = d->Ho; f->Wi = d->Wo; f->Ho = d->Hi; f->Wo = d->Wi; f->I = d->O; f->O = d->I;
+  f->pad = d->kh - 1 - d->pad;
+  f->sO = d->sI; f->sI = d->sO; f->sH = -d->sH; f->sW = -d->sW;     // w'[i][o][ky][kx] = w[o][i][kh-1-ky][kw-1-kx]
+  *w_off = (long long)(d->kh - 1) * d->sH + (long long)(d->kw - 1) * d->sW;
+  return rgbin_applicable(f);
+}
+
+struct DgradGeom { IgemmParams p; int phases; bool reflect, wino, narrow, rgbin; int Hd, Wd; size_t packed_elems; };
 
 static DgradGeom dgrad_geometry(const srgan_conv_desc* d) {
   DgradGeom g{};
@@ -1348,6 +1365,8 @@ static DgradGeom dgrad_geometry(const srgan_conv_desc* d) {
   long long w_off;
   g.narrow = !g.wino && narrow_dgrad_desc(d, &f, &w_off);
   if (g.narrow) g.packed_elems = rowconv_applicable(&f) ? rowconv_packed_elems(&f) : (size_t)f.I * f.kh * f.kw * 4;
+  g.rgbin = !g.wino && !g.narrow && rgbin_dgrad_desc(d, &f, &w_off);
+  if (g.rgbin) g.packed_elems = rgbin_packed_elems(&f);
   return g;
 }
 
@@ -1369,6 +1388,12 @@ static int dgrad_pack(const srgan_conv_desc* d, const float* w, float* dst, hipS
     if (rowconv_applicable(&f)) return rowconv_pack(&f, w + w_off, dst, st);
     return narrow_pack(&f, w + w_off, dst, st);
   }
+  if (g.rgbin) {
+    srgan_conv_desc f;
+    long long w_off;
+    rgbin_dgrad_desc(d, &f, &w_off);
+    return rgbin_pack(&f, w + w_off, dst, st);
+  }
   const PackParams q = dgrad_pack_params(d, g, w, dst);
   long long total = (long long)g.packed_elems;
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, q);
@@ -1386,6 +1411,12 @@ static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp,
     narrow_dgrad_desc(d, &f, &w_off);
     if (rowconv_applicable(&f)) return rowconv_run(&f, dy, wp, nullptr, dx, st);
     return narrow_fwd_packed(&f, dy, wp, nullptr, dx, st);
+  }
+  if (g.rgbin) {
+    srgan_conv_desc f;
+    long long w_off;
+    rgbin_dgrad_desc(d, &f, &w_off);
+    return rgbin_run(&f, dy, wp, nullptr, dx, SRGAN_ACT_NONE, 0.f, st);
   }
   if (g.wino) {
     // (F(4,3) needs zero padding, the fold scratch needs reflect padding: the two uses of `scratch` never meet)
@@ -1452,12 +1483,12 @@ extern "C" int srgan_conv2d_pack_entry(const srgan_conv_desc* d, int kind, int a
   PackEntry pe{};
   if (kind == 0) {
     const FwdPath path = fwd_path(d, act);
-    if (path == PATH_NARROW || path == PATH_ROWCONV) return 1;
+    if (path == PATH_NARROW || path == PATH_ROWCONV || path == PATH_RGBIN) return 1;
     if (path == PATH_WINO) { pe.type = 1; wino_pack_params(d, 0, w, (float*)packed, &pe.wn); }
     else { pe.type = 0; pe.ig = fwd_pack_params(d, path, w, (float*)packed); }
   } else {
     const DgradGeom g = dgrad_geometry(d);
-    if (g.narrow) return 1;
+    if (g.narrow || g.rgbin) return 1;
     if (g.wino) { pe.type = 1; wino_pack_params(d, 1, w, (float*)packed, &pe.wn); }
     else { pe.type = 0; pe.ig = dgrad_pack_params(d, g, w, (float*)packed); }
   }
