@@ -114,6 +114,9 @@ bool rgbin_applicable(const srgan_conv_desc* d);
 size_t rgbin_packed_elems(const srgan_conv_desc* d);
 int rgbin_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st);
 int rgbin_run(const srgan_conv_desc* d, const float* x, const float* packed, const float* bias, float* y, int act, float slope, hipStream_t st);
+int rgb_wgrad_kind(const srgan_conv_desc* d);      // -1: not applicable
+void rgb_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad);
+int rgb_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, hipStream_t st);
 
 // conv_narrow.hip: direct kernels for Cout <= 4, stride-1, zero-pad layers
 bool narrow_applicable(const srgan_conv_desc* d);

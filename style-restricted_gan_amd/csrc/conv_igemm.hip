@@ -43,8 +43,8 @@ static const char* const kProfNames[] = {
     "igemm_kernel<128,32,4,1,gen>",  "igemm_kernel<128,32,4,1,vec>",  "igemm_kernel<64,64,2,2,gen>",  "igemm_kernel<64,64,2,2,vec>",
     "wgrad_kernel<gen>", "wgrad_kernel<vec>", "igemm_kernel<256,128,4,2,gen>", "igemm_kernel<256,128,4,2,vec>",
     "igemm_kernel<256,64,4,2,gen>", "igemm_kernel<256,64,4,2,vec>", "wino_kernel", "wino_wgrad_kernel", "wino_kernel<4x4s2>", "wino_wgrad_kernel<4x4s2>",
-    "wino43_kernel", "wino43_input_kernel", "rgbin_conv_kernel"};
-constexpr int kProfKernels = 21;
+    "wino43_kernel", "wino43_input_kernel", "rgbin_conv_kernel", "rgb_wgrad_kernel"};
+constexpr int kProfKernels = 22;
 
 struct ProfScope {
   bool on;
@@ -1148,6 +1148,7 @@ extern "C" size_t srgan_conv2d_workspace(const srgan_conv_desc* d) {
   bytes = std::max(bytes, (size_t)round_up((long long)pack_bytes(d), 256) + std::max(wino_scratch_bytes(d, 0), wino_scratch_bytes(d, 1)));
   WgradPlan w = plan_wgrad(d);
   if (wino_wgrad_applicable(d)) wino_wgrad_slab(d, &w.splits, &w.Cdpad, &w.NNpad);
+  if (rgb_wgrad_kind(d) >= 0) rgb_wgrad_slab(d, &w.splits, &w.Cdpad, &w.NNpad);
   size_t wg = (size_t)w.splits * w.Cdpad * w.NNpad * sizeof(float);
   size_t cs = (size_t)1024 * d->O * sizeof(float);
   if (wg + cs > bytes) bytes = wg + cs;
@@ -1578,6 +1579,11 @@ extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, cons
   if (wino_wgrad_applicable(d)) {
     wino_wgrad_slab(d, &w.splits, &w.Cdpad, &w.NNpad);
     if (int e = wino_wgrad_run(d, x, dy, (float*)ws, st)) return e;
+    return finish_wgrad(d, w, dy, dw, dbias, ws, st);
+  }
+  if (rgb_wgrad_kind(d) >= 0) {
+    rgb_wgrad_slab(d, &w.splits, &w.Cdpad, &w.NNpad);
+    if (int e = rgb_wgrad_run(d, x, dy, (float*)ws, st)) return e;
     return finish_wgrad(d, w, dy, dw, dbias, ws, st);
   }
   if (narrow_applicable(d)) {

@@ -119,6 +119,180 @@ __global__ void rgbin_pack_kernel(const float* w, float* dst, long long sO, long
   }
 }
 
+// ---- weight gradient of the 7x7 stride-1 layers between a 3-channel and a 64-channel tensor ----
+//   R[ch][(ky, kx, c)] = sum over pixels  C64[pixel][ch] * T3[pixel + (ky - 3, kx - 3)][c]
+// SWAP 0: the RGB INPUT layer (model.py:212): C64 = dy, T3 = x, dW[o = ch][c][ky][kx] = R.
+// SWAP 1: the RGB OUTPUT layer (model.py:232): C64 = x, T3 = dy and the offsets change sign:
+//         dW[o = c][i = ch][ky][kx] = R[ch][(6 - ky, 6 - kx, c)].
+// A GEMM with M = 64 channels, N = 154 (-> 160) taps laid out as in the forward kernel, K = pixels.  A workgroup walks over
+// 16 x 32 pixel tiles (persistent, one per CU); the T3 halo of a tile sits in LDS (double-buffered, one barrier per tile) and
+// the B fragment of (pixel, tap) is halo[pixel base (immediate) + tap offset (one register per 32-tap tile)]; the A fragment
+// (32 channels of two pixels) comes straight from global memory, 128 contiguous bytes per pixel, reloaded in place one
+// 32-pixel row ahead.  Every wave accumulates ALL 2 x 5 output tiles (160 registers) over its two rows of each tile; at
+// the end the eight partial results meet in LDS and one slab per workgroup goes to the split-K reduce of conv_igemm.hip.
+struct RgbWgradParams {
+  const float* c64;   // [NB][H][W][64]
+  const float* t3;    // [NB][H][W][3]
+  float* slab;        // [gridDim.x][Cdpad][NNpad]
+  int NB, H, W, tiles_x, tiles_y, ntiles;
+};
+
+template <int SWAP>
+__global__ __launch_bounds__(512) void rgb_wgrad_kernel(RgbWgradParams p) {
+  constexpr int KH = 7, KW = 7, CI = 3, TR = 16, TC = 32;
+  constexpr int HR = TR + KH - 1, HC = TC + KW - 1, HW = HC * CI, HSZ = HR * HW + 8;
+  constexpr int KR = 22, KP = KH * KR;      // 154 taps, padded to 5 x 32
+  __shared__ float lds[8 * 1024];           // 2 halo buffers (2 x 2516 floats); the final reduction reuses all 32 KB
+  float* halo = lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // B role: lane = tap 32 nt + lr, pixel parity lh
+  int tapoff[5];
+#pragma unroll
+  for (int nt = 0; nt < 5; ++nt) {
+    const int k = nt * 32 + lr;
+    const int ky = k / KR, j = k - ky * KR;
+    tapoff[nt] = (k < KP && j < KW * CI) ? ky * HW + j + lh * CI : lh * CI;      // pad taps read a valid slot, their column is dropped
+  }
+  f32x16 acc[2][5];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.c64), 0, (unsigned)((size_t)p.NB * p.H * p.W * 64 * 4), 0x00020000);
+  // A role: lane = channel lr (+32 for the second row tile), pixel parity lh; a unit = one 32-pixel row of a tile
+  float areg[2][16];
+  const unsigned alane = (unsigned)(lh * 64 + lr) * 4u;
+  auto unit_base = [&](int t, int u) -> unsigned {          // byte offset of pixel (row 2 wave + u, column 0) of tile t
+    const int tx = t % p.tiles_x;
+    int r = t / p.tiles_x;
+    const int ty = r % p.tiles_y, n = r / p.tiles_y;
+    return (unsigned)(((n * p.H + ty * TR + 2 * wave + u) * p.W + tx * TC) * 64) * 4u;
+  };
+  auto load_a = [&](unsigned base, int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+      areg[it][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_c, alane + it * 128, base + s * 512, 0));
+  };
+  auto fill_halo = [&](int t, int buf) __attribute__((always_inline)) {
+    const int tx = t % p.tiles_x;
+    int r = t / p.tiles_x;
+    const int ty = r % p.tiles_y, n = r / p.tiles_y;
+    const float* img = p.t3 + (size_t)n * p.H * p.W * CI;
+    const int gx0 = (tx * TC - 3) * CI, gy0 = ty * TR - 3;
+    float* h = halo + buf * HSZ;
+    for (int e = tid; e < HSZ; e += 512) {
+      const int rr = e / HW, j = e - rr * HW;
+      const int gy = gy0 + rr, gx = gx0 + j;
+      float v = 0.f;
+      if (rr < HR && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)(p.W * CI)) v = img[(size_t)gy * p.W * CI + gx];
+      h[e] = v;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t < p.ntiles) {
+    fill_halo(t, 0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) load_a(unit_base(t, 0), s);
+  }
+  int buf = 0;
+  for (; t < p.ntiles; t += gridDim.x) {
+    __syncthreads();                                 // halo[buf] filled; everyone is done with halo[buf ^ 1]
+    const int tn = t + gridDim.x;
+    if (tn < p.ntiles) fill_halo(tn, buf ^ 1);
+    const float* h = halo + buf * HSZ + (2 * wave) * HW;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      // the unit after this one: the second row of the tile, or the first row of the next tile (after the last tile the
+      // same row is loaded once more and never used: no branch inside the unrolled steps)
+      const unsigned nbase = u == 0 ? unit_base(t, 1) : unit_base(tn < p.ntiles ? tn : t, 0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        float vb[5];
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) vb[nt] = h[u * HW + 2 * s * CI + tapoff[nt]];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+          for (int nt = 0; nt < 5; ++nt)
+            acc[it][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[it][s], vb[nt], acc[it][nt], 0, 0, 0);
+        load_a(nbase, s);                            // in place: lands a whole row later
+      }
+    }
+    buf ^= 1;
+  }
+
+  // ---- the eight partial results meet in LDS, one 32 x 32 output tile at a time ----
+  float* slab = p.slab + (size_t)blockIdx.x * (SWAP ? 4 * (KH * KW * 64) : 64 * (KH * KW * CI));
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+      __syncthreads();
+      // D[i = channel][j = tap]: lane = tap lr, register e = channel 8 * (e / 4) + 4 * lh + e % 4
+#pragma unroll
+      for (int e = 0; e < 16; ++e) lds[wave * 1024 + (8 * (e >> 2) + 4 * lh + (e & 3)) * 32 + lr] = acc[it][nt][e];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int el = tid + 512 * q;                // element (channel, tap) of the 32 x 32 tile
+        float v = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) v += lds[w8 * 1024 + el];
+        const int ch = it * 32 + (el >> 5), k = nt * 32 + (el & 31);
+        const int ky = k / KR, j = k - ky * KR;
+        if (k < KP && j < KW * CI) {
+          const int kx = j / CI, c = j - kx * CI;
+          if (SWAP) slab[(size_t)c * (KH * KW * 64) + ((KH - 1 - ky) * KW + (KW - 1 - kx)) * 64 + ch] = v;
+          else slab[(size_t)ch * (KH * KW * CI) + (ky * KW + kx) * CI + c] = v;
+        }
+      }
+    }
+  if (SWAP) {      // the slab has 4 channel rows (Cdpad of the reduce): row 3 is never written above
+    for (int e = tid; e < KH * KW * 64; e += 512) slab[(size_t)3 * (KH * KW * 64) + e] = 0.f;
+  }
+}
+
+// kind 0: RGB input layer (I == 3, O == 64); kind 1: RGB output layer (I == 64, O == 3)
+int rgb_wgrad_kind(const srgan_conv_desc* d) {
+  static const bool off = std::getenv("SRGAN_NO_RGBIN") != nullptr;
+  if (off || compute_bf16()) return -1;
+  if (d->kh != 7 || d->kw != 7 || d->stride != 1 || d->pad != 3 || d->pad_mode != SRGAN_PAD_ZERO) return -1;
+  if (d->Hi % 16 != 0 || d->Wi % 32 != 0 || (long long)d->N * d->Hi * d->Wi * 64 >= (1LL << 29)) return -1;
+  if (d->I == 3 && d->O == 64) return 0;
+  if (d->I == 64 && d->O == 3) return 1;
+  return -1;
+}
+
+// slab geometry for the reduce: [splits][Cdpad][NNpad]
+void rgb_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad) {
+  const long long tiles = (long long)d->N * (d->Hi / 16) * (d->Wi / 32);
+  *splits = (int)std::min<long long>(tiles, 256);
+  *Cdpad = rgb_wgrad_kind(d) == 1 ? 4 : 64;
+  *NNpad = d->kh * d->kw * d->I;
+}
+
+int rgb_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, hipStream_t st) {
+  const int kind = rgb_wgrad_kind(d);
+  SRGAN_REQUIRE(kind >= 0, "rgb weight gradient: layer not applicable");
+  RgbWgradParams p{};
+  p.c64 = kind == 0 ? dy : x; p.t3 = kind == 0 ? x : dy; p.slab = slab;
+  p.NB = d->N; p.H = d->Hi; p.W = d->Wi; p.tiles_x = d->Wi / 32; p.tiles_y = d->Hi / 16;
+  p.ntiles = p.NB * p.tiles_x * p.tiles_y;
+  int splits, cd, nn;
+  rgb_wgrad_slab(d, &splits, &cd, &nn);
+  ProfToken tok = prof_begin(21, 2.0 * d->N * d->Ho * d->Wo * (double)d->O * d->kh * d->kw * d->I, st);
+  if (kind == 0) hipLaunchKernelGGL(rgb_wgrad_kernel<0>, dim3((unsigned)splits), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL(rgb_wgrad_kernel<1>, dim3((unsigned)splits), dim3(512), 0, st, p);
+  prof_end(tok, st);
+  return check_launch("rgb_wgrad_kernel");
+}
+
 bool rgbin_applicable(const srgan_conv_desc* d) {
   static const bool off = std::getenv("SRGAN_NO_RGBIN") != nullptr;
   if (off || compute_bf16()) return false;

@@ -71,6 +71,8 @@ CONV_CASES = [
     (32, 64, 32, 32, 128, 3, 1, 1, False, True),  # F(4x4,3x3) Winograd by default dispatch (128 workgroups), bias
     (3, 64, 8, 12, 96, 3, 1, 1, False, True),     # F(4x4,3x3) when forced: 18 tiles (ragged block), 8 chunks, 3 channel blocks
     (2, 3, 40, 33, 128, 7, 1, 3, False, True),    # RGB-input 7x7 layer on the MFMA (LDS halo): ragged tiles, 2 channel blocks, bias
+    (9, 3, 128, 128, 64, 7, 1, 3, False, False),  # RGB-input layer: MFMA weight gradient, 288 pixel tiles on 256 persistent workgroups
+    (3, 64, 32, 64, 3, 7, 1, 3, False, False),    # RGB-output layer: MFMA weight gradient (swapped roles, flipped taps), 12 tiles
 ]
 
 
