@@ -22,6 +22,10 @@ def prof_name(n):
     m = re.match(r"wino_kernel<(\d)>", n)
     if m:
         return "wino_kernel" if m.group(1) == "0" else "wino_kernel<4x4s2>"
+    if n.startswith("rgbin_conv_kernel"):
+        return "rgbin_conv_kernel"
+    if n.startswith("rgb_wgrad_kernel"):
+        return "rgb_wgrad_kernel"
     if n.startswith("wino43_input_kernel"):
         return "wino43_input_kernel"
     if n.startswith("wino43_kernel"):
