@@ -308,8 +308,10 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
     iter(kc + 1, I1{}, F{}, F{});
   }
 
-  // ---- epilogue: output transform (A^T M A: 2x2, or G^T M G: 3x3), two halves of 32 output channels ----
-  const int cl = tid & 31, tg = tid >> 5;
+  // ---- epilogue: output transform (A^T M A: 2x2, or G^T M G: 3x3), two halves of 32 output channels; thread = (tile, 4
+  // channels): 16-byte LDS reads and 16-byte stores, the 8 lanes of a tile write one whole 128-byte line per pixel
+  // (a quarter of the store instructions of a one-channel-per-thread layout: the texture path takes ~16 cycles each) ----
+  const int cq = tid & 7, et = tid >> 3;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();
@@ -323,50 +325,52 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
           lds[(2 * wave + a) * 2048 + tile * 32 + lr] = acc[a][i][half][e];
         }
     __syncthreads();
-    const int n = n_tile * WNB + half * 32 + cl;
-    const bool nok = n < p.Cd;
-    const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+    const int n = n_tile * WNB + half * 32 + cq * 4;
+    const bool nok = n < p.Cd;                       // Cd % 4 == 0 (wino_variant): the four channels are in or out together
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (nok && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    f32x4 m[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int tile = tg + 16 * q;
-      float m[16];
+    for (int k = 0; k < 16; ++k) m[k] = *reinterpret_cast<const f32x4*>(lds + k * 2048 + et * 32 + cq * 4);
+    f32x4 y[OT][OT];
+    if constexpr (MODE == 0) {
+      f32x4 s0[4], s1[4];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) m[k] = lds[k * 2048 + tile * 32 + cl];
-      float y[OT][OT];
-      if constexpr (MODE == 0) {
-        float s0[4], s1[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          s0[c] = m[0 * 4 + c] + m[1 * 4 + c] + m[2 * 4 + c];
-          s1[c] = m[1 * 4 + c] - m[2 * 4 + c] - m[3 * 4 + c];
-        }
-        y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s0[1] - s0[2] - s0[3];
-        y[1][0] = s1[0] + s1[1] + s1[2]; y[1][1] = s1[1] - s1[2] - s1[3];
-      } else {
-        float h[3][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          h[0][c] = m[0 * 4 + c] + 0.5f * (m[1 * 4 + c] + m[2 * 4 + c]);
-          h[1][c] = 0.5f * (m[1 * 4 + c] - m[2 * 4 + c]);
-          h[2][c] = 0.5f * (m[1 * 4 + c] + m[2 * 4 + c]) + m[3 * 4 + c];
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          y[a][0] = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
-          y[a][1] = 0.5f * (h[a][1] - h[a][2]);
-          y[a][2] = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
-        }
+      for (int c = 0; c < 4; ++c) {
+        s0[c] = m[0 * 4 + c] + m[1 * 4 + c] + m[2 * 4 + c];
+        s1[c] = m[1 * 4 + c] - m[2 * 4 + c] - m[3 * 4 + c];
       }
-      const int o = tile_o[tile], f = tile_f[tile];
-      if (nok && o >= 0) {
-        const int nr = f & 15, nc = f >> 4;
-        float* dp = p.dst + (size_t)o * p.Cd + n;
+      y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s0[1] - s0[2] - s0[3];
+      y[1][0] = s1[0] + s1[1] + s1[2]; y[1][1] = s1[1] - s1[2] - s1[3];
+    } else {
+      f32x4 h[3][4];
 #pragma unroll
-        for (int a = 0; a < OT; ++a)
-#pragma unroll
-          for (int b = 0; b < OT; ++b)
-            if (a < nr && b < nc) dp[(size_t)(a * p.Wo + b) * PS * p.Cd] = apply_act(y[a][b] + bv, p.act, p.slope);
+      for (int c = 0; c < 4; ++c) {
+        h[0][c] = m[0 * 4 + c] + 0.5f * (m[1 * 4 + c] + m[2 * 4 + c]);
+        h[1][c] = 0.5f * (m[1 * 4 + c] - m[2 * 4 + c]);
+        h[2][c] = 0.5f * (m[1 * 4 + c] + m[2 * 4 + c]) + m[3 * 4 + c];
       }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        y[a][0] = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
+        y[a][1] = 0.5f * (h[a][1] - h[a][2]);
+        y[a][2] = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
+      }
+    }
+    const int o = tile_o[et], f = tile_f[et];
+    if (nok && o >= 0) {
+      const int nr = f & 15, nc = f >> 4;
+      float* dp = p.dst + (size_t)o * p.Cd + n;
+#pragma unroll
+      for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < OT; ++b2)
+          if (a < nr && b2 < nc) {
+            f32x4 v = y[a][b2] + bv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], p.act, p.slope);
+            *reinterpret_cast<f32x4*>(dp + (size_t)(a * p.Wo + b2) * PS * p.Cd) = v;
+          }
     }
   }
 }
@@ -742,7 +746,7 @@ static int wino_variant(const srgan_conv_desc* d, int kind) {
   if (wino_disabled() || compute_bf16()) return 0;       // bf16 mode: the transforms would eat the 8-bit mantissa
 
   const int C = kind == 0 ? d->I : d->O, N = kind == 0 ? d->O : d->I;
-  if (C % (2 * WC) != 0 || C < 32 || N < 32) return 0;   // an even number of 8-channel chunks
+  if (C % (2 * WC) != 0 || C < 32 || N < 32 || N % 4 != 0) return 0;   // an even number of 8-channel chunks; 16-byte stores
   // the gather's "outside" offset (2 GiB) must lie past the end of the source tensor
   const long long src_elems = (long long)d->N * (kind == 0 ? (long long)d->Hi * d->Wi * d->I : (long long)d->Ho * d->Wo * d->O);
   if (src_elems >= (1LL << 29)) return 0;
