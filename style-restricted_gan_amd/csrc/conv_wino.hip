@@ -642,8 +642,8 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
   }
 
   // ---- epilogue: G^T dU G (3x3 taps) or A^T dU A (the 2x2 taps of this input phase) per (o, i), two halves of 32
-  // input channels; slab[split][o][tap * C + i] ----
-  const int cl = tid & 31, tg = tid >> 5;
+  // input channels; slab[split][o][tap * C + i]; thread = (output channel, 4 input channels): 16-byte reads and stores ----
+  const int cq = tid & 7, row = tid >> 3;
   constexpr int NT = MODE == 0 ? 9 : 16;
   float* slab = p.slab + (size_t)split * p.Opad * (NT * p.C);
 #pragma unroll
@@ -655,47 +655,43 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          lds[(2 * wave + a) * 2048 + row * 32 + lr] = acc[a][i][half][e];
+          const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          lds[(2 * wave + a) * 2048 + r * 32 + lr] = acc[a][i][half][e];
         }
     __syncthreads();
-    const int ic = i_tile * 64 - phase * p.C + half * 32 + cl;
+    const int ic = i_tile * 64 - phase * p.C + half * 32 + cq * 4;      // C % 64 == 0: the four channels are in or out together
+    const int oc = o_tile * 64 + row;
+    f32x4 u[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = tg + 16 * q;
-      const int oc = o_tile * 64 + row;
-      float u[16];
+    for (int k = 0; k < 16; ++k) u[k] = *reinterpret_cast<const f32x4*>(lds + k * 2048 + row * 32 + cq * 4);
+    if (oc < p.O && ic < p.C) {
+      float* dst = slab + (size_t)oc * (NT * p.C) + ic;
+      if constexpr (MODE == 0) {
+        f32x4 h[3][4];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) u[k] = lds[k * 2048 + row * 32 + cl];
-      if (oc < p.O && ic < p.C) {
-        float* dst = slab + (size_t)oc * (NT * p.C) + ic;
-        if constexpr (MODE == 0) {
-          float h[3][4];
+        for (int c = 0; c < 4; ++c) {
+          h[0][c] = u[0 * 4 + c] + 0.5f * (u[1 * 4 + c] + u[2 * 4 + c]);
+          h[1][c] = 0.5f * (u[1 * 4 + c] - u[2 * 4 + c]);
+          h[2][c] = 0.5f * (u[1 * 4 + c] + u[2 * 4 + c]) + u[3 * 4 + c];
+        }
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            h[0][c] = u[0 * 4 + c] + 0.5f * (u[1 * 4 + c] + u[2 * 4 + c]);
-            h[1][c] = 0.5f * (u[1 * 4 + c] - u[2 * 4 + c]);
-            h[2][c] = 0.5f * (u[1 * 4 + c] + u[2 * 4 + c]) + u[3 * 4 + c];
-          }
+        for (int a = 0; a < 3; ++a) {
+          *reinterpret_cast<f32x4*>(dst + (a * 3 + 0) * p.C) = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
+          *reinterpret_cast<f32x4*>(dst + (a * 3 + 1) * p.C) = 0.5f * (h[a][1] - h[a][2]);
+          *reinterpret_cast<f32x4*>(dst + (a * 3 + 2) * p.C) = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
+        }
+      } else {
+        f32x4 h[2][4];
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            dst[(a * 3 + 0) * p.C] = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
-            dst[(a * 3 + 1) * p.C] = 0.5f * (h[a][1] - h[a][2]);
-            dst[(a * 3 + 2) * p.C] = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
-          }
-        } else {
-          float h[2][4];
+        for (int c = 0; c < 4; ++c) {
+          h[0][c] = u[0 * 4 + c] + u[1 * 4 + c] + u[2 * 4 + c];
+          h[1][c] = u[1 * 4 + c] - u[2 * 4 + c] - u[3 * 4 + c];
+        }
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            h[0][c] = u[0 * 4 + c] + u[1 * 4 + c] + u[2 * 4 + c];
-            h[1][c] = u[1 * 4 + c] - u[2 * 4 + c] - u[3 * 4 + c];
-          }
-#pragma unroll
-          for (int a = 0; a < 2; ++a) {
-            const int ky = 2 * a + ph_p;
-            dst[(ky * 4 + 0 + ph_q) * p.C] = h[a][0] + h[a][1] + h[a][2];
-            dst[(ky * 4 + 2 + ph_q) * p.C] = h[a][1] - h[a][2] - h[a][3];
-          }
+        for (int a = 0; a < 2; ++a) {
+          const int ky = 2 * a + ph_p;
+          *reinterpret_cast<f32x4*>(dst + (ky * 4 + 0 + ph_q) * p.C) = h[a][0] + h[a][1] + h[a][2];
+          *reinterpret_cast<f32x4*>(dst + (ky * 4 + 2 + ph_q) * p.C) = h[a][1] - h[a][2] - h[a][3];
         }
       }
     }
