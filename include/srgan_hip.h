@@ -85,6 +85,13 @@ int srgan_conv2d_pack_multi(const void* entries_dev, int n_entries, void* stream
 int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, const float* dy, float* dw,
                        float* dbias, void* ws, size_t ws_bytes, void* stream);
 
+/* The same gradient from the transformed input the FORWARD of an F(4x4,3x3) layer already wrote (pyfiles/model.py:191,193: the
+ * residual-trunk convs): when srgan_conv2d_wgrad_v_bytes(d) != 0, hand srgan_conv2d_fwd_packed a buffer of that many bytes as
+ * `ws` and keep it until the backward pass; srgan_conv2d_wgrad_v then needs neither x nor a second input transform. */
+size_t srgan_conv2d_wgrad_v_bytes(const srgan_conv_desc* d);
+int srgan_conv2d_wgrad_v(const srgan_conv_desc* d, const float* v_image, const float* dy, float* dw,
+                         float* dbias, void* ws, size_t ws_bytes, void* stream);
+
 /* Instance norm + per-(n,c) affine + activation (+ residual):
  *   xh = (x - mean_nc) * rstd_nc ; y = act(xh * scale[n,c] + shift[n,c]) (+ res)
  * F.instance_norm(eps=1e-5, biased var) at model.py:58-60 (CBIN), nn.InstanceNorm2d at

@@ -99,6 +99,10 @@ struct WinoParams {
 // conv_wino43.hip: F(4x4,3x3) kernel behind wino_run
 size_t wino43_scratch_floats(long long T, int C);
 int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops, hipStream_t st);
+// F(4x4,3x3) weight gradient from the forward's V image (conv_wino43.hip; geometry and dispatch in conv_wino.hip)
+struct Wino43WgradGeom { int NB, H, W, C, O, ntc, splits, chunks_per_split; size_t v_bytes, z_bytes, slab_bytes; };
+bool wino43_wgrad_geometry(const srgan_conv_desc* d, Wino43WgradGeom* g);      // false: not applicable
+int wino43_wgrad_launch(const Wino43WgradGeom& g, const float* vimg, const float* dy, float* zimg, float* slab, double flops, hipStream_t st);
 // conv_wino.hip: Winograd F(2x2,3x3) for 3x3 stride-1 pad-1 layers; kind 0 = forward, 1 = input gradient
 bool wino_applicable(const srgan_conv_desc* d, int kind);
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind);

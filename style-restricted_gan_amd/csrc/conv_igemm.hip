@@ -43,8 +43,8 @@ static const char* const kProfNames[] = {
     "igemm_kernel<128,32,4,1,gen>",  "igemm_kernel<128,32,4,1,vec>",  "igemm_kernel<64,64,2,2,gen>",  "igemm_kernel<64,64,2,2,vec>",
     "wgrad_kernel<gen>", "wgrad_kernel<vec>", "igemm_kernel<256,128,4,2,gen>", "igemm_kernel<256,128,4,2,vec>",
     "igemm_kernel<256,64,4,2,gen>", "igemm_kernel<256,64,4,2,vec>", "wino_kernel", "wino_wgrad_kernel", "wino_kernel<4x4s2>", "wino_wgrad_kernel<4x4s2>",
-    "wino43_kernel", "wino43_input_kernel", "rgbin_conv_kernel", "rgb_wgrad_kernel"};
-constexpr int kProfKernels = 22;
+    "wino43_kernel", "wino43_input_kernel", "rgbin_conv_kernel", "rgb_wgrad_kernel", "wino43_wgrad_kernel", "wino43_dy_kernel"};
+constexpr int kProfKernels = 24;
 
 struct ProfScope {
   bool on;
@@ -1153,6 +1153,10 @@ extern "C" size_t srgan_conv2d_workspace(const srgan_conv_desc* d) {
   size_t cs = (size_t)1024 * d->O * sizeof(float);
   if (wg + cs > bytes) bytes = wg + cs;
   if (narrow_applicable(d)) bytes = std::max(bytes, narrow_workspace(d) + cs);
+  {
+    Wino43WgradGeom wg43{};
+    if (wino43_wgrad_geometry(d, &wg43)) bytes = std::max(bytes, (size_t)round_up((long long)(wg43.slab_bytes + cs), 256) + wg43.z_bytes);
+  }
   return bytes + 4096;
 }
 
@@ -1527,6 +1531,36 @@ extern "C" int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* 
   const size_t need = srgan_conv2d_packed_scratch(d, 1);
   SRGAN_REQUIRE(need == 0 || (ws && ws_bytes >= need), "conv2d_dgrad_packed: workspace too small (srgan_conv2d_packed_scratch)");
   return dgrad_run(d, dy, (const float*)packed, dx, (float*)ws, as_stream(stream));
+}
+
+namespace srgan {
+static int finish_wgrad(const srgan_conv_desc* d, const WgradPlan& w, const float* dy, float* dw, float* dbias, void* ws,
+                        hipStream_t st);
+}
+
+// Weight gradient of a layer whose forward kept its F(4x4,3x3) V image (srgan_conv2d_wgrad_v_bytes(d) != 0 bytes, handed to
+// srgan_conv2d_fwd_packed as `ws` and kept alive by the caller instead of the shared scratch).
+extern "C" size_t srgan_conv2d_wgrad_v_bytes(const srgan_conv_desc* d) {
+  if (validate(d) != 0) return 0;
+  Wino43WgradGeom g{};
+  return wino43_wgrad_geometry(d, &g) ? g.v_bytes : 0;
+}
+
+extern "C" int srgan_conv2d_wgrad_v(const srgan_conv_desc* d, const float* v_image, const float* dy, float* dw, float* dbias,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(v_image && dy && dw && ws, "conv2d_wgrad_v: null pointer");
+  SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_wgrad_v: workspace too small");
+  Wino43WgradGeom g{};
+  SRGAN_REQUIRE(wino43_wgrad_geometry(d, &g), "conv2d_wgrad_v: layer not applicable");
+  hipStream_t st = as_stream(stream);
+  const size_t cs = (size_t)1024 * d->O * sizeof(float);
+  float* zimg = reinterpret_cast<float*>(static_cast<char*>(ws) + round_up((long long)(g.slab_bytes + cs), 256));
+  if (int e = wino43_wgrad_launch(g, v_image, dy, zimg, (float*)ws, conv_flops(d), st)) return e;
+  if (int e = check_launch("wino43_wgrad_kernel")) return e;
+  WgradPlan w = plan_wgrad(d);
+  w.splits = g.splits; w.Cdpad = d->O; w.NNpad = 9 * d->I;
+  return finish_wgrad(d, w, dy, dw, dbias, ws, st);
 }
 
 namespace srgan {

@@ -799,6 +799,27 @@ size_t wino_scratch_bytes(const srgan_conv_desc* d, int kind) {
   return wino43_scratch_floats((long long)d->N * (ho / 4) * (wo / 4), kind == 0 ? d->I : d->O) * sizeof(float);
 }
 
+// Weight gradient of an F(4x4,3x3) layer from the V image its forward wrote (conv_wino43.hip): applicable when the forward runs
+// that path, Cin % 64 == 0, Cout % 32 == 0; split-K over 8-tile chunks so that ~256 workgroups run.
+bool wino43_wgrad_geometry(const srgan_conv_desc* d, Wino43WgradGeom* g) {
+  static const bool off = std::getenv("SRGAN_NO_WINOGRAD43_WGRAD") != nullptr;
+  if (off || wino_variant(d, 0) != 3 || d->I % 64 != 0 || d->O % 32 != 0) return false;
+  const long long T = (long long)d->N * (d->Ho / 4) * (d->Wo / 4);
+  const long long ntc = ceil_div(T, 64) * 8;
+  const int tiles = (d->O / 32) * (d->I / 64);
+  long long splits = std::max(1, 256 / tiles);
+  long long cps = std::max<long long>(2, ceil_div(ntc, splits));
+  if (ntc % cps == 1) ++cps;                       // the last split needs two chunks too
+  splits = ceil_div(ntc, cps);
+  if (ntc < 2 || ntc - (splits - 1) * cps < 2) return false;
+  g->NB = d->N; g->H = d->Ho; g->W = d->Wo; g->C = d->I; g->O = d->O; g->ntc = (int)ntc;
+  g->splits = (int)splits; g->chunks_per_split = (int)cps;
+  g->v_bytes = wino_scratch_bytes(d, 0);
+  g->z_bytes = (size_t)(d->O / 32) * ntc * 36 * 256 * sizeof(float);
+  g->slab_bytes = (size_t)splits * d->O * 9 * d->I * sizeof(float);
+  return g->v_bytes < (1ULL << 32) && g->z_bytes < (1ULL << 32);
+}
+
 void wino_pack_params(const srgan_conv_desc* d, int kind, const float* w, float* dst, WinoPackParams* out) {
   WinoPackParams q{};
   int C, N;

@@ -306,10 +306,212 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
   else role(std::integral_constant<int, 0>{});
 }
 
+// ---- weight gradient on the SAME transformed input:  dU[pos][o][c] = sum_tiles Z[pos][tile][o] * V[pos][tile][c],
+//      Z = A dY A^T (6x6 from the 4x4 output-gradient tile),  dW = G^T dU G  ----
+// V is the image the forward pass wrote (kept by the caller instead of being scratch), so the weight gradient costs one
+// transform pass (dy -> Z) instead of two and 1.78x fewer MFMA FLOPs than the F(2x2,3x3) kernel.
+// wino43_dy_kernel writes Z as the A-operand register image [32-o block][8-tile chunk][36 pos][lane = half * 32 + o][4 tiles];
+// wino43_wgrad_kernel is wino43_kernel with the reduce index = tiles: workgroup = 32 o x 64 c x 36 positions over a split of
+// the tile chunks; the B operand comes from the forward image [tile block][c chunk][pos][quad][64 tiles][4 c] -- 576 pieces of
+// 128 bytes per 8-tile chunk, copied to LDS as [pos][c quad 16][tile ^ (quad & 7)][4 c] (the XOR keeps the four ds_read_b32 of
+// a fragment off each other's banks); epilogue: 8 output channels per pass meet in LDS, thread = (o, c) applies G^T . G and
+// writes nine taps into the [split][O][9 C] slab of the split-K reduce.
+struct Wino43WgradParams {
+  const float* vimg;
+  const float* zimg;
+  float* slab;
+  int C, O, cchunks, ntc, chunks_per_split, splits, c_blocks, o_blocks;
+};
+
+struct Wino43DyParams {
+  const float* dy;    // [NB][H][W][O]
+  float* zimg;
+  int NB, H, W, O, TH, TW, T, ntc, o_blocks;
+};
+
+__global__ __launch_bounds__(512) void wino43_dy_kernel(Wino43DyParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long unit = (long long)blockIdx.x * 8 + wave;      // one wave = one (tile chunk, o block)
+  if (unit >= (long long)p.ntc * p.o_blocks) return;
+  const int o_blk = (int)(unit % p.o_blocks), tchunk = (int)(unit / p.o_blocks);
+  const int o = o_blk * 32 + (lane & 31), lh = lane >> 5;
+  const auto rs = uniform_rsrc43(p.dy, (unsigned)((size_t)p.NB * p.H * p.W * p.O * 4));
+  float z[36][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = tchunk * 8 + lh * 4 + j;
+    const bool tv = t < p.T;
+    const int tt = tv ? t : 0;
+    const int per = p.TH * p.TW;
+    const int nb = tt / per;
+    const int r0 = tt - nb * per;
+    const int ty = r0 / p.TW, tx = r0 - ty * p.TW;
+    const unsigned base = tv ? (unsigned)(((nb * p.H + 4 * ty) * p.W + 4 * tx) * p.O + o) * 4u : 0x80000000u;
+    float e[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        e[a][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, base, (a * p.W + b) * p.O * 4, 0));
+    // A = [1 0 0 0; 1 1 1 1; 1 -1 1 -1; 1 2 4 8; 1 -2 4 -8; 0 0 0 1]: columns first, then rows
+    float h[6][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float v0 = e[0][b], v1 = e[1][b], v2 = e[2][b], v3 = e[3][b];
+      const float s02 = v0 + v2, s13 = v1 + v3, q02 = v0 + 4.f * v2, q13 = 2.f * v1 + 8.f * v3;
+      h[0][b] = v0; h[1][b] = s02 + s13; h[2][b] = s02 - s13; h[3][b] = q02 + q13; h[4][b] = q02 - q13; h[5][b] = v3;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const float v0 = h[r][0], v1 = h[r][1], v2 = h[r][2], v3 = h[r][3];
+      const float s02 = v0 + v2, s13 = v1 + v3, q02 = v0 + 4.f * v2, q13 = 2.f * v1 + 8.f * v3;
+      z[r * 6 + 0][j] = v0; z[r * 6 + 1][j] = s02 + s13; z[r * 6 + 2][j] = s02 - s13;
+      z[r * 6 + 3][j] = q02 + q13; z[r * 6 + 4][j] = q02 - q13; z[r * 6 + 5][j] = v3;
+    }
+  }
+  float* out = p.zimg + ((size_t)(o_blk * p.ntc + tchunk) * 36) * 256 + lane * 4;
+#pragma unroll
+  for (int k = 0; k < 36; ++k) {
+    const f32x4 v = {z[k][0], z[k][1], z[k][2], z[k][3]};
+    *reinterpret_cast<f32x4*>(out + k * 256) = v;
+  }
+}
+
+__global__ __launch_bounds__(512) void wino43_wgrad_kernel(Wino43WgradParams p) {
+  constexpr int BSZ = 36 * 512;                    // floats of one chunk image in LDS: [36 pos][16 c quads][8 tiles][4 c]
+  __shared__ __attribute__((aligned(16))) float lds[2 * BSZ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  int bid = blockIdx.x;
+  const int per_split = p.o_blocks * p.c_blocks;
+  const int split = bid / per_split;
+  bid -= split * per_split;
+  const int o_blk = bid / p.c_blocks, cb = bid - o_blk * p.c_blocks;
+  const int tc0 = split * p.chunks_per_split;
+  const int nk = min(p.chunks_per_split, p.ntc - tc0);      // >= 2 (wino43_wgrad_plan)
+
+  const auto rs_v = uniform_rsrc43(p.vimg, (unsigned)((size_t)(p.ntc >> 3) * p.cchunks * W4BLK * 4));
+  const auto rs_u = uniform_rsrc43(p.zimg + ((size_t)o_blk * p.ntc + tc0) * (36 * 256), (unsigned)nk * (36u * 1024u));
+
+  // copy role: float4 j * 512 + tid of the chunk -> position 4 j + tid / 128, c quad (tid / 8) & 15, tile tid & 7
+  f32x4 stage[9];
+  const int cq = (tid >> 3) & 15;
+  const unsigned vsrc = (unsigned)((cq >> 1) * W4BLK + (tid >> 7) * 512 + (cq & 1) * 256 + (tid & 7) * 4) * 4u;
+  const int vst = (tid >> 7) * 512 + cq * 32 + (((tid & 7) ^ (cq & 7))) * 4;
+  auto load_v1 = [&](int kc, int j) __attribute__((always_inline)) {
+    const int tc = tc0 + kc;
+    const unsigned so = (unsigned)(((tc >> 3) * p.cchunks + cb * 8) * W4BLK + (tc & 7) * 32 + j * 2048) * 4u;
+    stage[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vsrc, so, 0));
+  };
+  auto store_v1 = [&](int buf, int j) __attribute__((always_inline)) {
+    *reinterpret_cast<f32x4*>(lds + buf * BSZ + vst + j * 2048) = stage[j];
+  };
+
+  auto role = [&](auto odd_c) __attribute__((always_inline)) {
+    constexpr int ODD = decltype(odd_c)::value;
+    const int pbase = (9 * wave) >> 1;
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    f32x4 ufr[5];
+    const unsigned ulane = (unsigned)(pbase * 256 + lane * 4) * 4u;
+    auto load_u = [&](int a, int kc) __attribute__((always_inline)) {
+      ufr[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ulane, kc * (36 * 1024) + a * 1024, 0));
+    };
+    // B fragment of unit (position a, c half h), step s: tile 4 lh + s, channel 32 h + lr
+    const int g4 = lr >> 2;
+    const int vrd = pbase * 512 + g4 * 32 + (lr & 3);
+    int tsl[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) tsl[s] = ((4 * lh + s) ^ g4) * 4;
+    auto read_b = [&](const float* V, int g, float* dst) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dst[s] = V[(g >> 1) * 512 + (g & 1) * 256 + tsl[s]];
+    };
+    auto mma_chunk = [&](int kc, auto reload, auto st_c, auto ld_c) __attribute__((always_inline)) {
+      constexpr bool RL = decltype(reload)::value, ST = decltype(st_c)::value, LD = decltype(ld_c)::value;
+      const float* V = lds + (kc & 1) * BSZ + vrd;
+      float vf[2][4];
+      read_b(V, ODD, vf[0]);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int g = i + ODD, a = g >> 1, h = g & 1;
+        if (i + 1 < 9) read_b(V, g + 1, vf[(i + 1) & 1]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[a][s], vf[i & 1][s], acc[i], 0, 0, 0);
+        if (RL && (h == 1 || i == 8)) load_u(a, kc + 1);
+        if constexpr (ST) store_v1((kc + 1) & 1, i);
+        if constexpr (LD) load_v1(kc + 2, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) load_v1(0, j);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) store_v1(0, j);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) load_v1(1, j);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < 5; ++a) load_u(a, 0);
+    __syncthreads();
+    int kc = 0;
+    for (; kc + 2 < nk; ++kc) {
+      mma_chunk(kc, T{}, T{}, T{});
+      __syncthreads();
+    }
+    mma_chunk(kc, T{}, T{}, F{});
+    __syncthreads();
+    mma_chunk(kc + 1, F{}, F{}, F{});
+
+    // ---- epilogue: 8 output channels per pass meet in LDS as X[pos][o][64 c] (two buffers); thread = (o, c) ----
+    const int eo = tid >> 6, ec = tid & 63;
+    float* slab = p.slab + ((size_t)split * p.O + o_blk * 32) * (9 * p.C) + cb * 64 + ec;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      __syncthreads();                             // pass k - 2 has been read (k = 0: the V buffers are free)
+      float* X = lds + (k & 1) * BSZ;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int g = i + ODD, a = g >> 1, h = g & 1;
+        // accumulator lane = channel 32 h + lr, register e = output channel 8 * (e / 4) + 4 * lh + e % 4
+#pragma unroll
+        for (int j = 0; j < 4; ++j) X[(pbase + a) * 512 + (4 * lh + j) * 64 + h * 32 + lr] = acc[i][4 * k + j];
+      }
+      __syncthreads();
+      const float* M = X + eo * 64 + ec;
+      // t[a][c] = sum_r G[r][a] M[r][c],  G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+      float t[3][6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const float m0 = M[(0 * 6 + c) * 512], m1 = M[(1 * 6 + c) * 512], m2 = M[(2 * 6 + c) * 512], m3 = M[(3 * 6 + c) * 512],
+                    m4 = M[(4 * 6 + c) * 512], m5 = M[(5 * 6 + c) * 512];
+        const float s12 = m1 + m2, d12 = m2 - m1, s34 = m3 + m4, d34 = m3 - m4;
+        t[0][c] = 0.25f * m0 - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+        t[1][c] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+        t[2][c] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + m5;
+      }
+      float* dst = slab + (size_t)(8 * k + eo) * (9 * p.C);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float s12 = t[a][1] + t[a][2], d12 = t[a][2] - t[a][1], s34 = t[a][3] + t[a][4], d34 = t[a][3] - t[a][4];
+        dst[(a * 3 + 0) * p.C] = 0.25f * t[a][0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+        dst[(a * 3 + 1) * p.C] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+        dst[(a * 3 + 2) * p.C] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + t[a][5];
+      }
+    }
+  };
+  if (wave & 1) role(std::integral_constant<int, 1>{});
+  else role(std::integral_constant<int, 0>{});
+}
+
 size_t wino43_scratch_floats(long long T, int C) { return (size_t)ceil_div(T, (long long)W4T) * (C / W4C) * W4BLK; }
 
-// `vimg`: wino43_scratch_floats(T, C) floats of scratch (the caller keeps them behind the packed filters)
-// (`flops`: the layer's ALGORITHMIC FLOPs, booked on the multiply kernel; the input transform is HBM-bound and has its own slot)
+// `flops`: the layer's ALGORITHMIC FLOPs, booked on the multiply kernel; the input transform is HBM-bound and has its own slot
 int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops, hipStream_t st) {
   // SRGAN_W43_ONLY=1 / 2 (timing experiments only): launch just the input transform / just the multiply kernel
   static const int only = std::getenv("SRGAN_W43_ONLY") ? std::atoi(std::getenv("SRGAN_W43_ONLY")) : 0;
@@ -323,6 +525,26 @@ int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops
     hipLaunchKernelGGL(wino43_kernel, dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
     prof_end(tok, st);
   }
+  return 0;
+}
+
+// Weight gradient from the forward's V image.  g: geometry from wino43_wgrad_geometry (conv_wino.hip); zimg: Z scratch.
+int wino43_wgrad_launch(const Wino43WgradGeom& g, const float* vimg, const float* dy, float* zimg, float* slab, double flops,
+                        hipStream_t st) {
+  Wino43DyParams q{};
+  q.dy = dy; q.zimg = zimg; q.NB = g.NB; q.H = g.H; q.W = g.W; q.O = g.O; q.TH = g.H / 4; q.TW = g.W / 4;
+  q.T = g.NB * q.TH * q.TW; q.ntc = g.ntc; q.o_blocks = g.O / 32;
+  {
+    ProfToken tok = prof_begin(23, 0.0, st);
+    hipLaunchKernelGGL(wino43_dy_kernel, dim3((unsigned)ceil_div((long long)q.ntc * q.o_blocks, 8)), dim3(512), 0, st, q);
+    prof_end(tok, st);
+  }
+  Wino43WgradParams p{};
+  p.vimg = vimg; p.zimg = zimg; p.slab = slab; p.C = g.C; p.O = g.O; p.cchunks = g.C / 8; p.ntc = g.ntc;
+  p.chunks_per_split = g.chunks_per_split; p.splits = g.splits; p.c_blocks = g.C / 64; p.o_blocks = g.O / 32;
+  ProfToken tok = prof_begin(22, flops, st);
+  hipLaunchKernelGGL(wino43_wgrad_kernel, dim3((unsigned)(p.o_blocks * p.c_blocks * p.splits)), dim3(512), 0, st, p);
+  prof_end(tok, st);
   return 0;
 }
 

@@ -243,6 +243,13 @@ def refresh_packed(params):
     if tab is None:
         ids = set(tkey)
         hits = [h for k, h in _pack_cache.items() if k[0] in ids]
+        for h in hits:
+            # the layout of an operand follows the kernel dispatch (compute mode, SRGAN_* switches): an entry made under another
+            # dispatch gets a buffer of the size the current one wants before anything is packed into it
+            want = lib.srgan_conv2d_packed_bytes(ctypes.byref(h.desc), h.kind, h.act)
+            if want != h.buf.numel():
+                h.buf = torch.empty(want, dtype=torch.uint8, device=h.buf.device)
+                h.scratch = lib.srgan_conv2d_packed_scratch(ctypes.byref(h.desc), h.kind)
         nb = lib.srgan_pack_entry_bytes()
         multi, singles, blob = [], [], bytearray()
         for h in hits:
@@ -276,11 +283,12 @@ def refresh_packed(params):
         _pack_one(h)
 
 
-def _run_conv_fwd(desc, x, weight, bias, y, act, slope):
+def _run_conv_fwd(desc, x, weight, bias, y, act, slope, keep_v=None):
     lib = _lib.load()
     if _pack_cache_on:
         hit = _packed(desc, weight, 0, act)
-        ws = workspace(x.device, hit.scratch) if hit.scratch else None
+        # keep_v: the caller's own buffer for the F(4x4,3x3) transformed input (kept for the weight gradient) instead of scratch
+        ws = keep_v if keep_v is not None else (workspace(x.device, hit.scratch) if hit.scratch else None)
         _lib.check(lib.srgan_conv2d_fwd_packed(ctypes.byref(desc), _ptr(x), _ptr(hit.buf), _ptr(bias), _ptr(y), act,
                                                float(slope), _ptr(ws), hit.scratch, _stream()), "conv2d_fwd_packed")
         return
@@ -302,8 +310,12 @@ def _run_conv_dgrad(desc, dy, weight, dx):
                                       _stream()), "conv2d_dgrad")
 
 
-def _run_conv_wgrad(desc, x, dy, dw, dbias):
+def _run_conv_wgrad(desc, x, dy, dw, dbias, v_image=None):
     ws, nb = _conv_ws(desc, x.device)
+    if v_image is not None:
+        _lib.check(_lib.load().srgan_conv2d_wgrad_v(ctypes.byref(desc), _ptr(v_image), _ptr(dy), _ptr(dw), _ptr(dbias), _ptr(ws),
+                                                    nb, _stream()), "conv2d_wgrad_v")
+        return
     _lib.check(_lib.load().srgan_conv2d_wgrad(ctypes.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias), _ptr(ws),
                                               nb, _stream()), "conv2d_wgrad")
 
@@ -327,7 +339,14 @@ class _Conv2dFn(Function):
         wo = (wi + 2 * pad - kw) // stride + 1
         desc = _conv_desc(n, hi, wi, i, ho, wo, o, kh, kw, stride, pad, pad_mode, weight)
         y = nhwc_empty(n, o, ho, wo, x.device)
-        _run_conv_fwd(desc, x, weight, bias, y, act, slope)
+        # F(4x4,3x3) layers: the forward's transformed input serves the weight gradient too -- keep it instead of scratch
+        keep_v = None
+        if _pack_cache_on and ctx.needs_input_grad[1]:
+            nv = _lib.load().srgan_conv2d_wgrad_v_bytes(ctypes.byref(desc))
+            if nv:
+                keep_v = torch.empty(nv, dtype=torch.uint8, device=x.device)
+        _run_conv_fwd(desc, x, weight, bias, y, act, slope, keep_v)
+        ctx.v_image = keep_v
         ctx.desc, ctx.act, ctx.slope = desc, act, slope
         ctx.weight = weight            # by reference: read at backward time (torch 1.4 semantics)
         ctx.has_bias = bias is not None
@@ -351,7 +370,7 @@ class _Conv2dFn(Function):
             desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
             if ctx.has_bias:
                 db = torch.empty(weight.shape[0], dtype=torch.float32, device=weight.device)
-            _run_conv_wgrad(desc, x, gy, dw, db)
+            _run_conv_wgrad(desc, x, gy, dw, db, ctx.v_image)
         return dx, dw, db, None, None, None, None, None
 
 

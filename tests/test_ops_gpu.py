@@ -114,6 +114,34 @@ def test_conv2d_fwd_bwd(ops, case, dispatch):
         close(bd.grad, b.grad, 5e-5)
 
 
+@pytest.mark.parametrize("case", [(32, 64, 32, 32, 128, True), (3, 64, 8, 12, 96, True), (5, 128, 16, 16, 64, False),
+                                  (2, 256, 32, 32, 256, False)])
+def test_conv2d_f43_weight_gradient_from_kept_image(ops, case, dispatch):
+    """Inside a pack-cache scope (the trainer's mode) the forward of an F(4x4,3x3) layer keeps its transformed input and the
+    weight gradient is computed from it (srgan_conv2d_wgrad_v): ragged tile blocks, several splits, bias."""
+    n, i, h, w, o, has_bias = case
+    torch.set_num_threads(16)
+    x = rnd(n, i, h, w, seed=11).requires_grad_(True)
+    wt = (rnd(o, i, 3, 3, seed=12) / np.sqrt(i * 9)).requires_grad_(True)
+    b = (rnd(o, seed=13) * 0.1).requires_grad_(True) if has_bias else None
+    yr = F.conv2d(x, wt, b, 1, 1)
+    gy = rnd(*yr.shape, seed=14)
+    yr.backward(gy)
+    xd = x.detach().cuda().requires_grad_(True)
+    wd = wt.detach().cuda().requires_grad_(True)
+    bd = b.detach().cuda().requires_grad_(True) if has_bias else None
+    ops.invalidate_packed()            # entries of earlier tests were laid out under another dispatch setting
+    with ops.pack_cache():
+        y = ops.conv2d(xd, wd, bd, 1, 1, ops.PAD_ZERO)
+        y.backward(gy.cuda())
+    ops.invalidate_packed()
+    close(y, yr)
+    close(xd.grad, x.grad)
+    close(wd.grad, wt.grad, 5e-5)
+    if has_bias:
+        close(bd.grad, b.grad, 5e-5)
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
