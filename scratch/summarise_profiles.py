@@ -26,6 +26,10 @@ def prof_name(n):
         return "rgbin_conv_kernel"
     if n.startswith("rgb_wgrad_kernel"):
         return "rgb_wgrad_kernel"
+    if n.startswith("wino43_wgrad_kernel"):
+        return "wino43_wgrad_kernel"
+    if n.startswith("wino43_dy_kernel"):
+        return "wino43_dy_kernel"
     if n.startswith("wino43_input_kernel"):
         return "wino43_input_kernel"
     if n.startswith("wino43_kernel"):
