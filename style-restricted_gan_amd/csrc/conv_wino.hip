@@ -924,7 +924,8 @@ static int wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
   if (variant == 1) {
     if (blocks < 16 * ts || chunks < 4 * ts) return 0;      // too few workgroups / too short a K range: implicit GEMM instead
   } else {
-    if (blocks < 192 * ts || chunks < 48 * ts) return 0;    // measured: the discriminator's small maps stay faster on the implicit GEMM
+    static const int min_blocks = std::getenv("SRGAN_WGRAD_S2_MIN_BLOCKS") ? std::atoi(std::getenv("SRGAN_WGRAD_S2_MIN_BLOCKS")) : 192;
+    if (blocks < min_blocks * ts || chunks < 48 * ts) return 0;    // measured: the discriminator's small maps stay faster on the implicit GEMM
   }
   return variant;
 }
