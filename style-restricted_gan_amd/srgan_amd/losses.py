@@ -108,8 +108,13 @@ def _normalise_target(h):
 def class_encode(label, device, ref_class):
     """Rows of the reference label table (one-hot by default) for each sample   (util.py:205-234)."""
     table = torch.tensor(np.asarray(ref_class), dtype=torch.float32)
+    if torch.is_tensor(label) and label.is_cuda:
+        # labels already on the device: look the rows up there (a .cpu() here would stall the host on the whole stream)
+        from .model import host_to_device
+        return host_to_device(table, label.device)[label.detach().long()].view(-1, table.shape[1]).to(device)
     idx = label.detach().cpu().long() if torch.is_tensor(label) else torch.as_tensor(label).long()
-    return table[idx].view(-1, table.shape[1]).to(device)
+    from .model import host_to_device
+    return host_to_device(table[idx].view(-1, table.shape[1]), device)
 
 
 def get_target(label, classes, to_tensor=False, to_cuda=False, whole=False, shuffle=True):

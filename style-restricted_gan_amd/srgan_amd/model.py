@@ -14,6 +14,7 @@ yields the same initial weights.
 import functools
 
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 
@@ -358,10 +359,20 @@ class BasicBlock(nn.Module):
         return [ops.add(h, self.shortcut(x)), d]
 
 
+def host_to_device(t, device):
+    """Small host tensor -> device without stalling the host: a pageable ``.to(device)`` makes the host wait until the stream
+    has drained (the GPU then idles while the next launches are being queued); a copy out of PyTorch's cached pinned
+    allocator is asynchronous and the allocator keeps the staging block alive until the copy has run."""
+    device = torch.device(device)
+    if device.type != "cuda" or t.device.type != "cpu" or os.environ.get("SRGAN_SYNC_H2D"):
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def _cpu_normal_like(t):
     """Noise from the CPU default generator, then moved -- the reference's reparametrize does
     ``torch.FloatTensor(size).normal_().to(device)`` (model.py:461), so seeds reproduce."""
-    return torch.FloatTensor(t.size()).normal_().to(t.device)
+    return host_to_device(torch.FloatTensor(t.size()).normal_(), t.device)
 
 
 class _ReparamFn(torch.autograd.Function):

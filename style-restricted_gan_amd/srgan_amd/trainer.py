@@ -26,7 +26,7 @@ import torch.optim as optim
 
 from . import dp, ops
 from .losses import class_encode, get_domainloss_D, get_loss_D, histogram_imitation
-from .model import SingleGenerator, _cpu_normal_like
+from .model import SingleGenerator, _cpu_normal_like, host_to_device
 from .optim import Adam
 
 __all__ = ["SRGAN_training", "SingleGAN_training"]
@@ -116,7 +116,7 @@ class SRGAN_training():
 
     def _label_dev(self, which):
         return self._cached("index", which,
-                            lambda lab: torch.as_tensor(lab).to(device=self.device, dtype=torch.int64))
+                            lambda lab: host_to_device(torch.as_tensor(lab).to(dtype=torch.int64), self.device))
 
     @staticmethod
     def _opt_params(opt):
@@ -194,7 +194,7 @@ class SRGAN_training():
             elif self.encoded_feature == "mu":
                 latent_vector = mu
         else:
-            latent_vector = self.noise_fn(source_image.shape[0], self.ndim).to(self.device)
+            latent_vector = host_to_device(self.noise_fn(source_image.shape[0], self.ndim), self.device)
             info = latent_vector
         if isinstance(target_label, str):
             class_vector = self._onehot(target_label)
@@ -326,7 +326,7 @@ class SRGAN_training():
             if do_idt_reg and self._fused_paths():
                 # reference order of the noise draws: E(target_image), E(source), E(idt_random_image)
                 nb = src.shape[0]
-                n1, n2, n3 = (torch.FloatTensor(nb, self.ndim).normal_().to(self.device) for _ in range(3))
+                n1, n2, n3 = (host_to_device(torch.FloatTensor(nb, self.ndim).normal_(), self.device) for _ in range(3))
                 with torch.no_grad():                       # its gradient only reaches E's parameters
                     info = self._encode(src, noise=n2)
                 idt_random_image, info = self.G_transformation("source", src, True, src, _enc_info=info)
@@ -374,7 +374,7 @@ class SRGAN_training():
         # G does not change during the k discriminator updates, so all k translations are computed up front, with the
         # noise drawn in the reference's order (k x randn(B, ndim) on the CPU generator).  Only the LAST translation's
         # graph is ever back-propagated (phases 1 and 2); the first k-1 run as ONE no-grad batch of (k-1)*B images.
-        noises = [self.noise_fn(nb, self.ndim).to(self.device) for _ in range(k)]
+        noises = [host_to_device(self.noise_fn(nb, self.ndim), self.device) for _ in range(k)]
         oh = self._onehot("target")
         fakes = []
         if k > 1 and isinstance(dp.unwrap(self.G), SingleGenerator):     # per-sample network: batching is exact
@@ -478,7 +478,7 @@ class SingleGAN_training():
             info = [latent, mu, logvar]
             latent_vector = latent if self.encoded_feature == "latent" else mu
         else:
-            latent_vector = self.noise_fn(source_image.shape[0], self.ndim).to(self.device)
+            latent_vector = host_to_device(self.noise_fn(source_image.shape[0], self.ndim), self.device)
             info = latent_vector
         target_image = self.G(source_image, torch.cat([class_vector, latent_vector], 1))
         return target_image, info
