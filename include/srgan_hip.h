@@ -120,6 +120,21 @@ int srgan_cbin_affine_bwd(const float* c, const float* W, const float* gamma, co
                           float* dW, float* db, float* dc, int N, int C, int num_con,
                           void* ws, size_t ws_bytes /* >= N*C floats */, void* stream);
 
+/* The same affine for ALL central-biasing layers of a network in one launch (forward) / two launches (backward): the 15
+ * `_CBINorm` layers of SingleGenerator (model.py:213-224) depend on the style code and their own parameters only.
+ * The caller fills one host record per layer (srgan_cbin_rec_bytes() bytes each; pointers a pass does not use may be NULL),
+ * copies the array to the device and passes it as `table_dev`; outputs of a layer are dense [N][C] blocks.
+ * Backward: dscale / dshift must be non-NULL (zeros for absent gradients), `da` is [N][C] scratch per layer, `gamma` is the
+ * forward-time copy (row 0 of the saved scale); dc[N][num_con] sums the layers in table order. */
+size_t srgan_cbin_rec_bytes(void);
+int srgan_cbin_rec_fill(void* rec, const float* W, const float* b, const float* gamma, const float* beta, float* t,
+                        float* scale, float* shift, const float* dscale, const float* dshift, float* dgamma,
+                        float* dbeta, float* dW, float* db, float* da, int C);
+int srgan_cbin_affine_multi_fwd(const float* c, const void* table_dev, int n_layers, int N, int max_C, int num_con,
+                                void* stream);
+int srgan_cbin_affine_multi_bwd(const float* c, const void* table_dev, int n_layers, int N, int max_C, int num_con,
+                                float* dc, void* stream);
+
 /* Pointwise: y = act(x) and dx = dy * act'(y) (mask from the OUTPUT sign, slope>0). tanh: model.py:248 */
 int srgan_act_fwd(const float* x, float* y, long long n, int act, float slope, void* stream);
 int srgan_act_bwd(const float* y, const float* dy, float* dx, long long n, int act, float slope, void* stream);

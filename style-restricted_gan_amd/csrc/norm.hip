@@ -7,6 +7,7 @@
 // formulas of SURVEY.md Appendix F.1.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "common.h"
 
 namespace srgan {
@@ -391,6 +392,97 @@ __global__ __launch_bounds__(256) void cbin_affine_bwd_c(const float* W, const f
 }
 
 
+// ---- the same three kernels over ALL central-biasing layers of a network in one launch each (the affine depends on the
+// style code and the layer's parameters only, never on activations: the generator's 15 layers cost 45 launches of ~5 us per
+// pass one by one).  Device table of per-layer records; outputs of layer l are dense [N][C_l] blocks. ----
+struct CbinRec {
+  const float *W, *b, *gamma, *beta;     // forward: parameters.  backward: W, gamma = the forward-time copy (row 0 of scale)
+  float *t, *scale, *shift;              // forward outputs / backward inputs (t)
+  const float *dscale, *dshift;          // backward inputs ([N][C], never null: the host substitutes zeros)
+  float *dgamma, *dbeta, *dW, *db, *da;  // backward outputs; da = [N][C] scratch for the dc pass
+  int C, pad;
+};
+
+__global__ void cbin_affine_multi_fwd_kernel(const float* c, const CbinRec* tab, int N, int nc) {
+  const CbinRec r = tab[blockIdx.y];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * r.C) return;
+  const int n = idx / r.C, ch = idx - n * r.C;
+  float a = r.b[ch];
+  for (int j = 0; j < nc; ++j) a += c[n * nc + j] * r.W[ch * nc + j];
+  const float tv = tanhf(a);
+  r.t[idx] = tv;
+  r.scale[idx] = r.gamma[ch];
+  r.shift[idx] = tv * r.gamma[ch] + r.beta[ch];
+}
+
+__global__ __launch_bounds__(256) void cbin_affine_multi_bwd_ch(const float* c, const CbinRec* tab, int N, int nc) {
+  const CbinRec r = tab[blockIdx.y];
+  const int ch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (ch >= r.C) return;
+  const int C = r.C;
+  float dg = 0.f, dbt = 0.f, dbb = 0.f;
+  float dw[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dw[j] = 0.f;
+  const float g = r.gamma[ch];
+  for (int n = lane; n < N; n += 64) {
+    const int i = n * C + ch;
+    const float tv = r.t[i], ds = r.dshift[i];
+    dg += r.dscale[i] + ds * tv;
+    dbt += ds;
+    const float a = g * ds * (1.f - tv * tv);
+    r.da[i] = a;
+    dbb += a;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nc) dw[j] += a * c[n * nc + j];
+  }
+  dg = wave_sum(dg);
+  dbt = wave_sum(dbt);
+  dbb = wave_sum(dbb);
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < nc) dw[j] = wave_sum(dw[j]);
+  if (lane == 0) {
+    r.dgamma[ch] = dg;
+    r.dbeta[ch] = dbt;
+    r.db[ch] = dbb;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < nc && lane == j) r.dW[ch * nc + j] = dw[j];
+}
+
+// one WAVE per sample: dc[n][j] = sum over layers and channels of da[n][ch] * W[ch][j] (layers in table order)
+__global__ __launch_bounds__(256) void cbin_affine_multi_bwd_c(const CbinRec* tab, int n_layers, float* dc, int N, int nc) {
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float tot[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) tot[j] = 0.f;
+  for (int l = 0; l < n_layers; ++l) {
+    const CbinRec r = tab[l];
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int ch = lane; ch < r.C; ch += 64) {
+      const float a = r.da[n * r.C + ch];
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < nc) acc[j] += a * r.W[ch * nc + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nc) tot[j] += wave_sum(acc[j]);      // per-layer wave sums added in layer order: the order autograd uses
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < nc && lane == j) dc[n * nc + j] = tot[j];
+}
+
 // ---- single-pass variants: the (image, 32-channel) slab lives in registers --------------------------------------------
 // For maps of <= 1024 pixels (the generator's 32x32x256 trunk: 17 of its ~22 norm layers, and the deep encoder /
 // discriminator maps) one workgroup holds its whole slab -- HW x 32 channels, <= 128 KB -- in VGPRs: the statistics, the
@@ -645,6 +737,38 @@ extern "C" int srgan_cbin_affine_fwd(const float* c, const float* W, const float
   hipLaunchKernelGGL(cbin_affine_fwd_kernel, dim3((N * C + 255) / 256), dim3(256), 0, as_stream(stream), c, W, b, gamma, beta, t,
                      scale, shift, N, C, num_con);
   return check_launch("cbin_affine_fwd");
+}
+
+extern "C" size_t srgan_cbin_rec_bytes(void) { return sizeof(CbinRec); }
+
+// one host record of the table (the caller copies the array to the device); unused pointers may be null
+extern "C" int srgan_cbin_rec_fill(void* rec, const float* W, const float* b, const float* gamma, const float* beta, float* t,
+                                   float* scale, float* shift, const float* dscale, const float* dshift, float* dgamma,
+                                   float* dbeta, float* dW, float* db, float* da, int C) {
+  SRGAN_REQUIRE(rec && C > 0, "cbin_rec_fill: bad argument");
+  CbinRec r{W, b, gamma, beta, t, scale, shift, dscale, dshift, dgamma, dbeta, dW, db, da, C, 0};
+  std::memcpy(rec, &r, sizeof(r));
+  return 0;
+}
+
+extern "C" int srgan_cbin_affine_multi_fwd(const float* c, const void* table_dev, int n_layers, int N, int max_C, int num_con,
+                                           void* stream) {
+  SRGAN_REQUIRE(c && table_dev && n_layers > 0 && N > 0 && max_C > 0, "cbin_affine_multi_fwd: bad argument");
+  SRGAN_REQUIRE(num_con > 0 && num_con <= 16, "cbin_affine: num_con must be in 1..16");
+  hipLaunchKernelGGL(cbin_affine_multi_fwd_kernel, dim3((N * max_C + 255) / 256, n_layers), dim3(256), 0, as_stream(stream), c,
+                     reinterpret_cast<const CbinRec*>(table_dev), N, num_con);
+  return check_launch("cbin_affine_multi_fwd");
+}
+
+extern "C" int srgan_cbin_affine_multi_bwd(const float* c, const void* table_dev, int n_layers, int N, int max_C, int num_con,
+                                           float* dc, void* stream) {
+  SRGAN_REQUIRE(c && table_dev && dc && n_layers > 0 && N > 0 && max_C > 0, "cbin_affine_multi_bwd: bad argument");
+  SRGAN_REQUIRE(num_con > 0 && num_con <= 16, "cbin_affine: num_con must be in 1..16");
+  hipStream_t st = as_stream(stream);
+  const CbinRec* tab = reinterpret_cast<const CbinRec*>(table_dev);
+  hipLaunchKernelGGL(cbin_affine_multi_bwd_ch, dim3((max_C + 3) / 4, n_layers), dim3(256), 0, st, c, tab, N, num_con);
+  hipLaunchKernelGGL(cbin_affine_multi_bwd_c, dim3((N + 3) / 4), dim3(256), 0, st, tab, n_layers, dc, N, num_con);
+  return check_launch("cbin_affine_multi_bwd");
 }
 
 extern "C" int srgan_cbin_affine_bwd(const float* c, const float* W, const float* gamma, const float* t,

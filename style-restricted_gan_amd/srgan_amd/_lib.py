@@ -42,6 +42,10 @@ SIGNATURES = {
     "srgan_instnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "srgan_cbin_affine_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "srgan_cbin_affine_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
+    "srgan_cbin_rec_bytes": (c_size_t, []),
+    "srgan_cbin_rec_fill": (c_int, [P] * 15 + [c_int]),
+    "srgan_cbin_affine_multi_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srgan_cbin_affine_multi_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
     "srgan_act_fwd": (c_int, [P, P, c_longlong, c_int, c_float, P]),
     "srgan_act_bwd": (c_int, [P, P, P, c_longlong, c_int, c_float, P]),
     "srgan_tanh_fwd": (c_int, [P, P, c_longlong, P]),

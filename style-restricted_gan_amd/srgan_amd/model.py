@@ -125,14 +125,27 @@ class CBINorm2d(nn.Module):
     def forward(self, input, ConInfor, act=ACT_NONE, slope=0.0, res=None):
         """(IN(x) + tanh(Linear(c))) * weight + bias, with optional fused activation / residual."""
         self._check_input_dim(input)
+        if isinstance(ConInfor, PrecomputedCon):       # the network computed every layer's affine in one launch
+            scale, shift = ConInfor.affine[id(self)]
+            return ops.instance_norm_act(input, scale, shift, res, act, slope, self.eps)
+        scale, shift = ops.cbin_affine(ConInfor, *self.affine_params(input.device))
+        return ops.instance_norm_act(input, scale, shift, res, act, slope, self.eps)
+
+    def affine_params(self, device):
         lin = self.ConBias[0]
         if self.affine:
-            gamma, beta = self.weight, self.bias
-        else:
-            gamma = torch.ones(self.num_features, device=input.device)
-            beta = torch.zeros(self.num_features, device=input.device)
-        scale, shift = ops.cbin_affine(ConInfor, lin.weight, lin.bias, gamma, beta)
-        return ops.instance_norm_act(input, scale, shift, res, act, slope, self.eps)
+            return lin.weight, lin.bias, self.weight, self.bias
+        return lin.weight, lin.bias, torch.ones(self.num_features, device=device), torch.zeros(self.num_features, device=device)
+
+
+class PrecomputedCon:
+    """Style code plus the (scale, shift) pair of every central-biasing layer of a network, made by ONE launch
+    (ops.cbin_affine_multi): the affine depends on the code and the layer's parameters only."""
+
+    def __init__(self, c, layers):
+        self.c = c
+        affs = ops.cbin_affine_multi(c, [l.affine_params(c.device) for l in layers])
+        self.affine = {id(l): a for l, a in zip(layers, affs)}
 
 
 def get_norm_layer(layer_type='instance', num_con=2):
@@ -195,6 +208,9 @@ class SingleGenerator(nn.Module):
         self.up_norms = nn.ModuleList(norms)
 
     def forward(self, x, c):
+        # (not under hipGraph capture: the per-call table is staged through a transient pinned buffer a replay would re-read)
+        if c.is_cuda and not os.environ.get("SRGAN_NO_CBIN_MULTI") and not torch.cuda.is_current_stream_capturing():
+            c = PrecomputedCon(c, list(self.down_cnorms) + [n for blk in self.resBlocks for n in (blk.cn1, blk.cn2)])
         for i in range(self.num_cls + 1):
             x = self.down_cnorms[i](self.down_convs[i](x), c, ACT_RELU)
         x = self.resBlocks([x, c])[0]

@@ -515,6 +515,94 @@ def cbin_affine(c, W, b, gamma, beta):
     return _CbinAffineFn.apply(c, W, b, gamma, beta)
 
 
+def _cbin_table(records, device):
+    """Host records (ctypes buffers) -> one device array, through pinned staging (no host stall)."""
+    blob = b"".join(bytes(r) for r in records)
+    host = torch.frombuffer(bytearray(blob), dtype=torch.uint8).pin_memory()
+    return host.to(device, non_blocking=True)
+
+
+class _CbinAffineMultiFn(Function):
+    """cbin_affine of L layers in one launch (backward: two).  params = (W_1, b_1, gamma_1, beta_1, ..., W_L, ...);
+    returns (scale_1, shift_1, ..., scale_L, shift_L).  Same kept semantics as _CbinAffineFn: the Linear weights are held by
+    reference and read at backward time, gamma in backward is the forward-time copy (row 0 of scale)."""
+
+    @staticmethod
+    def forward(ctx, c, *params):
+        _require_gpu(c, "cbin condition vector")
+        lib = _lib.load()
+        c = _dense2d(c)
+        n, nc = c.shape
+        L = len(params) // 4
+        chs = [params[4 * l].shape[0] for l in range(L)]
+        dev = c.device
+        outs, ts, recs = [], [], []
+        nb = lib.srgan_cbin_rec_bytes()
+        for l in range(L):
+            W, b, g, be = params[4 * l: 4 * l + 4]
+            t = torch.empty(n, chs[l], dtype=torch.float32, device=dev)
+            scale = torch.empty_like(t)
+            shift = torch.empty_like(t)
+            rec = (ctypes.c_char * nb)()
+            _lib.check(lib.srgan_cbin_rec_fill(ctypes.byref(rec), _ptr(W), _ptr(b), _ptr(g), _ptr(be), _ptr(t), _ptr(scale),
+                                               _ptr(shift), None, None, None, None, None, None, None, chs[l]), "cbin_rec_fill")
+            recs.append(rec)
+            ts.append(t)
+            outs += [scale, shift]
+        table = _cbin_table(recs, dev)
+        _lib.check(lib.srgan_cbin_affine_multi_fwd(_ptr(c), _ptr(table), L, n, max(chs), nc, _stream()), "cbin_affine_multi_fwd")
+        ctx.Ws = [params[4 * l] for l in range(L)]          # by reference: read at backward time
+        ctx.chs = chs
+        ctx.save_for_backward(c, *ts, *outs[0::2])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        L = len(ctx.chs)
+        c, ts, scales = saved[0], saved[1:1 + L], saved[1 + L:1 + 2 * L]
+        n, nc = c.shape
+        dev = c.device
+        nb = lib.srgan_cbin_rec_bytes()
+        zeros = None
+        res, recs = [], []
+        da = workspace(dev, n * sum(ctx.chs) * 4).view(torch.float32)
+        off = 0
+        for l in range(L):
+            ch = ctx.chs[l]
+            dscale, dshift = grads[2 * l], grads[2 * l + 1]
+            if dscale is None or dshift is None:
+                if zeros is None:
+                    zeros = torch.zeros(n, max(ctx.chs), dtype=torch.float32, device=dev)
+                dscale = zeros if dscale is None else dscale
+                dshift = zeros if dshift is None else dshift
+            dscale, dshift = _dense2d(dscale), _dense2d(dshift)
+            dgamma = torch.empty(ch, dtype=torch.float32, device=dev)
+            dbeta = torch.empty_like(dgamma)
+            dW = torch.empty(ch, nc, dtype=torch.float32, device=dev)
+            db = torch.empty_like(dgamma)
+            rec = (ctypes.c_char * nb)()
+            _lib.check(lib.srgan_cbin_rec_fill(ctypes.byref(rec), _ptr(ctx.Ws[l]), None, _ptr(scales[l]), None, _ptr(ts[l]), None,
+                                               None, _ptr(dscale), _ptr(dshift), _ptr(dgamma), _ptr(dbeta), _ptr(dW), _ptr(db),
+                                               da.data_ptr() + off * 4, ch), "cbin_rec_fill")
+            off += n * ch
+            recs.append((rec, dscale, dshift))
+            res += [dW, db, dgamma, dbeta]
+        table = _cbin_table([r[0] for r in recs], dev)
+        dc = torch.empty(n, nc, dtype=torch.float32, device=dev)
+        _lib.check(lib.srgan_cbin_affine_multi_bwd(_ptr(c), _ptr(table), L, n, max(ctx.chs), nc, _ptr(dc), _stream()),
+                   "cbin_affine_multi_bwd")
+        return (dc, *res)
+
+
+def cbin_affine_multi(c, layer_params):
+    """layer_params: [(W, b, gamma, beta), ...] -> [(scale, shift), ...], one launch for all layers."""
+    flat = [p for lp in layer_params for p in lp]
+    out = _CbinAffineMultiFn.apply(c, *flat)
+    return [(out[2 * l], out[2 * l + 1]) for l in range(len(layer_params))]
+
+
 # ------------------------------------------------------------------------------------------
 # pointwise / pools / heads
 # ------------------------------------------------------------------------------------------

@@ -279,6 +279,40 @@ def test_cbin_affine(ops):
         close(d.grad, r.grad, 5e-5)
 
 
+def test_cbin_affine_multi(ops):
+    """All central-biasing layers of a network in one launch (forward) / two (backward): three layers of different widths,
+    one of them without a gradient on its scale output, against the torch formula; dc sums the layers."""
+    n, nc, chs = 7, 12, (24, 64, 256)
+    c = rnd(n, nc, seed=1).requires_grad_(True)
+    params, outs_r, weights = [], [], []
+    for l, ch in enumerate(chs):
+        W = (rnd(ch, nc, seed=10 + l) * 0.3).requires_grad_(True)
+        b = (rnd(ch, seed=20 + l) * 0.1).requires_grad_(True)
+        gam = (1 + 0.2 * rnd(ch, seed=30 + l)).requires_grad_(True)
+        bet = (0.1 * rnd(ch, seed=40 + l)).requires_grad_(True)
+        params.append((W, b, gam, bet))
+        t = torch.tanh(F.linear(c, W, b))
+        outs_r.append((gam[None, :].expand(n, ch), t * gam + bet))
+        weights.append((rnd(n, ch, seed=50 + l), rnd(n, ch, seed=60 + l)))
+    loss = 0
+    for l, ((sc, sh), (g1, g2)) in enumerate(zip(outs_r, weights)):
+        loss = loss + (sh * g2).sum() + ((sc * g1).sum() if l != 1 else 0)
+    loss.backward()
+    cd = c.detach().cuda().requires_grad_(True)
+    pd = [tuple(v.detach().cuda().requires_grad_(True) for v in p) for p in params]
+    outs = ops.cbin_affine_multi(cd, pd)
+    loss = 0
+    for l, ((sc, sh), (g1, g2)) in enumerate(zip(outs, weights)):
+        close(sc, outs_r[l][0])
+        close(sh, outs_r[l][1])
+        loss = loss + (sh * g2.cuda()).sum() + ((sc * g1.cuda()).sum() if l != 1 else 0)
+    loss.backward()
+    close(cd.grad, c.grad, 5e-5)
+    for p, r in zip(pd, params):
+        for d, v in zip(p, r):
+            close(d.grad, v.grad, 5e-5)
+
+
 def test_pools_and_heads(ops):
     x = rnd(2, 8, 13, 13, seed=1).requires_grad_(True)
     gy = None
