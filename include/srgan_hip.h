@@ -67,6 +67,9 @@ int srgan_conv2d_pack(const srgan_conv_desc* d, int kind, int act, const float* 
  * Winograd layers (kind 0 and 1), the padded-gradient temp of a reflect-padded layer (kind 1).  Caller-owned like every
  * workspace of this library; only live between the launches of one call, so one buffer serves every layer of a stream. */
 size_t srgan_conv2d_packed_scratch(const srgan_conv_desc* d, int kind);
+/* Non-zero when the packed operand depends on the weights and channel counts only (Winograd filter images, RGB-input image):
+ * descriptors of the same weight that differ in N / H / W only and return the same signature may share one packed buffer. */
+unsigned long long srgan_conv2d_pack_signature(const srgan_conv_desc* d, int kind, int act);
 int srgan_conv2d_fwd_packed(const srgan_conv_desc* d, const float* x, const void* packed, const float* bias, float* y,
                             int act, float slope, void* ws, size_t ws_bytes, void* stream);
 int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* dy, const void* packed, float* dx,

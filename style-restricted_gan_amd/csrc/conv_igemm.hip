@@ -1508,6 +1508,23 @@ extern "C" int srgan_conv2d_pack_multi(const void* entries_dev, int n_entries, v
   return check_launch("pack_multi_kernel");
 }
 
+// Non-zero when the packed operand of (d, kind, act) does not depend on the batch size or the map size (the Winograd filter
+// images and the RGB-input image depend on the weights and the channel counts only): a caller may then share one packed buffer
+// between descriptors that differ in N / H / W only and return the same signature.  0: the layout follows the geometry.
+extern "C" unsigned long long srgan_conv2d_pack_signature(const srgan_conv_desc* d, int kind, int act) {
+  if (validate(d) != 0) return 0;
+  if (kind == 0) {
+    const FwdPath path = fwd_path(d, act);
+    if (path == PATH_RGBIN) return 100;
+    if (path == PATH_WINO) return 10 + (unsigned long long)(wino_packed_bytes(d, 0) % 1000003) * 16 + 1;
+    return 0;
+  }
+  const DgradGeom g = dgrad_geometry(d);
+  if (g.rgbin) return 101;
+  if (g.wino) return 10 + (unsigned long long)(wino_packed_bytes(d, 1) % 1000003) * 16 + 2;
+  return 0;
+}
+
 extern "C" size_t srgan_conv2d_packed_scratch(const srgan_conv_desc* d, int kind) {
   if (validate(d) != 0) return 0;
   if (kind == 1 && d->pad_mode == SRGAN_PAD_REFLECT) return srgan_conv2d_workspace(d);      // padded-gradient temp

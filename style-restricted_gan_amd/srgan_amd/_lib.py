@@ -32,6 +32,7 @@ SIGNATURES = {
     "srgan_conv2d_packed_bytes": (c_size_t, [_DESC, c_int, c_int]),
     "srgan_conv2d_pack": (c_int, [_DESC, c_int, c_int, P, P, c_size_t, P]),
     "srgan_conv2d_packed_scratch": (c_size_t, [_DESC, c_int]),
+    "srgan_conv2d_pack_signature": (ctypes.c_ulonglong, [_DESC, c_int, c_int]),
     "srgan_conv2d_fwd_packed": (c_int, [_DESC, P, P, P, P, c_int, c_float, P, c_size_t, P]),
     "srgan_conv2d_dgrad_packed": (c_int, [_DESC, P, P, P, P, c_size_t, P]),
     "srgan_conv2d_wgrad": (c_int, [_DESC, P, P, P, P, P, c_size_t, P]),

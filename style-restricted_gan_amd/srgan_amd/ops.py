@@ -165,6 +165,7 @@ def set_compute_dtype(name):
     mode = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[str(name).replace("torch.", "")]
     _lib.check(_lib.load().srgan_set_compute_mode(mode), "set_compute_mode")
     _pack_cache.clear()
+    _geo_cache.clear()
     _tables.clear()
 
 
@@ -176,11 +177,14 @@ def invalidate_packed(params=None):
     """Forget cached operands (all, or those of ``params``): they are re-packed one by one at their next use."""
     if params is None:
         _pack_cache.clear()
+        _geo_cache.clear()
         _tables.clear()
         return
     ids = {id(p) for p in params}
     for key in [k for k in _pack_cache if k[0] in ids]:
         del _pack_cache[key]
+    for key in [k for k in _geo_cache if k[0] in ids]:
+        del _geo_cache[key]
     _tables.clear()
 
 
@@ -205,25 +209,41 @@ def _pack_one(hit):
         _tables.clear()
 
 
+_geo_cache = {}           # (id(weight), kind, act_flag, full geometry) -> (_Packed, scratch bytes of that geometry)
+
+
 def _packed(desc, weight, kind, act):
-    key = (id(weight), kind, int(act != ACT_NONE), desc.N, desc.Hi, desc.Wi, desc.I, desc.O, desc.kh, desc.stride,
-           desc.pad, desc.pad_mode)
-    hit = _pack_cache.get(key)
-    if hit is None or hit.weight is not weight:
+    """-> (_Packed, scratch bytes).  Operands whose layout does not depend on batch / map size (srgan_conv2d_pack_signature:
+    the Winograd filter images) are shared between the geometries a weight is used with (the trainer runs the generator at
+    batch 32, 64 and 128: one repack per optimiser step instead of three)."""
+    gkey = (id(weight), kind, int(act != ACT_NONE), desc.N, desc.Hi, desc.Wi, desc.I, desc.O, desc.kh, desc.stride,
+            desc.pad, desc.pad_mode)
+    g = _geo_cache.get(gkey)
+    if g is not None and g[0].weight is weight and _pack_cache.get(g[2]) is g[0]:
+        hit, scratch = g[0], g[1]
+    else:
         lib = _lib.load()
-        nbytes = lib.srgan_conv2d_packed_bytes(ctypes.byref(desc), kind, act)
-        if nbytes == 0:
-            raise _lib.SrganHipError("conv2d pack: " + lib.srgan_last_error().decode())
-        own = _lib.ConvDesc()
-        ctypes.memmove(ctypes.byref(own), ctypes.byref(desc), ctypes.sizeof(own))
-        hit = _Packed(torch.empty(nbytes, dtype=torch.uint8, device=weight.device), weight, own, kind, act,
-                      lib.srgan_conv2d_packed_scratch(ctypes.byref(desc), kind))
-        _pack_cache[key] = hit
-        _tables.clear()
+        sig = lib.srgan_conv2d_pack_signature(ctypes.byref(desc), kind, act)
+        key = gkey if sig == 0 else (id(weight), kind, int(act != ACT_NONE), "sig", sig, desc.I, desc.O, desc.kh, desc.stride,
+                                     desc.pad, desc.pad_mode)
+        scratch = lib.srgan_conv2d_packed_scratch(ctypes.byref(desc), kind)
+        hit = _pack_cache.get(key)
+        if hit is None or hit.weight is not weight:
+            nbytes = lib.srgan_conv2d_packed_bytes(ctypes.byref(desc), kind, act)
+            if nbytes == 0:
+                raise _lib.SrganHipError("conv2d pack: " + lib.srgan_last_error().decode())
+            own = _lib.ConvDesc()
+            ctypes.memmove(ctypes.byref(own), ctypes.byref(desc), ctypes.sizeof(own))
+            hit = _Packed(torch.empty(nbytes, dtype=torch.uint8, device=weight.device), weight, own, kind, act, scratch)
+            _pack_cache[key] = hit
+            _tables.clear()
+            _pack_one(hit)
+            _geo_cache[gkey] = (hit, scratch, key)
+            return hit, scratch
+        _geo_cache[gkey] = (hit, scratch, key)
+    if not hit.fresh or hit.version != weight._version or hit.ptr != weight.data_ptr():
         _pack_one(hit)
-    elif not hit.fresh or hit.version != weight._version or hit.ptr != weight.data_ptr():
-        _pack_one(hit)
-    return hit
+    return hit, scratch
 
 
 _tables = {}              # frozenset of parameter ids -> (entries, device table, singles)
@@ -286,11 +306,11 @@ def refresh_packed(params):
 def _run_conv_fwd(desc, x, weight, bias, y, act, slope, keep_v=None):
     lib = _lib.load()
     if _pack_cache_on:
-        hit = _packed(desc, weight, 0, act)
+        hit, scratch = _packed(desc, weight, 0, act)
         # keep_v: the caller's own buffer for the F(4x4,3x3) transformed input (kept for the weight gradient) instead of scratch
-        ws = keep_v if keep_v is not None else (workspace(x.device, hit.scratch) if hit.scratch else None)
+        ws = keep_v if keep_v is not None else (workspace(x.device, scratch) if scratch else None)
         _lib.check(lib.srgan_conv2d_fwd_packed(ctypes.byref(desc), _ptr(x), _ptr(hit.buf), _ptr(bias), _ptr(y), act,
-                                               float(slope), _ptr(ws), hit.scratch, _stream()), "conv2d_fwd_packed")
+                                               float(slope), _ptr(ws), scratch, _stream()), "conv2d_fwd_packed")
         return
     ws, nb = _conv_ws(desc, x.device)
     _lib.check(lib.srgan_conv2d_fwd(ctypes.byref(desc), _ptr(x), _ptr(weight), _ptr(bias), _ptr(y), act,
@@ -300,9 +320,9 @@ def _run_conv_fwd(desc, x, weight, bias, y, act, slope, keep_v=None):
 def _run_conv_dgrad(desc, dy, weight, dx):
     lib = _lib.load()
     if _pack_cache_on:
-        hit = _packed(desc, weight, 1, ACT_NONE)
-        ws = workspace(dy.device, hit.scratch) if hit.scratch else None
-        _lib.check(lib.srgan_conv2d_dgrad_packed(ctypes.byref(desc), _ptr(dy), _ptr(hit.buf), _ptr(dx), _ptr(ws), hit.scratch,
+        hit, scratch = _packed(desc, weight, 1, ACT_NONE)
+        ws = workspace(dy.device, scratch) if scratch else None
+        _lib.check(lib.srgan_conv2d_dgrad_packed(ctypes.byref(desc), _ptr(dy), _ptr(hit.buf), _ptr(dx), _ptr(ws), scratch,
                                                  _stream()), "conv2d_dgrad_packed")
         return
     ws, nb = _conv_ws(desc, dy.device)
