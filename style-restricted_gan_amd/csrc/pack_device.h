@@ -48,54 +48,62 @@ struct WinoPackParams {
 
 constexpr int WP_WNB = 64, WP_WC = 8;
 __device__ __host__ __forceinline__ long long wino_pack_total(const WinoPackParams& p) {
-  if (p.variant == 3) return (long long)p.n_tiles * 32 * p.nchunk * WP_WC;      // 32-channel column tiles
+  if (p.variant == 3) return (long long)p.n_tiles * 32 * p.nchunk * 2;          // one item = 4 channels of one cout
   return (long long)p.n_tiles * WP_WNB * p.nchunk * WP_WC * p.phases;
 }
 
 // variant 3, F(4x4,3x3):  U = G g G^T (6x6), laid out [n_tile (32 couts)][chunk][36 pos][lane = half * 32 + cout][4 ch]:
 // the A-operand register image of wino43_kernel.  kind 0: g = w[n][c][ky][kx];  kind 1: g = w[c][n][2-ky][2-kx].
 __device__ __forceinline__ void wino43_pack_item(const WinoPackParams& p, long long idx) {
-  const int j = (int)(idx % 4);
-  long long r = idx / 4;
+  // item = (cout nl, channel quad lh, chunk, cout tile): the lane's 4 channels are 16 contiguous bytes of every position
+  // plane, so the 36 results go out as 16-byte stores (a quarter of the store instructions of a one-channel item)
+  long long r = idx;
   const int nl = (int)(r % 32); r /= 32;
   const int lh = (int)(r % 2); r /= 2;
   const int chunk = (int)(r % p.nchunk);
   const int ntile = (int)(r / p.nchunk);
-  const int n = ntile * 32 + nl, c = chunk * WP_WC + lh * 4 + j;
-  const bool ok = n < p.N && c < p.C;
-  float g[3][3];
+  const int n = ntile * 32 + nl;
+  f32x4 u[36];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
+  for (int j = 0; j < 4; ++j) {
+    const int c = chunk * WP_WC + lh * 4 + j;
+    const bool ok = n < p.N && c < p.C;
+    float g[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        float v = 0.f;
+        if (ok) v = p.kind == 0 ? p.w[n * p.sO + c * p.sI + ky * p.sH + kx * p.sW]
+                                : p.w[c * p.sO + n * p.sI + (2 - ky) * p.sH + (2 - kx) * p.sW];
+        g[ky][kx] = v;
+      }
+    // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+    float h[6][3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      float v = 0.f;
-      if (ok) v = p.kind == 0 ? p.w[n * p.sO + c * p.sI + ky * p.sH + kx * p.sW]
-                              : p.w[c * p.sO + n * p.sI + (2 - ky) * p.sH + (2 - kx) * p.sW];
-      g[ky][kx] = v;
+      const float a = g[0][kx], b = g[1][kx], cc = g[2][kx];
+      h[0][kx] = 0.25f * a;
+      h[1][kx] = (-1.f / 6.f) * (a + b + cc);
+      h[2][kx] = (-1.f / 6.f) * (a - b + cc);
+      h[3][kx] = (1.f / 24.f) * a + (1.f / 12.f) * b + (1.f / 6.f) * cc;
+      h[4][kx] = (1.f / 24.f) * a - (1.f / 12.f) * b + (1.f / 6.f) * cc;
+      h[5][kx] = cc;
     }
-  // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
-  float h[6][3];
 #pragma unroll
-  for (int kx = 0; kx < 3; ++kx) {
-    const float a = g[0][kx], b = g[1][kx], cc = g[2][kx];
-    h[0][kx] = 0.25f * a;
-    h[1][kx] = (-1.f / 6.f) * (a + b + cc);
-    h[2][kx] = (-1.f / 6.f) * (a - b + cc);
-    h[3][kx] = (1.f / 24.f) * a + (1.f / 12.f) * b + (1.f / 6.f) * cc;
-    h[4][kx] = (1.f / 24.f) * a - (1.f / 12.f) * b + (1.f / 6.f) * cc;
-    h[5][kx] = cc;
+    for (int a = 0; a < 6; ++a) {
+      const float x = h[a][0], y = h[a][1], z = h[a][2];
+      u[a * 6 + 0][j] = 0.25f * x;
+      u[a * 6 + 1][j] = (-1.f / 6.f) * (x + y + z);
+      u[a * 6 + 2][j] = (-1.f / 6.f) * (x - y + z);
+      u[a * 6 + 3][j] = (1.f / 24.f) * x + (1.f / 12.f) * y + (1.f / 6.f) * z;
+      u[a * 6 + 4][j] = (1.f / 24.f) * x - (1.f / 12.f) * y + (1.f / 6.f) * z;
+      u[a * 6 + 5][j] = z;
+    }
   }
-  float* out = p.dst + (((size_t)ntile * p.nchunk + chunk) * 36) * 256 + lh * 128 + nl * 4 + j;
+  float* out = p.dst + (((size_t)ntile * p.nchunk + chunk) * 36) * 256 + lh * 128 + nl * 4;
 #pragma unroll
-  for (int a = 0; a < 6; ++a) {
-    const float x = h[a][0], y = h[a][1], z = h[a][2];
-    out[(a * 6 + 0) * 256] = 0.25f * x;
-    out[(a * 6 + 1) * 256] = (-1.f / 6.f) * (x + y + z);
-    out[(a * 6 + 2) * 256] = (-1.f / 6.f) * (x - y + z);
-    out[(a * 6 + 3) * 256] = (1.f / 24.f) * x + (1.f / 12.f) * y + (1.f / 6.f) * z;
-    out[(a * 6 + 4) * 256] = (1.f / 24.f) * x - (1.f / 12.f) * y + (1.f / 6.f) * z;
-    out[(a * 6 + 5) * 256] = z;
-  }
+  for (int k = 0; k < 36; ++k) *reinterpret_cast<f32x4*>(out + k * 256) = u[k];
 }
 
 __device__ __forceinline__ void wino_pack_item(const WinoPackParams& p, long long idx) {
