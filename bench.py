@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """Benchmark of the SRGAN G+D+E train step on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 from a bare shell: the parent starts N fresh rank processes (``python -m torch.distributed.run``, one per GPU,
+RCCL) BEFORE touching the GPU itself, forwards rank 0's JSON line and exits with their status.  Already under
+torch.distributed.run (WORLD_SIZE set): runs as that rank.
 
 A "step" = one ``SRGAN_training.train`` call (k=5 D updates + the two-phase G/E update) on one synthetic
 CelebA-shaped batch.  Workload at N=1 = BASELINE.json configs[1]: SRGAN-nopretrain, 128x128, bs=32/GPU, fp32,
 notebook hyper-parameters (05-train cells 13/16).  Weak scaling: 32 images per GPU, global batch 32*N.
-Prints ONE JSON line on rank 0 with ``roofline`` (dominant kernel, HIP-event timed inside the timed region)
-and, at N=1, ``cpu_baseline`` (the CPU oracle timed on the host cores on a bounded sample).
+Prints ONE JSON line on rank 0 with ``roofline`` (dominant kernel, HIP-event timed) and, at N=1, ``cpu_baseline``
+(the CPU oracle timed on the host cores on a bounded sample) and ``micro_gd`` (north_star's G+D forward-backward target).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,7 +35,9 @@ import torch.nn as nn  # noqa: E402
 LBD = {"class": 1.0, "cycle": 5.0, "idt": 5.0, "reg": 0.5, "idt_reg": 0.5, "KL": 0.0,
        "batch_KL": 10.0, "corr_enc": 100.0, "hist": 100.0}          # 05-train cell 16
 GFLOP_PER_IMAGE = {128: 412.46, 256: 1677.69}                        # SURVEY.md 8d (k=5, E trainable)
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2516.6}                                         # MI355X dense matrix peak, MI355X_MICROARCH.md
+GFLOP_PER_IMAGE_FROZEN_E = {128: 399.34, 256: 1621.70}               # SURVEY.md 8d (config 3: encoder trunk frozen)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2516.6}                         # MI355X dense matrix peak, MI355X_MICROARCH.md
+FIRST_STEP_FIXTURE = os.path.join(ROOT, "tests", "golden", "bench_first_step.json")
 
 
 def synthetic_batch(batch, size, n_class, seed):
@@ -40,16 +48,35 @@ def synthetic_batch(batch, size, n_class, seed):
     return x, src, tgt
 
 
-def build_trainer(size, global_batch, k, device):
+def build_nets(size, device):
+    """The three networks of 05-train cell 13 with PyTorch's default initialisation under seed 0 (the reference's
+    ``weights_init`` is a no-op).  Parameter holders only: constructing them needs no GPU."""
     from srgan_amd import model
-    from srgan_amd.trainer import SRGAN_training
-    torch.manual_seed(0)             # identical replicas on every rank (default PyTorch init, as the reference)
+    torch.manual_seed(0)             # identical replicas on every rank
     np.random.seed(0)
     d_cls = 4 if size == 128 else 5
     G = model.SingleGenerator(3, 64, 2, 2, 6, "instance", num_con=12)
     D = model.SingleDiscriminator_solo_multi(3, 64, 2, d_cls, "instance", 4)
     E = model.Encoder(3, 8, 64, 4, "instance", 4, device)
-    sg = SRGAN_training([G, D, E], [None, None, None], [nn.MSELoss(), nn.MSELoss()], dict(LBD), k, device,
+    return G, D, E
+
+
+TRUNK_KEYS_NOT_FROZEN = ("fcmean.weight", "fcmean.bias", "fcvar.weight", "fcvar.bias")
+
+
+def build_trainer(size, global_batch, k, device, pretrained_e=False):
+    from srgan_amd.optim import Adam
+    from srgan_amd.trainer import SRGAN_training
+    G, D, E = build_nets(size, device)
+    opt_e = None
+    if pretrained_e:
+        # BASELINE configs[2] (05-train cells 14-16): the classifier keys are frozen, only fcmean / fcvar train, with an
+        # externally built Adam(lr=1e-3).  The real .pth is a git-LFS pointer, so the "pretrained" trunk is the default init.
+        keys = [k_ for k_ in E.state_dict().keys() if k_ not in TRUNK_KEYS_NOT_FROZEN]
+        E.freeze_melt(keys, "freeze")
+        E.to(device)
+        opt_e = Adam([p for p in E.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+    sg = SRGAN_training([G, D, E], [None, None, opt_e], [nn.MSELoss(), nn.MSELoss()], dict(LBD), k, device,
                         np.eye(4), global_batch, "mu", 8)
     sg.opt_sche_initialization()
     return sg
@@ -62,6 +89,16 @@ def host_cores():
     except AttributeError:
         n = os.cpu_count() or 1
     return max(1, min(n, int(os.environ.get("SRGAN_BENCH_CPU_THREADS", "16"))))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def log(msg):
@@ -90,40 +127,46 @@ def cpu_baseline(size, k):
         orc.train(x, label)
         dt += time.perf_counter() - t0
         steps += 1
-    return {"value": round(batch * steps / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+    return {"value": round(batch * steps / dt, 4), "unit": "images/sec", "cores": cores, "cpu_model": cpu_model(),
+            "kind": "port",
             "sample": f"{steps} full train steps (k={k}, fp32, same networks/losses) of the CPU oracle at batch {batch} "
-                      f"({size}x{size}) after a k=1 batch-2 warm-up; {dt:.1f} s on {cores} threads"}
+                      f"({size}x{size}; a batch-32 step is ~9 s per step on these cores and would not fit the time bound) "
+                      f"after a k=1 batch-2 warm-up; {dt:.1f} s on {cores} threads"}
 
 
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed PMC summary (profiles/r*_pmc_traffic.json, collected
-    with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same bench command), or None."""
+    """HBM bytes per launch of `kernel_name` REPLAYED from the committed PMC summary (profiles/r*_pmc_traffic.json, collected
+    with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same bench command) -- not measured in this run."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None
     try:
         entry = json.load(open(files[-1]))["kernels"].get(kernel_name)
-        return entry["hbm_bytes_per_launch"] if entry else None
+        return (entry["hbm_bytes_per_launch"] if entry else None), os.path.relpath(files[-1], ROOT)
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
 GD_GFLOP_PER_IMAGE = {128: 60.54, 256: 243.86}        # (3 F_G - f_G) + (3 F_D - f_D), SURVEY.md 8d
 
 
-def micro_gd(args):
-    """One generator forward + full backward and one discriminator forward + full backward on a batch of 32 (inputs do not
+def executed_divisor(name):
+    """Algorithmic conv FLOPs / MFMA FLOPs actually issued: Winograd F(4x4,3x3) multiplies 36 values per 16 outputs x 9 taps
+    (4x fewer), F(2x2,3x3) / F(3x3,2x2) 16 per 36 (2.25x fewer, before the waste of ragged edge tiles); 1 for the direct forms."""
+    if name.startswith("wino43"):
+        return 4.0
+    if name.startswith("wino"):
+        return 2.25
+    return 1.0
+
+
+def micro_gd_run(size, batch, dtype, steps, warmup, device):
+    """One generator forward + full backward and one discriminator forward + full backward on a batch (inputs do not
     require gradients, so the first-layer input gradients are skipped, as in the SURVEY formula).  Single GPU."""
-    from srgan_amd import _lib, model, ops
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
-    device = torch.device("cuda", 0)
-    _lib.load()
-    if args.dtype == "bf16":
-        ops.set_compute_dtype("bf16")
+    from srgan_amd import model, ops
     torch.manual_seed(0)
-    B, S = args.batch_per_gpu, args.size
+    B, S = batch, size
     G = model.SingleGenerator(3, 64, 2, 2, 6, "instance", num_con=12).to(device)
     D = model.SingleDiscriminator_solo_multi(3, 64, 2, 4 if S == 128 else 5, "instance", 4).to(device)
     x = (torch.rand(B, 3, S, S, device=device) * 2 - 1)
@@ -137,29 +180,109 @@ def micro_gd(args):
             outs, cls = D(x)
             (sum(o.square().mean() for o in outs) + sum(q.square().mean() for q in cls)).backward()
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = (time.perf_counter() - t0) / steps
     gf = GD_GFLOP_PER_IMAGE.get(S)
     value = B / dt
-    peak = PEAK_TFLOPS["f32" if args.dtype == "f32" else "bf16"]
+    peak = PEAK_TFLOPS["f32" if dtype == "f32" else "bf16"]
     tf = value * gf / 1e3 if gf else None
-    print(json.dumps({
+    return {
         "metric": f"images/sec G+D forward-backward, {S}x{S} bs={B} (micro-benchmark, SURVEY 8d)", "value": round(value, 2),
-        "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt, 3),
-        "higher_is_better": True, "dtype": args.dtype, "data": "synthetic",
+        "unit": "images/sec", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt, 3),
+        "higher_is_better": True, "dtype": dtype, "data": "synthetic",
         "config": {"workload": "one G forward + backward and one D forward + backward (all parameter gradients), default PyTorch "
                                "init, first-layer input gradients skipped", "gflop_per_image_algorithmic": gf},
-        "roofline": {"bound": "mfma", "achieved": round(tf, 2) if tf else None, "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(tf / peak, 4) if tf else None,
+        "roofline": {"bound": "mfma", "algorithmic_tflops": round(tf, 2) if tf else None, "peak": peak, "unit": "TFLOP/s",
+                     "algorithmic_frac": round(tf / peak, 4) if tf else None,
                      "note": "whole micro-benchmark: algorithmic FLOPs (SURVEY 8d) x images/s against the dense MFMA peak of the "
-                             "dtype; includes norm / pointwise / reduction kernels; Winograd layers execute 2.25x fewer MFMA FLOPs "
-                             "than counted, so the algorithmic fraction can exceed 1"}}))
+                             "dtype; includes norm / pointwise / reduction kernels; the Winograd layers issue 2.25-4x fewer MFMA "
+                             "FLOPs than counted, so this ALGORITHMIC fraction can exceed 1 (north_star's >= 0.70 target is "
+                             "stated on algorithmic FLOPs)"}}
+
+
+def micro_gd(args):
+    from srgan_amd import _lib, ops
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    device = torch.device("cuda", 0)
+    _lib.load()
+    if args.dtype == "bf16":
+        ops.set_compute_dtype("bf16")
+    print(json.dumps(micro_gd_run(args.size, args.batch_per_gpu, args.dtype, args.steps, args.warmup, device)))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# multi-GPU launcher: runs in the parent BEFORE any GPU call
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """Start n rank processes of this script under torch.distributed.run and return their exit status.  The parent has
+    not initialised HIP (``import torch`` does not), so nothing that owns a GPU context is ever forked or re-exec'ed."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC only on this pool (RCCL needs it)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or n
+    env.setdefault("OMP_NUM_THREADS", str(max(1, cores // n)))   # host threads per rank: the CPU-generator noise, not a pool fight
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"launching {n} ranks: {' '.join(cmd[1:])}")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(rank, world, device):
+    """--launch-check: prove the rendezvous (every rank reports in) and stop before any GPU work."""
+    ranks = [None] * world
+    if world > 1:
+        dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", "0")), str(device)))
+    else:
+        ranks = [(rank, 0, str(device))]
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": sorted(ranks),
+                          "backend": dist.get_backend() if world > 1 else None,
+                          "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def first_step_check(first, args, world):
+    """The first (un-warmed) step's [errG, errD, errE] against the CPU oracle's values for the SAME seeds, networks and
+    batch (tests/golden/bench_first_step.json, written by tests/golden/make_bench_first_step.py).  Only the configuration
+    the fixture was generated for is compared; everything else must at least be finite."""
+    vals = [float(v) for v in first]
+    if not all(np.isfinite(vals)):
+        raise SystemExit(f"bench: non-finite losses in the first step: {vals}")
+    if not os.path.exists(FIRST_STEP_FIXTURE):
+        return {"hip": vals, "oracle": None}
+    fx = json.load(open(FIRST_STEP_FIXTURE))
+    key = f"{args.size}x{args.size}_b{args.batch_per_gpu}_k{args.k}"
+    same = (world == 1 and args.dtype == "f32" and not args.pretrained_e and key in fx["configs"])
+    if not same:
+        return {"hip": vals, "oracle": None}
+    ref = fx["configs"][key]["losses"]
+    rel = max(abs(a - b) / max(abs(b), 1e-6) for a, b in zip(vals, ref))
+    band = fx["band"]
+    if rel > band:
+        raise SystemExit(f"bench: first-step losses {vals} differ from the CPU oracle's {ref} by {rel:.2e} (> {band})")
+    return {"hip": [round(v, 5) for v in vals], "oracle": ref, "max_rel_err": float(f"{rel:.3e}"), "band": band}
+
+
+def _trainer_has_graph():
+    from srgan_amd.trainer import SRGAN_training
+    return hasattr(SRGAN_training, "enable_graph")
 
 
 def main():
@@ -171,31 +294,57 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-micro", action="store_true", help="skip the G+D forward-backward sub-record of the N=1 line")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 (default, BASELINE configs[1]) or the bf16 MFMA compute mode of configs [2]-[4] (never the headline)")
+    ap.add_argument("--pretrained-e", action="store_true",
+                    help="BASELINE configs[2] recipe: encoder trunk frozen, fcmean/fcvar on an external Adam(1e-3)")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step as a captured hipGraph (auto: when the trainer supports it)")
     ap.add_argument("--micro", choices=["gd"], default=None,
                     help="gd: the 'G+D forward-backward' micro-benchmark of SURVEY.md 8d (north_star's >= 70 %% MFMA-roofline target) "
                          "instead of the full train step")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: every rank reports in, rank 0 prints a JSON line, nobody touches the GPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))            # parent: no GPU call has happened in this process
     if args.micro == "gd":
         return micro_gd(args)
 
-    from srgan_amd import _lib, dp
+    from srgan_amd import dp
+    if args.launch_check:
+        ws = int(os.environ.get("WORLD_SIZE", "1"))
+        if ws > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=int(os.environ.get("RANK", "0")), world_size=ws)
+        if ws != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}")
+        return launch_check(int(os.environ.get("RANK", "0")), ws, "unopened")
+
+    from srgan_amd import _lib
     rank, world, device = dp.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if world > 1:
+        torch.set_num_threads(max(1, host_cores() // world))
     lib = _lib.load()
     if args.dtype == "bf16":
         from srgan_amd import ops as _ops
         _ops.set_compute_dtype("bf16")
     B = args.batch_per_gpu
-    sg = build_trainer(args.size, B * world, args.k, device)
+    sg = build_trainer(args.size, B * world, args.k, device, args.pretrained_e)
     torch.manual_seed(1000 + rank)           # per-rank noise stream after identical construction
 
+    use_graph = args.graph != "off" and _trainer_has_graph()
+    if args.graph == "on" and not use_graph:
+        raise SystemExit("--graph on: this trainer has no hipGraph mode")
+    warm = max(args.warmup, 2 if use_graph else 1)      # step 0 is the oracle-checked one; a graph needs one more to be captured
     batches = []
-    for s in range(args.steps + args.warmup):
+    for s in range(args.steps + warm):
         x, src, tgt = synthetic_batch(B, args.size, 4, seed=10_000 * (rank + 1) + s)
         batches.append((x.to(device), {"source": src.to(device), "target": tgt}))   # inputs resident in HBM
     torch.cuda.synchronize()
@@ -205,38 +354,72 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"rank {rank}/{world}: inputs resident, warm-up x{args.warmup}")
-    for s in range(args.warmup):
+    # step 0 (eager, un-warmed): checked against the CPU oracle's losses for the same seeds
+    log(f"rank {rank}/{world}: inputs resident; first step (checked against the oracle fixture)")
+    first = [float(v) for v in sg.train(*batches[0])]
+    check = first_step_check(first, args, world) if rank == 0 else None
+    if use_graph:
+        sg.enable_graph()
+    log(f"warm-up x{args.warmup}" + (" (captures the hipGraph)" if use_graph else ""))
+    for s in range(1, warm):
         sg.train(*batches[s])
         torch.cuda.synchronize()
         log(f"warm-up step {s} done")
+    graphed = bool(use_graph and getattr(sg, "graph_active", False))
     barrier()
-    lib.srgan_prof_enable(1)
+    prof_live = not graphed                   # HIP events cannot bracket kernels inside a graph replay
+    if prof_live:
+        lib.srgan_prof_enable(1)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     last = None
-    for s in range(args.warmup, args.warmup + args.steps):
+    marks[0].record()
+    for i, s in enumerate(range(warm, warm + args.steps)):
         last = sg.train(*batches[s])
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    lib.srgan_prof_enable(0)
+    if prof_live:
+        lib.srgan_prof_enable(0)
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, median_ms], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, median_ms = float(t[0].item()), float(t[1].item())
+    last = [float(v) for v in last]
+    if not all(np.isfinite(last)):
+        raise SystemExit(f"bench: non-finite losses after the timed region: {last}")
 
-    # dominant kernel by accumulated HIP-event time inside the timed region
-    best = None
+    prof_steps = args.steps
+    if not prof_live:
+        # same kernels, same shapes, eager launches: per-kernel HIP-event durations for the roofline record
+        prof_steps = min(args.steps, 3)
+        if hasattr(sg, "disable_graph"):
+            sg.disable_graph()
+        torch.cuda.synchronize()
+        lib.srgan_prof_enable(1)
+        for s in range(prof_steps):
+            sg.train(*batches[1 + s])
+        torch.cuda.synchronize()
+        lib.srgan_prof_enable(0)
+
+    # per-kernel totals of the HIP-event brackets
     kernels = {}
+    best = None
     for kid in range(lib.srgan_prof_num_kernels()):
         ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
         _lib.check(lib.srgan_prof_collect(kid, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_collect")
         if n.value == 0:
             continue
         name = lib.srgan_prof_kernel_name(kid).decode()
+        div = executed_divisor(name)
         kernels[name] = {"launches": n.value, "total_ms": round(ms.value, 3), "avg_us": round(1e3 * ms.value / n.value, 2),
-                         "tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 2)}
-        if best is None or ms.value > best[1]:
+                         "algorithmic_tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
+                         "executed_tflops": round(fl.value / div / (ms.value * 1e-3) / 1e12, 2),
+                         "_ms": ms.value, "_fl": fl.value}
+        if fl.value > 0 and (best is None or ms.value > best[1]):
             best = (name, ms.value, n.value, fl.value)
 
     if rank == 0:
@@ -244,42 +427,72 @@ def main():
         value = images / elapsed
         peak = PEAK_TFLOPS["f32" if args.dtype == "f32" else "bf16"]
         name, ms, n, fl = best
-        achieved = fl / (ms * 1e-3) / 1e12
-        # Winograd F(2x2,3x3) kernels issue 16 multiplies per 36 algorithmic ones: the algorithmic rate can exceed the
-        # MFMA peak, so the rate of the FLOPs actually issued on the matrix pipe is reported next to it
-        wino = name.startswith("wino")
-        wino43 = name.startswith("wino43")
-        executed = achieved / (4.0 if wino43 else 2.25) if wino else achieved
+        div = executed_divisor(name)
+        algorithmic = fl / (ms * 1e-3) / 1e12
+        executed = algorithmic / div
+        # the layer a Winograd F(4x4,3x3) multiply belongs to also runs its HBM-bound transform kernel
+        partner = {"wino43_kernel": "wino43_input_kernel", "wino43_wgrad_kernel": "wino43_dy_kernel"}.get(name)
+        layer = None
+        if partner and partner in kernels:
+            lms = ms + kernels[partner]["_ms"]
+            layer = {"kernels": [partner, name], "total_ms": round(lms, 3),
+                     "executed_tflops": round(fl / div / (lms * 1e-3) / 1e12, 2),
+                     "frac": round(fl / div / (lms * 1e-3) / 1e12 / peak, 4),
+                     "algorithmic_tflops": round(fl / (lms * 1e-3) / 1e12, 2)}
+        step_exec = sum(kk["_fl"] / executed_divisor(nm) for nm, kk in kernels.items()) / prof_steps      # FLOPs per step
+        gemm_ms = sum(kk["_ms"] for kk in kernels.values()) / prof_steps
+        step_ms_mean = 1e3 * elapsed / args.steps
+        for kk in kernels.values():
+            kk.pop("_ms"), kk.pop("_fl")
+        traffic, traffic_src = pmc_traffic(name)
+        gflop_img = (GFLOP_PER_IMAGE_FROZEN_E if args.pretrained_e else GFLOP_PER_IMAGE).get(args.size)
         out = {
             "metric": "images/sec G+D+E train step, CelebA 128x128 bs=32/GPU" if (args.size == 128 and B == 32) else
                       f"images/sec G+D+E train step, CelebA {args.size}x{args.size} bs={B}/GPU",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_ms_mean, 3), "ms_per_step_median": round(median_ms, 3),
+            "value_at_median_step": round(B * world / (median_ms * 1e-3), 3),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"SRGAN-nopretrain (03-train) G+D+E train step, {args.size}x{args.size}, "
+            "config": {"workload": f"SRGAN-{'full, pretrained-E recipe (05-train)' if args.pretrained_e else 'nopretrain (03-train)'} "
+                                   f"G+D+E train step, {args.size}x{args.size}, "
                                    f"bs={B}/GPU, k={args.k}, " + ("fp32" if args.dtype == "f32" else "bf16 MFMA conv forward / input gradient, "
-                                   "fp32 storage, weight gradients, norms, losses, Adam") + ", E trainable (BASELINE configs[1])",
+                                   "fp32 storage, weight gradients, norms, losses, Adam") +
+                                   (", E trunk frozen (BASELINE configs[2])" if args.pretrained_e else ", E trainable (BASELINE configs[1])"),
                        "global_batch": B * world, "unrolled_k": args.k, "parallelism": f"dp{world}",
-                       "gflop_per_image_algorithmic": GFLOP_PER_IMAGE.get(args.size),
-                       "step_tflops_algorithmic": round(value * GFLOP_PER_IMAGE.get(args.size, 0) / 1e3, 2),
-                       "losses_last_step": [round(float(v), 4) for v in last]},
-            "roofline": {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(name),
-                         "executed_mfma_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4),
-                         "algorithm": ("Winograd F(4x4,3x3): the multiply kernel issues 4x fewer MFMA FLOPs than the algorithmic count "
-                                       "(its input transform is the separate HBM-bound wino43_input_kernel, listed in all_gemm_kernels), so the "
-                                       "ALGORITHMIC rate asked for in `achieved` exceeds the MFMA peak (frac > 1); executed_frac is the "
-                                       "utilisation of the matrix pipe") if wino43 else
-                                      ("Winograd F(2x2,3x3) / F(3x3,2x2): 2.25x fewer MFMA FLOPs than the algorithmic count, so the "
-                                       "ALGORITHMIC rate asked for in `achieved` can exceed the MFMA peak (frac > 1); "
-                                       "executed_frac is the utilisation of the matrix pipe") if wino
-                                      else "implicit GEMM: executed = algorithmic FLOPs",
+                       "execution": "hipGraph replay of the captured step" if graphed else "eager launches",
+                       "gflop_per_image_algorithmic": gflop_img,
+                       "step_tflops_algorithmic": round(value * (gflop_img or 0) / 1e3, 2),
+                       "losses_first_step_vs_oracle": check,
+                       "losses_last_step": [round(v, 4) for v in last]},
+            "roofline": {"bound": "mfma", "kernel": name, "achieved": round(executed, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(executed / peak, 4),
+                         "traffic": traffic,
+                         "traffic_note": f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC) REPLAYED from {traffic_src}: "
+                                         "collected over this same command in separate --pmc passes, not measured in this run",
+                         "achieved_note": "achieved / frac = MFMA FLOPs this kernel actually ISSUES (algorithmic conv FLOPs / "
+                                          f"{div:g}) / HIP-event duration, against the dense matrix peak: the utilisation of the matrix pipe",
+                         "algorithmic_tflops": round(algorithmic, 2), "algorithmic_over_peak": round(algorithmic / peak, 4),
+                         "algorithmic_note": "direct-convolution FLOPs (2*N*Ho*Wo*O*kh*kw*I, SURVEY 8d) of this kernel's launches / "
+                                             "their duration; exceeds the peak for the Winograd kernels because they skip multiplies",
                          "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
-                         "traffic_note": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, profiles/r*_pmc_traffic.json)",
-                         "note": "achieved = sum of algorithmic conv FLOPs (2*N*Ho*Wo*O*kh*kw*I) of this kernel's launches / "
-                                 "sum of their HIP-event durations inside the timed region (rank 0)",
+                         "layer": layer,
+                         "step": {"executed_mfma_tflop_per_step": round(step_exec / 1e12, 3),
+                                  "executed_frac": round(step_exec / (step_ms_mean * 1e-3) / 1e12 / peak, 4),
+                                  "executed_frac_over_gemm_kernel_time": round(step_exec / (gemm_ms * 1e-3) / 1e12 / peak, 4),
+                                  "gemm_kernel_ms_per_step": round(gemm_ms, 3),
+                                  "note": "all GEMM-class launches of a step: issued MFMA FLOPs / step time (and / their own "
+                                          "summed duration) / peak"},
+                         "measured_over": (f"{prof_steps} eager steps after the timed region (HIP events cannot bracket kernels "
+                                           "inside a hipGraph replay; same kernels and shapes)") if not prof_live else
+                                          "the timed region (HIP events on the launch stream, rank 0)",
                          "all_gemm_kernels": kernels},
         }
+        if world == 1 and not args.no_micro and args.size in GD_GFLOP_PER_IMAGE:
+            log("micro benchmark: G+D forward-backward")
+            del sg
+            torch.cuda.empty_cache()
+            out["micro_gd"] = micro_gd_run(args.size, B, args.dtype, 10, 3, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, args.k)
         print(json.dumps(out))

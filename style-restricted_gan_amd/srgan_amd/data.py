@@ -109,8 +109,8 @@ class GpuTransform:
                                                self.size[1], hb.data_ptr(), hc.data_ptr(), self.h_ksize, vb.data_ptr(),
                                                vc.data_ptr(), self.v_ksize, fd.data_ptr(), int(self.minmax), int(self.mean0),
                                                out.data_ptr(), ws.data_ptr(), nbytes, stream.cuda_stream), "preprocess_u8")
-            for t in (xd, fd, ws):
-                t.record_stream(stream)
+        # xd / fd / ws were allocated while `stream` was current and are only used on it: the caching allocator already orders
+        # their reuse.  `out` is the one tensor that crosses streams -- its CONSUMER must record it (PrefetchLoader does).
         return out.permute(0, 3, 1, 2)        # logical NCHW over NHWC memory
 
 
@@ -129,7 +129,12 @@ class PrefetchLoader:
         while nxt is not None:
             cur = nxt
             nxt = self._stage(it)
-            torch.cuda.current_stream(self.transform.device).wait_stream(self.stream)
+            consumer = torch.cuda.current_stream(self.transform.device)
+            consumer.wait_stream(self.stream)
+            # the batch was allocated on the side stream's pool but is read by the train step on the consumer stream: without
+            # this its block could be handed to a later _stage() (H2D + preprocess on the side stream, which never waits for
+            # the consumer) while the step that reads it is still queued
+            cur[0].record_stream(consumer)
             yield cur
 
     def _stage(self, it):

@@ -17,7 +17,12 @@ import torch.nn as nn
 
 
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True under a multi-rank process group.  ``SRGAN_DP_FORCE=1`` also takes the data-parallel code path with a
+    one-rank group: the 1-GPU test box then drives the real RCCL calls (side-stream all-reduce, all-gather inside autograd),
+    which two ranks cannot do on one device."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("SRGAN_DP_FORCE") == "1"
 
 
 def world_size():
@@ -39,7 +44,7 @@ def init_from_env(backend=None):
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
-    if ws > 1 and not (dist.is_available() and dist.is_initialized()):
+    if (ws > 1 or os.environ.get("SRGAN_DP_FORCE") == "1") and not (dist.is_available() and dist.is_initialized()):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rk, world_size=ws)
@@ -94,16 +99,54 @@ def all_gather_rows(x):
 BUCKET_BYTES = 16 << 20   # per all-reduce message: several buckets per network, so the first ones run under the backward
 
 
-class GradReducer:
-    """Averages ``.grad`` of a parameter list across ranks with bucketed all-reduce on a side stream.
+class _Bucket:
+    """One all-reduce message: a PERSISTENT flat fp32 buffer and, per parameter, the view of it that becomes ``p.grad``."""
+    __slots__ = ("params", "flat", "views", "ready", "done", "launched", "count", "expected", "hit")
 
-    ``arm()`` before the backward: every parameter carries a post-accumulate-grad hook, and a bucket's all-reduce is
-    enqueued on the side stream the moment its last gradient is final -- so the collectives of the layers near the loss
-    run under the backward conv stack of the layers below them (buckets are filled in reverse parameter order, the order
-    in which autograd finishes them).  ``start()`` after the backward enqueues whatever is left (parameters without a
-    gradient take part with zeros so every rank issues the same calls) and returns immediately; ``finish()`` makes the
-    compute stream wait for the collectives and scatters the averaged values back.  Without ``arm()`` everything is
-    enqueued by ``start()``.
+    def __init__(self, params):
+        self.params = params
+        self.flat = None               # allocated at first use (parameters may still move between devices before that)
+        self.views = None
+        self.ready = self.done = None  # HIP events: compute -> comm (bucket flattened), comm -> compute (all-reduce finished)
+        self.launched = False
+        self.count = 0
+        self.expected = sum(1 for p in params if p.requires_grad)
+        self.hit = [False] * len(params)
+
+    def materialise(self):
+        p0 = self.params[0]
+        if self.flat is not None and self.flat.device == p0.device:
+            return
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=p0.device)
+        self.views, off = [], 0
+        for p in self.params:
+            n = p.numel()
+            self.views.append(self.flat[off:off + n].view(p.shape))      # dense, contiguous: what the fused Adam wants
+            off += n
+        if p0.is_cuda:
+            self.ready, self.done = torch.cuda.Event(), torch.cuda.Event()
+
+
+class GradReducer:
+    """Averages ``.grad`` of a parameter list across ranks: bucketed, in-place all-reduce on a side HIP stream.
+
+    Every bucket owns a persistent flat buffer.  When a bucket is sent, its gradients are laid into the buffer by ONE
+    multi-tensor copy, the buffer is all-reduced IN PLACE on the communication stream (``ReduceOp.AVG`` on RCCL: no scaling
+    pass), and ``finish()`` binds each ``p.grad`` to its slice of the buffer -- nothing is copied back.  The two stream
+    dependencies are explicit events, so they hold for an asynchronous backend (RCCL enqueues and returns) as well as for
+    gloo: ``ready`` (recorded on the compute stream after the flatten, awaited by the communication stream before the
+    all-reduce) and ``done`` (recorded on the communication stream after the all-reduce, awaited by the compute stream in
+    ``finish()`` -- and therefore also ordered before the next flatten into the same buffer).
+
+    ``arm()`` before the backward: every parameter carries a post-accumulate-grad hook, and a bucket is sent the moment its
+    last gradient is final -- the collectives of the layers near the loss run under the backward conv stack of the layers
+    below them (buckets are filled in reverse parameter order, the order in which autograd finishes them).  ``start()``
+    after the backward sends whatever is left and returns immediately; ``finish()`` waits and binds the averages.
+
+    Parameters without a gradient take part with zeros so that every rank issues the same calls.  After an ARMED pass a
+    parameter that received no gradient (no hook hit -- a structural property of the graph, identical on every rank) keeps
+    ``p.grad = None``, so the optimiser skips it exactly as the single-process step does; ``reduce()`` without ``arm()``
+    (manual use) hands every parameter its averaged gradient.
     """
 
     def __init__(self, params):
@@ -111,13 +154,11 @@ class GradReducer:
         self._pending = None
         self._comm_stream = None
         self._armed = False
-        self._buckets_cache = self._buckets()
+        self._buckets_cache = [_Bucket(b) for b in self._buckets()]
         self._where = {}
         for b, bucket in enumerate(self._buckets_cache):
-            for p in bucket:
-                self._where[id(p)] = b
-        self._count = [0] * len(self._buckets_cache)
-        self._launched = [False] * len(self._buckets_cache)
+            for j, p in enumerate(bucket.params):
+                self._where[id(p)] = (b, j)
         self._work = []
         if hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
             for p in self.params:
@@ -137,76 +178,100 @@ class GradReducer:
             buckets.append(cur)
         return buckets
 
+    def _reset(self):
+        for bk in self._buckets_cache:
+            bk.launched, bk.count = False, 0
+            bk.expected = sum(1 for p in bk.params if p.requires_grad)
+            bk.hit = [False] * len(bk.params)
+        self._work = []
+
     def arm(self):
         if not is_distributed() or not self.params:
             return
         self._armed = True
-        self._count = [0] * len(self._buckets_cache)
-        self._launched = [False] * len(self._buckets_cache)
-        self._work = []
+        self._reset()
 
     def _on_grad(self, p):
         if not self._armed:
             return
-        b = self._where[id(p)]
-        self._count[b] += 1
-        if self._count[b] == sum(1 for q in self._buckets_cache[b] if q.requires_grad) and not self._launched[b]:
+        b, j = self._where[id(p)]
+        bk = self._buckets_cache[b]
+        if bk.launched:
+            raise RuntimeError("GradReducer: a gradient arrived for a bucket that was already all-reduced "
+                               "(a parameter's requires_grad changed between arm() and the backward?)")
+        bk.count += 1
+        bk.hit[j] = True
+        if bk.count == bk.expected:
             self._launch(b)
 
     def _launch(self, b):
-        bucket = self._buckets_cache[b]
-        on_gpu = self.params[0].is_cuda
-        if on_gpu and self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream()
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
-        flat = torch.cat([g.reshape(-1) for g in grads])
+        bk = self._buckets_cache[b]
+        bk.materialise()
+        on_gpu = bk.flat.is_cuda
+        srcs, dsts, holes = [], [], []
+        for p, v in zip(bk.params, bk.views):
+            g = p.grad
+            if g is None:
+                holes.append(v)
+            elif g.data_ptr() != v.data_ptr():        # already the bucket's own slice (no zero_grad since the last pass)
+                srcs.append(g)
+                dsts.append(v)
+        with torch.no_grad():
+            if dsts:
+                torch._foreach_copy_(dsts, srcs)       # one multi-tensor launch lays the bucket out
+            if holes:
+                torch._foreach_zero_(holes)
+        avg = _backend_has_avg()
         if on_gpu:
-            # the side stream must see the flattened bucket (and the backward kernels that produced it) complete
-            self._comm_stream.wait_stream(torch.cuda.current_stream())
-            flat.record_stream(self._comm_stream)
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=bk.flat.device)
+            bk.ready.record(torch.cuda.current_stream(bk.flat.device))
             with torch.cuda.stream(self._comm_stream):
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                self._comm_stream.wait_event(bk.ready)
+                dist.all_reduce(bk.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
+                if not avg:
+                    bk.flat.mul_(1.0 / dist.get_world_size())
+                bk.done.record(self._comm_stream)
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        self._launched[b] = True
-        self._work.append((bucket, flat))
+            dist.all_reduce(bk.flat, op=dist.ReduceOp.SUM)
+            bk.flat.mul_(1.0 / dist.get_world_size())
+        bk.launched = True
+        self._work.append(bk)
 
     def start(self):
         if not is_distributed() or not self.params:
             return
-        if not self._armed:
-            self._launched = [False] * len(self._buckets_cache)
-            self._work = []
+        armed = self._armed
+        if not armed:
+            self._reset()
         self._armed = False
         for b in range(len(self._buckets_cache)):      # same order on every rank
-            if not self._launched[b]:
+            if not self._buckets_cache[b].launched:
                 self._launch(b)
-        self._pending = (self._work, dist.get_world_size())
+        self._pending = (self._work, armed)
         self._work = []
 
     def finish(self):
         if self._pending is None:
             return
-        work, ws = self._pending
+        work, armed = self._pending
         self._pending = None
-        if self._comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
-        inv = 1.0 / ws
-        for bucket, flat in work:
-            flat.mul_(inv)                      # one launch for the whole bucket
-            views, dsts, off = [], [], 0
-            for p in bucket:
-                n = p.numel()
-                v = flat[off:off + n].view_as(p)
-                if p.grad is None:
-                    p.grad = v.clone()
-                else:
-                    views.append(v)
-                    dsts.append(p.grad)
-                off += n
-            if dsts:
-                torch._foreach_copy_(dsts, views)   # one multi-tensor launch instead of one copy per parameter
+        for bk in work:
+            if bk.done is not None:
+                torch.cuda.current_stream(bk.flat.device).wait_event(bk.done)
+            for j, (p, v) in enumerate(zip(bk.params, bk.views)):
+                if p.grad is None and armed and not bk.hit[j]:
+                    continue                            # received no gradient on any rank: the optimiser skips it
+                p.grad = v
 
     def reduce(self):
         self.start()
         self.finish()
+
+
+def _backend_has_avg():
+    """RCCL reduces with ncclAvg in the collective itself; gloo has no AVG (sum, then one scaling launch per bucket)."""
+    try:
+        return dist.get_backend() == "nccl"
+    except Exception:
+        return False

@@ -160,12 +160,18 @@ class SRGAN_training():
     def _fused_paths(self):
         """The batched / fused execution needs this package's own modules (feature / logit entry points)."""
         return (hasattr(dp.unwrap(self.D), "forward_logits") and self._ref_is_onehot
-                and hasattr(dp.unwrap(self.E), "features"))
+                and hasattr(dp.unwrap(self.E), "features") and self._class_is_mse())
+
+    def _class_is_mse(self):
+        """The fused class-loss kernel is softmax + MSE (nn.MSELoss in every reference notebook, 05-train cell 13); any other
+        criterion_class takes the generic path through the criterion itself."""
+        c = self.criterion_class
+        return isinstance(c, nn.MSELoss) and getattr(c, "reduction", "mean") == "mean"
 
     def _d_losses(self, image, gan_target, class_which, want_class):
         """LSGAN (+ class MSE) of D(image) through the fused head/loss kernels."""
         D = dp.unwrap(self.D)
-        if hasattr(D, "forward_logits") and self._ref_is_onehot:
+        if hasattr(D, "forward_logits") and self._ref_is_onehot and self._class_is_mse():
             outs, logits = D.forward_logits(image)
             gan = get_loss_D(outs, gan_target, self.criterion, self.device)
             cls = None
@@ -281,8 +287,11 @@ class SRGAN_training():
 
             _, mu, logvar, _, _ = source_enc_info
             if L["KL"] > 0:
+                # a SUM over the rows of the batch (util_notebook.py:630-634): under data parallelism each rank holds the
+                # sum over ITS rows and the gradient all-reduce averages, so the optimised term is pre-scaled by the world
+                # size (as the batch-statistics losses below); the reported value stays the local sum
                 errE_KL = -0.5 * torch.sum(1 + logvar - mu ** 2 - logvar.exp())
-                errE = errE + errE_KL * L["KL"]
+                errE = errE + errE_KL * (L["KL"] * ws if ws > 1 else L["KL"])
                 errE_output = errE_output + errE_KL * L["KL"]
                 terms["errE_KL"] = errE_KL
 
@@ -378,10 +387,18 @@ class SRGAN_training():
         oh = self._onehot("target")
         fakes = []
         if k > 1 and isinstance(dp.unwrap(self.G), SingleGenerator):     # per-sample network: batching is exact
+            # the kernels address an activation with 32-bit byte offsets (< 4 GiB per tensor): translations are batched in
+            # groups whose widest activation (the first conv's nch planes at full resolution) stays under that, e.g.
+            # 256x256, B=64, k=5 runs as two groups of 2*B images instead of one of 4*B
+            Gm = dp.unwrap(self.G)
+            widest = max(int(Gm.down_convs[0].weight.shape[0]), 3) * src.shape[2] * src.shape[3] * 4
+            per_group = max(1, min(k - 1, (((1 << 32) - (1 << 26)) // widest) // nb))
             with torch.no_grad():
-                c_all = torch.cat([torch.cat([oh, z], 1) for z in noises[:-1]], 0)
-                imgs = self.G(ops.cat_batch([src] * (k - 1)), c_all)
-            fakes = [(imgs[i * nb:(i + 1) * nb], noises[i]) for i in range(k - 1)]
+                for lo in range(0, k - 1, per_group):
+                    zs = noises[lo:min(lo + per_group, k - 1)]
+                    c_all = torch.cat([torch.cat([oh, z], 1) for z in zs], 0)
+                    imgs = self.G(ops.cat_batch([src] * len(zs)) if len(zs) > 1 else src, c_all)
+                    fakes += [(imgs[i * nb:(i + 1) * nb], z) for i, z in enumerate(zs)]
         elif k > 1:
             with torch.no_grad():
                 fakes = [(self.G(src, torch.cat([oh, z], 1)), z) for z in noises[:-1]]

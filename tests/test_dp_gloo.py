@@ -62,13 +62,36 @@ def _worker(rank, world, port, out):
     red.arm()
     xin = torch.arange(6.0) * (rank + 1)
     ((w1 * xin).sum() * w3.sum() + (w2 ** 2).sum() * (rank + 1)).backward()
-    assert len(red._work) >= 2 and not all(red._launched)       # w1/w2/w3 buckets went out from the hooks, `unused` did not
+    launched = [bk.launched for bk in red._buckets_cache]
+    assert len(red._work) >= 2 and not all(launched)            # w1/w2/w3 buckets went out from the hooks, `unused` did not
     local = [p.grad.clone() if p.grad is not None else None for p in (w1, w2, w3)]
     red.start()
     red.finish()
     assert torch.allclose(w1.grad, torch.arange(6.0) * 1.5 * 12.0) and torch.allclose(w2.grad, torch.full((20,), 0.5 * 1.5))
-    assert torch.allclose(w3.grad, torch.full((6,), 0.5 * 15.0 * 1.5)) and torch.allclose(unused.grad, torch.zeros(4))
+    assert torch.allclose(w3.grad, torch.full((6,), 0.5 * 15.0 * 1.5))
+    assert unused.grad is None          # no gradient on any rank in an ARMED pass: stays None, the optimiser skips it
     assert not torch.allclose(local[0], w1.grad)
+    # the averaged gradients ARE slices of the persistent flat buckets (nothing is copied back) ...
+    for p_ in (w1, w2, w3):
+        b_, j_ = red._where[id(p_)]
+        assert p_.grad.data_ptr() == red._buckets_cache[b_].views[j_].data_ptr()
+    # ... and a second pass without zero_grad accumulates into those slices and reduces them again in place
+    red.arm()
+    ((w1 * xin).sum() * w3.sum() + (w2 ** 2).sum() * (rank + 1)).backward()
+    red.start()
+    red.finish()
+    assert torch.allclose(w2.grad, torch.full((20,), 0.5 * 1.5 + 0.5 * 1.5))
+    # a gradient that arrives for a bucket that has already been sent is an error, not a silent drop
+    red.arm()
+    w2.grad = None
+    (w2 ** 2).sum().backward()
+    try:
+        (w2 ** 2).sum().backward()
+        raise AssertionError("late gradient was accepted")
+    except RuntimeError as e:
+        assert "already all-reduced" in str(e)
+    red.start()
+    red.finish()
 
     # 2. all_gather_rows forward / backward
     x = (torch.arange(6.0).view(3, 2) + 10 * rank).requires_grad_(True)
@@ -159,3 +182,25 @@ def test_single_process_is_a_no_op():
     p.grad = torch.ones(3)
     dp.GradReducer([p]).reduce()
     assert torch.equal(p.grad, torch.ones(3))
+
+
+def test_bench_launcher_spawns_ranks_before_any_gpu_call():
+    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE): the parent starts the ranks under torch.distributed.run,
+    rank 0's JSON line comes back on stdout, exit status 0.  --launch-check stops every rank before GPU work."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["launch_check"] and rec["n_gpus"] == 2 and [x[0] for x in rec["ranks"]] == [0, 1]
+    assert [x[1] for x in rec["ranks"]] == [0, 1]          # LOCAL_RANK -> device index
+    # a mismatch between --gpus and the environment is refused
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env2,
+                        capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0

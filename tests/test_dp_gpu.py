@@ -30,7 +30,7 @@ def _noise_source(rank, world):
     return fn
 
 
-def _run(rank, world, out_q=None):
+def _run(rank, world, out_q=None, kl=0.0):
     from oracle import trainer as otrainer
     from tests.common import build_hip_nets
     from srgan_amd.trainer import SRGAN_training
@@ -41,7 +41,7 @@ def _run(rank, world, out_q=None):
     # rounding-level differences between the two reduction orders are amplified to O(lr) parameter differences,
     # which would hide (or fake) a real data-parallel discrepancy.
     opts = [hoptim.Adam(net.parameters(), lr=1e-4, betas=(0.5, 0.999), eps=1e-2) for net in (G, D, E)]
-    sg = SRGAN_training([G, D, E], opts, [nn.MSELoss(), nn.MSELoss()], dict(otrainer.DEFAULT_LBD), K, "cuda",
+    sg = SRGAN_training([G, D, E], opts, [nn.MSELoss(), nn.MSELoss()], dict(otrainer.DEFAULT_LBD, KL=kl), K, "cuda",
                         np.eye(4), B, "mu", 8)
     sg.opt_sche_initialization()
     sg.noise_fn = _noise_source(rank, world)
@@ -59,9 +59,11 @@ def _run(rank, world, out_q=None):
     return losses, state, terms
 
 
-def _worker(rank, world, port, out_q):
+def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), SRGAN_DP_DEVICE="0", SRGAN_DP_BACKEND="gloo")
+                      LOCAL_RANK=str(rank), SRGAN_DP_DEVICE="0", SRGAN_DP_BACKEND=backend)
+    if force:
+        os.environ["SRGAN_DP_FORCE"] = "1"
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "style-restricted_gan_amd")):
@@ -70,19 +72,21 @@ def _worker(rank, world, port, out_q):
     import torch.distributed as dist
     from srgan_amd import dp
     dp.init_from_env()
-    assert dp.world_size() == world
-    _run(rank, world, out_q)
+    assert dp.world_size() == world and dp.is_distributed()
+    _run(rank, world, out_q, kl)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process():
-    from tests.common import close_params
-    ref_losses, ref_state, ref_terms = _run(0, 1)
+@pytest.mark.parametrize("kl", [0.0, 0.1])
+def test_two_ranks_equal_one_process(kl):
+    """kl=0.1: the conventional-KL term (a SUM over rows, 01/02/03/05 notebooks' 0.1 option) must be pre-scaled by the world
+    size like the batch-statistics losses, or E receives 1/ws of its gradient."""
+    ref_losses, ref_state, ref_terms = _run(0, 1, kl=kl)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kl)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
@@ -92,10 +96,36 @@ def test_two_ranks_equal_one_process():
     dp_losses = (np.array(res[0][1]) + np.array(res[1][1])) / 2
     ref = np.array(ref_losses)
     # errG / errD are per-sample means -> rank average == full batch; errE's latent part is global on every rank
-    np.testing.assert_allclose(dp_losses, ref, rtol=1e-3)
+    if kl == 0.0:
+        np.testing.assert_allclose(dp_losses, ref, rtol=1e-3)
+    else:      # errE reports the LOCAL KL sum: the rank sum (not the average) of that part equals the full-batch value
+        np.testing.assert_allclose(dp_losses[:, :2], ref[:, :2], rtol=1e-3)
+        kl_sum = res[0][3]["errE_KL"] + res[1][3]["errE_KL"]
+        assert abs(kl_sum - ref_terms["errE_KL"]) <= 1e-3 * abs(ref_terms["errE_KL"]), (kl_sum, ref_terms["errE_KL"])
     for key in ("errE_bKL", "errE_corr", "errE_hist"):
         for r in res:
             assert abs(r[3][key] - ref_terms[key]) <= 1e-3 * max(abs(ref_terms[key]), 1e-3), (key, r[3][key], ref_terms[key])
     for key, v in res[0][2].items():
         d = float(np.abs(v - ref_state[key]).max())
         assert d <= 1e-5, (key, d)        # 4 optimiser steps of at most lr=1e-4 each; observed ~2e-6
+
+
+def test_rccl_path_one_rank_equals_plain_step():
+    """The real RCCL calls on the test box's one GPU: a one-rank ``nccl`` process group with SRGAN_DP_FORCE=1 takes the whole
+    data-parallel path -- hook-driven buckets with the G and E reducers armed together, in-place all-reduce of the flat buffers
+    on the communication stream (asynchronous: only the ready / done events order it against the compute stream), the mu
+    all-gather inside autograd, gradients bound to bucket slices, parameters without gradient left at None -- and must
+    reproduce the plain single-process step.  (Two ranks cannot share a device under RCCL; the 2-rank arithmetic is the gloo
+    test above.)"""
+    ref_losses, ref_state, ref_terms = _run(0, 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), q, 0.0, "nccl", True))
+    p.start()
+    rank, losses, state, terms = q.get(timeout=240)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=1e-4)
+    for key, v in state.items():
+        d = float(np.abs(v - ref_state[key]).max())
+        assert d <= 1e-6, (key, d)
