@@ -1,4 +1,6 @@
 """Shared helpers for the parity tests (oracle side lives in oracle/)."""
+import os
+
 import numpy as np
 import torch
 
@@ -49,14 +51,19 @@ def close(a, b, rtol=1e-4, atol=1e-6, what=""):
     assert err <= atol + rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
 
 
-def close_grad(a, b, tol=2e-4, l2_tol=2e-2, what=""):
-    """Gradient comparison that tolerates activation-mask flips.
+def close_grad(a, b, tol=2e-4, l2_tol=2e-2, med_tol=2e-3, what=""):
+    """Gradient comparison that tolerates activation-mask flips -- and nothing else.
 
-    ReLU / LeakyReLU derivatives are discontinuous: an element whose pre-activation lies within fp32
-    rounding of zero can take the other branch in a different (equally valid) summation order.  One such
-    flip changes that element's gradient by O(1) and, through instance norm, its whole (n, c) plane and
-    everything upstream by O(1e-2) of the max.  So: pass if the max-norm error is within ``tol``; otherwise
-    require the relative L2 error to stay within ``l2_tol`` (a wiring/indexing bug gives O(1))."""
+    ReLU / LeakyReLU derivatives are discontinuous: an element whose pre-activation lies within fp32 rounding of zero can take
+    the other branch in a different (equally valid) summation order.  One such flip switches the gradient of THAT element on or
+    off: the weight-gradient row of its output channel gains or loses one term of its sum over pixels (relative size
+    ~1/sqrt(pixels): up to ~2e-2 on the 2x32x32 test maps), and through instance norm (mean over the H*W plane) every element
+    of that plane, and everything upstream, moves by ~1/(H*W) of it.  A flip is therefore SPARSE-and-large plus BROAD-and-tiny.
+    A wiring or scaling bug (a loss term weighted 2 % wrong, a missing factor on one path) is the opposite: broad and
+    proportional.  So: pass if the max-norm error is within ``tol``; otherwise require
+      * the relative L2 error within ``l2_tol`` (bounds the sparse part: an indexing bug gives O(1)), AND
+      * the MEDIAN element error within ``med_tol`` of the median magnitude (bounds the broad part: a term mis-scaled by 1 %
+        moves every element by ~1 % and fails this, which the L2 bound alone would let through)."""
     a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a)).double()
     b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b)).double()
     assert a.shape == b.shape, (what, a.shape, b.shape)
@@ -65,7 +72,15 @@ def close_grad(a, b, tol=2e-4, l2_tol=2e-2, what=""):
     if err <= 1e-6 + tol * scale:
         return
     l2 = float((a - b).norm() / max(float(b.norm()), 1e-30))
+    med = float((a - b).abs().median() / max(float(b.abs().median()), 1e-30)) if a.numel() >= 32 else 0.0
+    frac = float(((a - b).abs() > 1e-6 + tol * scale).double().mean())
+    log = os.environ.get("SRGAN_TEST_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write(f"close_grad fallback {what}: numel {a.numel()} max {err / scale:.3e} l2 {l2:.3e} median {med:.3e} "
+                    f"beyond-tol fraction {frac:.3e}\n")
     assert l2 <= l2_tol, f"{what}: max err {err:.3e} (scale {scale:.3e}), rel L2 {l2:.3e}"
+    assert med <= med_tol, f"{what}: median err / median magnitude {med:.3e} (broad error: not an activation flip)"
 
 
 def close_params(a, b, lr, n_opt_steps, what=""):
@@ -76,6 +91,9 @@ def close_params(a, b, lr, n_opt_steps, what=""):
     b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b)).double().flatten()
     assert a.shape == b.shape, (what, a.shape, b.shape)
     err = (a - b).abs()
-    assert float(err.max()) <= 2 * lr * n_opt_steps + 1e-6, f"{what}: max err {float(err.max()):.3e}"
+    # |Adam update| <= lr only in step 1; with betas (0.5, 0.999) the bias-corrected ratio m^/sqrt(v^) of step 2 reaches
+    # (g1 + 2 g2)/3 / sqrt((g1^2 + g2^2)/2) <= 1.054 (at g2 = 2 g1) and stays below 1.1 in the first handful of steps --
+    # observed 4.094e-4 = 2 * lr * 2.047 on one element of G.down_convs.1.weight after 2 steps at bs=32, k=5
+    assert float(err.max()) <= 2.2 * lr * n_opt_steps + 1e-6, f"{what}: max err {float(err.max()):.3e}"
     if a.numel() >= 32:      # tiny tensors (a 4-element bias) have no meaningful "bulk"
         assert float(err.median()) <= 0.2 * lr, f"{what}: median err {float(err.median()):.3e}"

@@ -148,3 +148,56 @@ def test_image_from_output_matches_reference(golden_dir):
     gold = np.load(os.path.join(golden_dir, "inference_T.npz"))
     img = image_from_output(torch.from_numpy(gold["source"]))[0]
     assert np.array_equal(np.asarray(img), gold["pil.source"])
+
+
+def test_get_target_draw_order_vs_reference(golden_dir):
+    """``get_target`` (util.py:268-319) under np.random.seed against the reference's own output: same targets, and the global
+    numpy generator left at the same position (one np.random.shuffle per row, in row order)."""
+    import json
+    from srgan_amd import losses as hl
+    fx = json.load(open(os.path.join(golden_dir, "host_logic.json")))
+    for c in fx["get_target"]:
+        np.random.seed(c["seed"])
+        t = hl.get_target(torch.tensor(c["labels"]), tuple(range(c["n_cls"])), whole=c["whole"], shuffle=c["shuffle"])
+        assert np.asarray(t).tolist() == c["target"], c
+        assert float(np.random.rand()) == c["next_rand"], c
+        if not c["whole"]:
+            assert all(c["labels"][i] not in row for i, row in enumerate(np.asarray(t).tolist()))
+    c = fx["get_target_tensor"]
+    np.random.seed(c["seed"])
+    t = hl.get_target(torch.tensor(c["labels"]), (0, 1, 2), to_tensor=True)
+    assert str(t.dtype) == c["dtype"] and t.tolist() == c["target"]
+
+
+def test_load_classifier_pth_round_trip_vs_reference(golden_dir, tmp_path, capsys):
+    """``load_classifier`` (util.py:236-266): an Encoder_classifier checkpoint written to a .pth and loaded into an Encoder
+    with strict=False.  Same printed key report as the reference, same tensors afterwards (classifier keys replaced, fcmean /
+    fcvar untouched), and the file this package writes has the reference's key names."""
+    import json
+    from oracle import params
+    from srgan_amd import losses as hl, model
+    fx = json.load(open(os.path.join(golden_dir, "host_logic.json")))["load_classifier"]
+    spec_e = params.encoder_spec(3, 8, 4, 4, 4)
+    spec_c = {k: v for k, v in spec_e.items() if not k.startswith(("fcmean", "fcvar"))}
+    clf = model.Encoder_classifier(3, 8, 4, 4, "instance", 4)
+    clf.load_state_dict(params.fill(spec_c, 40))
+    assert list(clf.state_dict().keys()) == fx["clf_keys"]
+    enc = model.Encoder(3, 8, 4, 4, "instance", 4, "cpu")
+    enc.load_state_dict(params.fill(spec_e, 41))
+    before = {k: v.clone() for k, v in enc.state_dict().items()}
+    path = str(tmp_path / "classifier.pth")
+    torch.save(clf.state_dict(), path)
+    ret = hl.load_classifier(enc, path, "cpu")
+    assert ret is enc
+    assert capsys.readouterr().out.strip() == fx["printed"]
+    sd = enc.state_dict()
+    for k, (s, n) in fx["checksums"].items():
+        assert abs(float(sd[k].double().sum()) - s) <= 1e-9 * max(abs(s), 1.0), k
+        assert abs(float(sd[k].double().norm()) - n) <= 1e-9 * max(n, 1.0), k
+    for k in fx["missing"]:
+        assert torch.equal(sd[k], before[k])
+    for k in fx["clf_keys"]:
+        assert torch.equal(sd[k], clf.state_dict()[k])
+    # freeze_melt on the loaded encoder: only fcmean / fcvar stay trainable (05-train cell 22)
+    enc.freeze_melt(fx["clf_keys"], "freeze")
+    assert sorted(k for k, p in enc.named_parameters() if p.requires_grad) == sorted(fx["missing"])
