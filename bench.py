@@ -356,10 +356,16 @@ def main():
 
     # step 0 (eager, un-warmed): checked against the CPU oracle's losses for the same seeds
     log(f"rank {rank}/{world}: inputs resident; first step (checked against the oracle fixture)")
+    if use_graph:
+        try:
+            sg.enable_graph()            # step 0 still runs eagerly (it creates optimiser state / packed operands); step 1 captures
+        except NotImplementedError as e:
+            if args.graph == "on":
+                raise SystemExit(f"--graph on: {e}")
+            log(f"hipGraph mode not available here, running eagerly: {e}")
+            use_graph = False
     first = [float(v) for v in sg.train(*batches[0])]
     check = first_step_check(first, args, world) if rank == 0 else None
-    if use_graph:
-        sg.enable_graph()
     log(f"warm-up x{args.warmup}" + (" (captures the hipGraph)" if use_graph else ""))
     for s in range(1, warm):
         sg.train(*batches[s])

@@ -207,6 +207,22 @@ int srgan_adam_step(float* p, const float* g, float* m, float* v, long long n, f
 int srgan_adam_multi(const void* table, int n_tensors, long long max_numel, float lr, float beta1, float beta2,
                      float eps, int step_count, void* stream);
 
+/* The optimiser as a hipGraph-capturable op (BASELINE configs[4] "hipGraph step"; the step captured is
+ * util_notebook.py:696-734): the step counter t and the hyper-parameters live in a 32-byte DEVICE record, so replaying a
+ * captured train step advances t like calling optimizer.step() would.  srgan_adam_multi_dev = t += 1, bias corrections of
+ * torch 1.4's Adam from the device-side t (in double), then the update of srgan_adam_multi -- two launches, no host value
+ * baked into the launch.  `steps_done` seeds t (0 for a fresh optimiser; the checkpoint's count when resuming);
+ * srgan_adam_state_set_lr follows lr_scheduler.ExponentialLR (util_notebook.py:501-507) between steps. */
+size_t srgan_adam_state_bytes(void);
+int srgan_adam_state_init(void* state, float lr, float beta1, float beta2, float eps, int steps_done, void* stream);
+int srgan_adam_state_set_lr(void* state, float lr, void* stream);
+int srgan_adam_multi_dev(const void* table, int n_tensors, long long max_numel, void* state, void* stream);
+
+/* Small host -> device upload (pointer tables: <= 1 MiB, multiple of 4 bytes) carried in kernel arguments: nothing to keep
+ * alive on the host after the call returns, and a captured hipGraph stores the bytes in its node instead of re-reading a host
+ * address at replay (no reference counterpart; plumbing of the multi-tensor ops above). */
+int srgan_upload_small(void* dst_dev, const void* src_host, size_t nbytes, void* stream);
+
 /* ---- compute mode.  0 (default): exact fp32 products on v_mfma_f32_32x32x2_f32 (BASELINE configs[0], [1]).
  * 1: bf16 MFMA compute for configs [2]-[4]: conv operands are rounded to bf16 (nearest even) on their way into LDS and
  * multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- torch.autocast(bfloat16) semantics for the convolutions;

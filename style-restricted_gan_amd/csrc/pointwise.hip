@@ -2,6 +2,7 @@
 // fused Adam.  NHWC fp32.  Reference call sites are listed in include/srgan_hip.h.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include "common.h"
 
 namespace srgan {
@@ -236,6 +237,75 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const unsigned long lon
   }
 }
 
+
+// ---- small host -> device uploads carried in the kernel ARGUMENTS -------------------------------------------------
+// Pointer tables (multi-tensor Adam, the central-biasing layer records, the weight-repack entries) are a few KB that the host
+// knows at launch time.  A pinned staging buffer + hipMemcpyAsync needs the staging block kept alive until the copy has run
+// and, captured into a hipGraph, would re-read that host address on every replay; a kernel whose by-value argument IS the
+// data has neither problem: the bytes travel in the launch packet (and are stored in the graph node).
+constexpr int kUploadChunk = 2048;
+struct UploadBlob { unsigned int w[kUploadChunk / 4]; };
+__global__ __launch_bounds__(256) void upload_small_kernel(unsigned int* __restrict__ dst, UploadBlob blob, int nwords) {
+  for (int i = threadIdx.x; i < nwords; i += 256) dst[i] = blob.w[i];
+}
+
+// ---- device-resident Adam state ---------------------------------------------------------------------------------------
+// {step, lr, beta1, beta2, eps, step_size, inv_sqrt_bc2}: the step counter lives on the device so that a captured train step
+// (hipGraph) advances it on every replay; the host mirrors the count for checkpoints only.
+struct AdamState { int step; float lr, beta1, beta2, eps, step_size, inv_sqrt_bc2; int pad; };
+static_assert(sizeof(AdamState) == 32, "AdamState layout");
+__global__ void adam_state_init_kernel(AdamState* s, int step, float lr, float beta1, float beta2, float eps) {
+  s->step = step; s->lr = lr; s->beta1 = beta1; s->beta2 = beta2; s->eps = eps; s->step_size = 0.f; s->inv_sqrt_bc2 = 0.f; s->pad = 0;
+}
+__global__ void adam_state_lr_kernel(AdamState* s, float lr) { s->lr = lr; }
+// torch 1.4: p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)   (bias corrections in double, as the host path did)
+__global__ void adam_tick_kernel(AdamState* s) {
+  const int t = s->step + 1;
+  s->step = t;
+  const double bc1 = 1.0 - pow((double)s->beta1, (double)t);
+  const double bc2 = 1.0 - pow((double)s->beta2, (double)t);
+  s->step_size = (float)((double)s->lr / bc1);
+  s->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+}
+__global__ __launch_bounds__(256) void adam_multi_dev_kernel(const unsigned long long* __restrict__ table,
+                                                             const AdamState* __restrict__ st) {
+  const float step_size = st->step_size, beta1 = st->beta1, beta2 = st->beta2, eps = st->eps, inv_sqrt_bc2 = st->inv_sqrt_bc2;
+  const unsigned long long* rec = table + (size_t)blockIdx.y * 5;
+  float* __restrict__ p = reinterpret_cast<float*>(rec[0]);
+  const float* __restrict__ g = reinterpret_cast<const float*>(rec[1]);
+  float* __restrict__ m = reinterpret_cast<float*>(rec[2]);
+  float* __restrict__ v = reinterpret_cast<float*>(rec[3]);
+  const long long n = (long long)rec[4];
+  const bool vec = ((rec[0] | rec[1] | rec[2] | rec[3]) & 15) == 0;
+  for (long long c0 = (long long)blockIdx.x * 4096; c0 < n; c0 += (long long)gridDim.x * 4096) {
+    if (vec && c0 + 4096 <= n) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long long i = c0 + (j * 256 + threadIdx.x) * 4;
+        const f32x4 gi = *reinterpret_cast<const f32x4*>(g + i);
+        const f32x4 mi = beta1 * *reinterpret_cast<const f32x4*>(m + i) + (1.f - beta1) * gi;
+        const f32x4 vi = beta2 * *reinterpret_cast<const f32x4*>(v + i) + (1.f - beta2) * gi * gi;
+        f32x4 pi = *reinterpret_cast<const f32x4*>(p + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pi[e] = pi[e] - step_size * (mi[e] / (sqrtf(vi[e]) * inv_sqrt_bc2 + eps));
+        *reinterpret_cast<f32x4*>(m + i) = mi;
+        *reinterpret_cast<f32x4*>(v + i) = vi;
+        *reinterpret_cast<f32x4*>(p + i) = pi;
+      }
+    } else {
+      const long long end = c0 + 4096 < n ? c0 + 4096 : n;
+      for (long long i = c0 + threadIdx.x; i < end; i += 256) {
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+      }
+    }
+  }
+}
+
 }  // namespace srgan
 
 using namespace srgan;
@@ -352,4 +422,43 @@ extern "C" int srgan_adam_multi(const void* table, int n_tensors, long long max_
   hipLaunchKernelGGL(adam_multi_kernel, dim3(bx, (unsigned)n_tensors), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const unsigned long long*>(table), step_size, beta1, beta2, eps, inv_sqrt_bc2);
   return check_launch("adam_multi_kernel");
+}
+
+extern "C" int srgan_upload_small(void* dst_dev, const void* src_host, size_t nbytes, void* stream) {
+  SRGAN_REQUIRE(dst_dev && src_host && nbytes % 4 == 0, "upload_small: bad argument (bytes must be a multiple of 4)");
+  SRGAN_REQUIRE(nbytes <= (1u << 20), "upload_small: meant for tables of a few KB (%zu bytes asked)", nbytes);
+  const unsigned char* src = static_cast<const unsigned char*>(src_host);
+  unsigned char* dst = static_cast<unsigned char*>(dst_dev);
+  for (size_t off = 0; off < nbytes; off += srgan::kUploadChunk) {
+    const size_t n = std::min<size_t>(srgan::kUploadChunk, nbytes - off);
+    srgan::UploadBlob blob;
+    std::memcpy(blob.w, src + off, n);
+    hipLaunchKernelGGL(srgan::upload_small_kernel, dim3(1), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<unsigned int*>(dst + off), blob, (int)(n / 4));
+  }
+  return check_launch("upload_small_kernel");
+}
+
+extern "C" size_t srgan_adam_state_bytes(void) { return sizeof(srgan::AdamState); }
+
+extern "C" int srgan_adam_state_init(void* state, float lr, float beta1, float beta2, float eps, int steps_done, void* stream) {
+  SRGAN_REQUIRE(state && steps_done >= 0, "adam_state_init: bad argument");
+  hipLaunchKernelGGL(srgan::adam_state_init_kernel, dim3(1), dim3(1), 0, as_stream(stream),
+                     static_cast<srgan::AdamState*>(state), steps_done, lr, beta1, beta2, eps);
+  return check_launch("adam_state_init_kernel");
+}
+
+extern "C" int srgan_adam_state_set_lr(void* state, float lr, void* stream) {
+  SRGAN_REQUIRE(state, "adam_state_set_lr: bad argument");
+  hipLaunchKernelGGL(srgan::adam_state_lr_kernel, dim3(1), dim3(1), 0, as_stream(stream), static_cast<srgan::AdamState*>(state), lr);
+  return check_launch("adam_state_lr_kernel");
+}
+
+extern "C" int srgan_adam_multi_dev(const void* table, int n_tensors, long long max_numel, void* state, void* stream) {
+  SRGAN_REQUIRE(table && state && n_tensors > 0 && max_numel > 0, "adam_multi_dev: bad argument");
+  hipLaunchKernelGGL(srgan::adam_tick_kernel, dim3(1), dim3(1), 0, as_stream(stream), static_cast<srgan::AdamState*>(state));
+  const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>(ceil_div(max_numel, 4096), 2048));
+  hipLaunchKernelGGL(srgan::adam_multi_dev_kernel, dim3(bx, (unsigned)n_tensors), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const unsigned long long*>(table), static_cast<const srgan::AdamState*>(state));
+  return check_launch("adam_multi_dev_kernel");
 }

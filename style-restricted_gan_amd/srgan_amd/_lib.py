@@ -88,6 +88,11 @@ SIGNATURES = {
     "srgan_prof_num_slots": (c_int, []),
     "srgan_prof_slot": (c_int, [c_int, POINTER(c_int), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "srgan_adam_step": (c_int, [P, P, P, P, c_longlong, c_float, c_float, c_float, c_float, c_int, P]),
+    "srgan_adam_state_bytes": (c_size_t, []),
+    "srgan_adam_state_init": (c_int, [P, c_float, c_float, c_float, c_float, c_int, P]),
+    "srgan_adam_state_set_lr": (c_int, [P, c_float, P]),
+    "srgan_adam_multi_dev": (c_int, [P, c_int, c_longlong, P, P]),
+    "srgan_upload_small": (c_int, [P, P, c_size_t, P]),
 }
 
 _lib = None

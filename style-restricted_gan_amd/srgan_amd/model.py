@@ -208,8 +208,7 @@ class SingleGenerator(nn.Module):
         self.up_norms = nn.ModuleList(norms)
 
     def forward(self, x, c):
-        # (not under hipGraph capture: the per-call table is staged through a transient pinned buffer a replay would re-read)
-        if c.is_cuda and not os.environ.get("SRGAN_NO_CBIN_MULTI") and not torch.cuda.is_current_stream_capturing():
+        if c.is_cuda and not os.environ.get("SRGAN_NO_CBIN_MULTI"):
             c = PrecomputedCon(c, list(self.down_cnorms) + [n for blk in self.resBlocks for n in (blk.cn1, blk.cn2)])
         for i in range(self.num_cls + 1):
             x = self.down_cnorms[i](self.down_convs[i](x), c, ACT_RELU)

@@ -56,6 +56,20 @@ def workspace(device, nbytes):
     return ws
 
 
+def upload_small(blob, device, out=None):
+    """bytes / bytearray (a pointer table of a few KB, multiple of 4 bytes) -> device uint8 tensor.  The bytes travel in the
+    arguments of a tiny kernel (C ABI ``srgan_upload_small``): no pinned staging buffer to keep alive, and inside a captured
+    hipGraph the node stores the bytes, so a replay rewrites the same table instead of re-reading a host address."""
+    n = len(blob)
+    if out is None:
+        out = torch.empty(n, dtype=torch.uint8, device=device)
+    elif out.numel() < n:
+        raise _lib.SrganHipError("upload_small: destination too small")
+    buf = (ctypes.c_char * n).from_buffer_copy(bytes(blob))
+    _lib.check(_lib.load().srgan_upload_small(_ptr(out), ctypes.byref(buf), n, _stream()), "upload_small")
+    return out
+
+
 def nhwc_empty(n, c, h, w, device):
     return torch.empty((n, h, w, c), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
 
@@ -140,13 +154,18 @@ class _Packed:
 
 
 class pack_cache:
-    """Context manager: cache packed conv weights (see above)."""
+    """Context manager: cache packed conv weights (see above).  ``refresh_on_entry=False``: the caller vouches that no
+    parameter was written behind the cache's back since the last scope (the captured train step does: it checks the
+    parameters' version counters itself before every replay)."""
+
+    def __init__(self, refresh_on_entry=True):
+        self._refresh = refresh_on_entry
 
     def __enter__(self):
         global _pack_cache_on
         self._prev = _pack_cache_on
         _pack_cache_on = True
-        if not self._prev and _pack_cache:
+        if self._refresh and not self._prev and _pack_cache:
             # entries persist between scopes; a ``.data`` update made outside (no version bump) would go unseen, so the
             # whole cache is re-packed on entry -- one multi-pack launch
             refresh_packed([h.weight for h in _pack_cache.values()])
@@ -249,10 +268,10 @@ def _packed(desc, weight, kind, act):
 _tables = {}              # frozenset of parameter ids -> (entries, device table, singles)
 
 
-def refresh_packed(params):
+def refresh_packed(params, force=False):
     """Re-pack every cached operand of ``params`` after their optimiser step: one multi-pack launch for the implicit-GEMM /
     Winograd operands (device table built once per parameter set), single launches for the few narrow-output layers."""
-    if not _pack_cache_on:
+    if not (_pack_cache_on or force):
         return
     params = list(params)
     if not params:
@@ -284,9 +303,7 @@ def refresh_packed(params):
                 _lib.check(rc, "conv2d_pack_entry")
         dev = None
         if multi:
-            host = torch.frombuffer(blob, dtype=torch.uint8).clone().pin_memory()
-            dev = host.to(params[0].device, non_blocking=True)
-            dev._srgan_host = host                 # keep the pinned source alive until the copy has run
+            dev = upload_small(blob, params[0].device)
         tab = (multi, dev, singles)
         _tables[tkey] = tab
     multi, dev, singles = tab
@@ -536,10 +553,8 @@ def cbin_affine(c, W, b, gamma, beta):
 
 
 def _cbin_table(records, device):
-    """Host records (ctypes buffers) -> one device array, through pinned staging (no host stall)."""
-    blob = b"".join(bytes(r) for r in records)
-    host = torch.frombuffer(bytearray(blob), dtype=torch.uint8).pin_memory()
-    return host.to(device, non_blocking=True)
+    """Host records (ctypes buffers) -> one device array (kernel-argument upload: capturable, nothing to keep alive)."""
+    return upload_small(b"".join(bytes(r) for r in records), device)
 
 
 class _CbinAffineMultiFn(Function):
@@ -981,6 +996,26 @@ def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
     _require_gpu(p, "adam")
     _lib.check(_lib.load().srgan_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
                                            float(beta2), float(eps), int(step), _stream()), "adam_step")
+
+
+def adam_state_new(device, lr, beta1, beta2, eps, steps_done):
+    """Device-resident Adam record {t, lr, betas, eps, derived step size} seeded with ``steps_done`` completed steps."""
+    lib = _lib.load()
+    st = torch.empty(lib.srgan_adam_state_bytes(), dtype=torch.uint8, device=device)
+    _lib.check(lib.srgan_adam_state_init(_ptr(st), float(lr), float(beta1), float(beta2), float(eps), int(steps_done), _stream()),
+               "adam_state_init")
+    return st
+
+
+def adam_state_set_lr(state, lr):
+    _lib.check(_lib.load().srgan_adam_state_set_lr(_ptr(state), float(lr), _stream()), "adam_state_set_lr")
+
+
+def adam_multi_dev_(table_dev, n_tensors, max_numel, state):
+    """t += 1 on the device, then one launch of torch-1.4 Adam over the tensors of the pointer table (hipGraph-capturable:
+    no host value is baked into the launches)."""
+    _lib.check(_lib.load().srgan_adam_multi_dev(_ptr(table_dev), int(n_tensors), int(max_numel), _ptr(state), _stream()),
+               "adam_multi_dev")
 
 
 def adam_multi_step_(table_dev, n_tensors, max_numel, lr, beta1, beta2, eps, step):

@@ -4,10 +4,29 @@
 Parameters are updated through raw device pointers: the autograd version counters are NOT bumped,
 which is what lets phase 2 of ``update_GandE`` back-propagate a graph recorded before the step
 (SURVEY.md Appendix C-1).  It is a ``torch.optim.Optimizer`` so ``ExponentialLR`` can drive ``lr``.
+
+The step counter and the hyper-parameters of a parameter cohort live in a small DEVICE record
+(``ops.adam_state_new``): ``step()`` launches "t += 1; derive the bias corrections; update" without
+baking t or lr into the launch, so a train step captured into a hipGraph advances the optimiser on every
+replay.  The host keeps ``state[p]["step"]`` in step for ``state_dict()`` / resume (``advance_host`` after a
+replay) and pushes ``lr`` changes made by a scheduler to the device record (``sync_device``).
 """
+import struct
+
 import torch
 
 from . import ops
+
+
+class _Cohort:
+    """Parameters of one group that share a step count: one pointer table, one device-side state record."""
+    __slots__ = ("state", "table", "steps", "lr", "n", "max_numel")
+
+    def __init__(self):
+        self.state = self.table = None
+        self.steps = -1            # completed steps the device record stands at
+        self.lr = None
+        self.n = self.max_numel = 0
 
 
 class Adam(torch.optim.Optimizer):
@@ -15,13 +34,36 @@ class Adam(torch.optim.Optimizer):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._cohorts = {}
+
+    def _cohort(self, gi, params, group, steps_done):
+        key = (gi,) + tuple(id(p) for p in params)
+        co = self._cohorts.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if co is None or co.steps != steps_done:
+            # first use, or the host-side count moved (load_state_dict / resume): (re)seed the device record
+            if capturing:
+                raise RuntimeError("srgan_amd.optim.Adam: an optimiser cohort first appears (or was re-seeded) inside a hipGraph "
+                                   "capture -- run one eager train step with the same parameter set first")
+            if co is None:
+                co = self._cohorts[key] = _Cohort()
+                co.table = torch.empty(40 * len(params), dtype=torch.uint8, device=params[0].device)
+            b1, b2 = group["betas"]
+            co.state = ops.adam_state_new(params[0].device, group["lr"], b1, b2, group["eps"], steps_done)
+            co.lr, co.steps = group["lr"], steps_done
+            co.n, co.max_numel = len(params), max(p.numel() for p in params)
+        if co.lr != group["lr"]:
+            if capturing:
+                raise RuntimeError("srgan_amd.optim.Adam: lr changed inside a hipGraph capture")
+            ops.adam_state_set_lr(co.state, group["lr"])
+            co.lr = group["lr"]
+        return co
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        for group in self.param_groups:
-            b1, b2 = group["betas"]
-            batches = {}                 # step count -> [(p, g, m, v)]: one multi-tensor launch per count
+        for gi, group in enumerate(self.param_groups):
+            batches = {}                 # completed step count -> [(p, g, m, v)]: one multi-tensor launch per count
             for p in group["params"]:
                 if p.grad is None:       # torch 1.4 skips parameters that received no gradient
                     continue
@@ -30,23 +72,41 @@ class Adam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p.data, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p.data, memory_format=torch.contiguous_format)
-                st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if not p.data.is_contiguous():
                     raise RuntimeError("srgan_amd.optim.Adam needs contiguous parameters")
-                batches.setdefault(st["step"], []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"]))
-            for step, items in batches.items():
-                if len(items) == 1:
-                    pd, g, m, v = items[0]
-                    ops.adam_step_(pd, g, m, v, group["lr"], b1, b2, group["eps"], step)
-                    continue
+                batches.setdefault(int(st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+                st["step"] += 1
+            for steps_done, items in batches.items():
+                params = [it[0] for it in items]
+                co = self._cohort(gi, params, group, steps_done)
                 rows = []
-                for pd, g, m, v in items:
-                    rows.extend((pd.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), pd.numel()))
-                host = torch.tensor(rows, dtype=torch.int64).pin_memory()
-                table = host.to(items[0][0].device, non_blocking=True)
-                ops.adam_multi_step_(table, len(items), max(pd.numel() for pd, _, _, _ in items), group["lr"], b1, b2,
-                                     group["eps"], step)
-                self._keep_alive = (host, table, items)     # until the next step: the launch reads them asynchronously
+                for p, g, m, v in items:
+                    rows.extend((p.data.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()))
+                # the gradient pointers change from step to step (and are the capture-time ones inside a graph): the table is
+                # rewritten by every step, in stream order, through kernel arguments
+                ops.upload_small(struct.pack(f"{len(rows)}q", *rows), params[0].device, out=co.table)
+                ops.adam_multi_dev_(co.table, co.n, co.max_numel, co.state)
+                co.steps = steps_done + 1
+                self._keep_alive = items                     # until the next step: the launch reads them asynchronously
             ops.mark_stale(group["params"])                  # parameters were written through raw pointers
         return loss
+
+    # -- hipGraph support --------------------------------------------------------------------------------------------
+    def sync_device(self):
+        """Push a scheduler's lr change to the device records (call between steps, outside any capture)."""
+        for key, co in self._cohorts.items():
+            lr = self.param_groups[key[0]]["lr"]
+            if co.lr != lr:
+                ops.adam_state_set_lr(co.state, lr)
+                co.lr = lr
+
+    def advance_host(self, n):
+        """A replayed graph ran ``n`` optimiser steps on the device: move the host-side counters with it."""
+        ids = {pid for key in self._cohorts for pid in key[1:]}
+        for group in self.param_groups:
+            for p in group["params"]:
+                if id(p) in ids and p in self.state and len(self.state[p]):
+                    self.state[p]["step"] += n
+        for co in self._cohorts.values():
+            co.steps += n
