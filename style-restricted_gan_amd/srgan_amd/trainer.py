@@ -559,6 +559,17 @@ class _StepGraph:
     def _capture(self):
         sg = self.sg
         lib_prof_off()
+        # Every autograd graph of the eager warm-up must be gone before recording: a parameter's AccumulateGrad node lives as
+        # long as any graph that points at it, and remembers the stream it was created on.  The step keeps its last graph
+        # alive on purpose (target_image is back-propagated twice), so the nodes of the eager step -- made on the caller's
+        # stream -- would be re-used by the recorded step and pull that stream into the capture as an unjoined fork.
+        sg.target_image = sg.recon_image = sg.c_rand = None
+        sg.loss_terms = {}
+        sg.__dict__.get("_label_cache", {}).clear()
+        for opt in (sg.optG, sg.optD, sg.optE):
+            opt._keep_alive = None
+        import gc
+        gc.collect()
         g = torch.cuda.CUDAGraph()
         sg._g_active = True
         self._noise_i, self._onehot = 0, {}
