@@ -135,3 +135,29 @@ elif stage.startswith("part_"):
                 out = sg.update_GandE()
                 return out[0]
     capture(body, warm=0)
+elif stage == "after":
+    from oracle import trainer as otrainer
+    from tests.common import build_hip_nets
+    from srgan_amd.trainer import SRGAN_training
+    G, D, E = build_hip_nets("T")
+    sg = SRGAN_training([G, D, E], [None, None, None], [nn.MSELoss(), nn.MSELoss()], dict(otrainer.DEFAULT_LBD), 2,
+                        "cuda", np.eye(4), 4, "mu", 8)
+    sg.opt_sche_initialization()
+    sg.enable_graph()
+    def run(b, seed):
+        x, label = otrainer.synthetic_batch(b, 128, 4, seed=seed)
+        out = sg.train(x.cuda(), {"source": label["source"].cuda(), "target": label["target"]})
+        torch.cuda.synchronize()
+        print(b, sg.graph_active, [float(v) for v in out], flush=True)
+    for s in range(3):
+        run(4, s)
+    mode = sys.argv[2] if len(sys.argv) > 2 else "small"
+    if mode == "small":
+        run(2, 10)
+    elif mode == "same_eager":
+        g = sg._graph; sg._graph = None
+        run(4, 10)
+        sg._graph = g
+    run(4, 11)
+    run(4, 12)
+    print("after ok")

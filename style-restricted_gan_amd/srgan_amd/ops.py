@@ -142,6 +142,26 @@ def _conv_ws(desc, device):
 # module calls) every call repacks.
 _pack_cache_on = False
 _pack_cache = {}          # (id(weight), kind, act_flag, geometry) -> _Packed
+_structure_epoch = 0      # bumped whenever a buffer a captured hipGraph may point at is dropped or re-allocated
+
+
+def structure_epoch():
+    return _structure_epoch
+
+
+def bump_structure_epoch():
+    global _structure_epoch
+    _structure_epoch += 1
+
+
+def graph_keepalive():
+    """Every persistent device buffer the conv / norm ops hand to kernels by pointer (packed operands, repack tables,
+    workspaces).  A captured train step holds these references for its lifetime: the caches may move on to new buffers
+    (a new geometry rebuilds a repack table), but memory a recorded launch points at is never handed to anyone else."""
+    keep = [h.buf for h in _pack_cache.values()]
+    keep += [t[1] for t in _tables.values() if t[1] is not None]
+    keep += list(_workspaces.values())
+    return keep
 
 
 class _Packed:
@@ -183,6 +203,7 @@ def set_compute_dtype(name):
     Process-wide; drops the packed-weight cache because the two modes use different kernels / layouts."""
     mode = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[str(name).replace("torch.", "")]
     _lib.check(_lib.load().srgan_set_compute_mode(mode), "set_compute_mode")
+    bump_structure_epoch()
     _pack_cache.clear()
     _geo_cache.clear()
     _tables.clear()
@@ -194,6 +215,7 @@ def get_compute_dtype():
 
 def invalidate_packed(params=None):
     """Forget cached operands (all, or those of ``params``): they are re-packed one by one at their next use."""
+    bump_structure_epoch()
     if params is None:
         _pack_cache.clear()
         _geo_cache.clear()
@@ -287,6 +309,7 @@ def refresh_packed(params, force=False):
             # dispatch gets a buffer of the size the current one wants before anything is packed into it
             want = lib.srgan_conv2d_packed_bytes(ctypes.byref(h.desc), h.kind, h.act)
             if want != h.buf.numel():
+                bump_structure_epoch()
                 h.buf = torch.empty(want, dtype=torch.uint8, device=h.buf.device)
                 h.scratch = lib.srgan_conv2d_packed_scratch(ctypes.byref(h.desc), h.kind)
         nb = lib.srgan_pack_entry_bytes()

@@ -45,6 +45,8 @@ class Adam(torch.optim.Optimizer):
             if capturing:
                 raise RuntimeError("srgan_amd.optim.Adam: an optimiser cohort first appears (or was re-seeded) inside a hipGraph "
                                    "capture -- run one eager train step with the same parameter set first")
+            if co is not None:
+                ops.bump_structure_epoch()       # a captured step points at the record being replaced
             if co is None:
                 co = self._cohorts[key] = _Cohort()
                 co.table = torch.empty(40 * len(params), dtype=torch.uint8, device=params[0].device)
@@ -100,6 +102,9 @@ class Adam(torch.optim.Optimizer):
             if co.lr != lr:
                 ops.adam_state_set_lr(co.state, lr)
                 co.lr = lr
+
+    def graph_keepalive(self):
+        return [t for co in self._cohorts.values() for t in (co.state, co.table)]
 
     def advance_host(self, n):
         """A replayed graph ran ``n`` optimiser steps on the device: move the host-side counters with it."""

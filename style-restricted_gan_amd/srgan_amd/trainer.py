@@ -484,6 +484,8 @@ class _StepGraph:
         self._noise_i = 0
         self._versions = None
         self.table = None
+        self._epoch = -1
+        self._keep = None
 
     def unsupported_reason(self):
         sg = self.sg
@@ -504,6 +506,10 @@ class _StepGraph:
         return (tuple(source_image.shape), dev(label["source"]), dev(label["target"]))
 
     def accepts(self, source_image, label):
+        if self.graph is not None and self._epoch != ops.structure_epoch():
+            # a buffer the recording points at was replaced (compute-mode switch, invalidate_packed, optimiser re-seeded):
+            # forget the graph; this step runs eagerly with the new buffers, the next one records again
+            self.graph, self.key, self._keep = None, None, None
         return self.key is not None and self._key(source_image, label) == self.key and source_image.is_cuda
 
     def note_eager_step(self, source_image, label):
@@ -585,6 +591,8 @@ class _StepGraph:
             raise RuntimeError(f"captured step consumed {self._noise_i} noise draws, staged {self.noise.shape[0]}")
         self.graph = g
         self.terms = dict(sg.loss_terms)
+        self._epoch = ops.structure_epoch()
+        self._keep = ops.graph_keepalive() + [t for opt in (sg.optG, sg.optD, sg.optE) for t in opt.graph_keepalive()]
 
     def run(self, source_image, label):
         sg = self.sg

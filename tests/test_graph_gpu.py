@@ -24,6 +24,7 @@ def _trainer(tier, batch, k, seed):
 
 
 def _steps(sg, batch, size, n, first_seed, hook=None):
+    torch.manual_seed(first_seed)      # the step's noise comes from the global CPU generator: same stream for both trainers
     out = []
     for s in range(n):
         if hook is not None:
