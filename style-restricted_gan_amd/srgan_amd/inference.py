@@ -8,7 +8,8 @@ import torch
 
 from .losses import class_encode
 
-__all__ = ["image_from_output", "dic_init", "get_samples", "GraphedForward"]
+__all__ = ["image_from_output", "dic_init", "get_samples", "GraphedForward", "cuda2numpy", "cuda2cpu", "get_output_tensors",
+           "get_output_and_plot"]
 
 
 def _numpy(x):
@@ -103,3 +104,67 @@ class GraphedForward:
             dst.copy_(src)
         self.graph.replay()
         return self.static_out
+
+
+def cuda2numpy(x):
+    """device (or host) tensor -> ndarray   (pyfiles/util.py:15-36)."""
+    return x.detach().to("cpu").numpy()
+
+
+def cuda2cpu(x):
+    """device tensor -> host tensor   (pyfiles/util.py:38-59)."""
+    return x.detach().to("cpu")
+
+
+@torch.no_grad()
+def get_output_tensors(sg, dataset, index, classes, random_sample_num=5, device="cuda"):
+    """The seven ``G_transformation`` calls of ``get_output_and_plot`` (pyfiles/util_notebook.py:764-799) in the reference's
+    order (the style noise comes from the CPU default generator, so the order fixes the result).  Returns host tensors:
+    source, target / recon / identity under the source's own style, one translation per other class, and
+    ``random_sample_num`` random-style targets, reconstructions and identities."""
+    from .losses import get_target
+    data = dataset[index]
+    src = data[0].view(1, 3, data[0].shape[-2], data[0].shape[-1]).to(device)
+    src_label = torch.tensor(data[1]).view(1,)
+    tgt_labels = torch.tensor(get_target(src_label, classes, whole=False, shuffle=False))
+    tgt = tgt_labels[:, 0:1]
+    n = random_sample_num
+    out = {"source": cuda2cpu(src), "target_labels": tgt_labels}
+    out["target"] = cuda2cpu(sg.G_transformation(tgt, src, True, src)[0])
+    out["target_random"] = cuda2cpu(sg.G_transformation(tgt.repeat(1, n), src.repeat(n, 1, 1, 1), False)[0])
+    first = out["target_random"][0:1].to(device)
+    out["recon"] = cuda2cpu(sg.G_transformation(src_label, first, True, src)[0])
+    out["identity"] = cuda2cpu(sg.G_transformation(src_label, src, True, src)[0])
+    out["translations"] = cuda2cpu(sg.G_transformation(tgt_labels, src.repeat(len(classes) - 1, 1, 1, 1), False)[0])
+    out["recon_random"] = cuda2cpu(sg.G_transformation(src_label.repeat(n), first.repeat(n, 1, 1, 1), False)[0])
+    out["identity_random"] = cuda2cpu(sg.G_transformation(src_label.repeat(n), src.repeat(n, 1, 1, 1), False)[0])
+    return out
+
+
+def get_output_and_plot(sg, dataset, index, class_info, random_sample_num=5, device="cuda"):
+    """Sample sheet of the train notebooks (pyfiles/util_notebook.py:738-846; called every third of an epoch by 05-train
+    cell 24): same arguments, same figure layout (4 columns, ``random_sample_num + 1`` rows, same titles), returns the
+    matplotlib figure.  The images come from the HIP modules through ``sg.G_transformation``."""
+    import matplotlib.pyplot as plt
+    classes, label_discription = class_info
+    t = get_output_tensors(sg, dataset, index, classes, random_sample_num, device)
+    n = random_sample_num
+    length, width = n + 1, 4
+    fig = plt.figure(figsize=(5 * width, 5 * length))
+
+    def panel(slot, tensor, title):
+        ax = fig.add_subplot(length, width, slot)
+        ax.imshow(image_from_output(tensor)[0])
+        ax.set_title(title)
+
+    panel(1, t["source"], "source")
+    panel(2, t["target"], "target by source condition")
+    panel(3, t["recon"], "recon by source condition")
+    panel(4, t["identity"], "identity image by source condition")
+    for i in range(len(classes) - 1):
+        panel(4 * (i + 1) + 1, t["translations"][i:i + 1], label_discription[t["target_labels"][0][i]])
+    for col, key, title in ((2, "target_random", "target by random latent"), (3, "recon_random", "recon by random latent"),
+                            (4, "identity_random", "idt by random latent")):
+        for i in range(n):
+            panel(4 * (i + 1) + col, t[key][i:i + 1], title)
+    return fig

@@ -318,6 +318,32 @@ def golden_inference():
     np.savez_compressed(os.path.join(HERE, "inference_T.npz"), **out)
 
 
+def golden_plot():
+    """get_output_and_plot (pyfiles/util_notebook.py:738-846), the sample sheet the train notebooks draw every third of an
+    epoch (05-train cell 24): the seven G_transformation calls in their order (CPU-generator noise), then a matplotlib
+    figure.  Stored: every panel's title and 8-bit image, read back from the figure the reference returns."""
+    G, D, E = build_nets("T")
+    sg = ref_nb.SRGAN_training([G, D, E], [LegacyAdam(G.parameters()), LegacyAdam(D.parameters()), LegacyAdam(E.parameters())],
+                               [nn.MSELoss(), nn.MSELoss()], dict(LBD), 1, "cpu", np.eye(4), 4, "mu", 8)
+    torch.manual_seed(3)
+    dataset = [(torch.rand(3, 128, 128) * 2 - 1, int(i % 4)) for i in range(3)]
+    names = ["male, smiling", "male, not smiling", "female, smiling", "female, not smiling"]     # 05-train cell 7
+    torch.manual_seed(5)
+    with torch.no_grad():
+        fig = ref_nb.get_output_and_plot(sg, dataset, 1, [(0, 1, 2, 3), names], 3, "cpu")
+    titles, panels, slots = [], [], []
+    for ax in fig.axes:
+        titles.append(ax.get_title())
+        panels.append(np.asarray(ax.images[0].get_array()))
+        g = ax.get_subplotspec().get_geometry()
+        slots.append([g[0], g[1], g[2]])
+    # every 4th pixel of every panel (random-noise images do not compress: 1.3 MB in full)
+    np.savez_compressed(os.path.join(HERE, "plot_T.npz"), titles=np.array(titles), panels=np.stack(panels).astype(np.uint8)[:, ::4, ::4],
+                        slots=np.array(slots), figsize=np.array(fig.get_size_inches()),
+                        image_checksum=np.array([float(d[0].double().sum()) for d in dataset]),      # the test re-draws them (seed 3)
+                        labels=np.array([d[1] for d in dataset]))
+
+
 def golden_facedataset():
     """File selection / split / label logic of FaceDataset (pyfiles/dataset.py:58-124) on a synthetic label set.
     The reference class still uses ``np.int`` (removed from numpy): the alias is restored for the import only."""
@@ -365,6 +391,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "inference":
         golden_inference()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "plot":
+        golden_plot()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "train256":
         golden_train_256()
         sys.exit(0)
@@ -376,4 +405,5 @@ if __name__ == "__main__":
     golden_pretrain()
     golden_facedataset()
     golden_inference()
+    golden_plot()
     print("golden fixtures written to", HERE)

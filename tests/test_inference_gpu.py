@@ -67,3 +67,31 @@ def test_graphed_forward_replays_the_generator(gold):
     y2, _ = g(x2, code)
     torch.cuda.synchronize()
     close(y2, y2_ref, 1e-6, what="graphed G, new input")
+
+
+def test_get_output_and_plot_vs_reference(golden_dir):
+    """The sample sheet of the train loop (util_notebook.py:738-846; 05-train cell 24 calls it every third of an epoch) against
+    the figure the reference itself draws for the same tier-T networks, seed and dataset: same panels in the same slots with the
+    same titles, 8-bit images within +-1."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import torch.nn as nn
+    from oracle import trainer as otrainer
+    from srgan_amd.inference import get_output_and_plot
+    from srgan_amd.trainer import SRGAN_training
+    gold = np.load(os.path.join(golden_dir, "plot_T.npz"))
+    G, D, E = build_hip_nets("T")
+    sg = SRGAN_training([G, D, E], [None, None, None], [nn.MSELoss(), nn.MSELoss()], dict(otrainer.DEFAULT_LBD), 1, "cuda",
+                        np.eye(4), 4, "mu", 8)
+    torch.manual_seed(3)
+    dataset = [(torch.rand(3, 128, 128) * 2 - 1, int(i % 4)) for i in range(3)]
+    np.testing.assert_allclose([float(d[0].double().sum()) for d in dataset], gold["image_checksum"], rtol=1e-12)
+    names = ["male, smiling", "male, not smiling", "female, smiling", "female, not smiling"]
+    torch.manual_seed(5)
+    fig = get_output_and_plot(sg, dataset, 1, [(0, 1, 2, 3), names], 3, "cuda")
+    assert list(fig.get_size_inches()) == list(gold["figsize"])
+    assert [ax.get_title() for ax in fig.axes] == [str(t) for t in gold["titles"]]
+    slots = [list(ax.get_subplotspec().get_geometry()[:3]) for ax in fig.axes]
+    assert slots == gold["slots"].tolist()
+    got = np.stack([np.asarray(ax.images[0].get_array()) for ax in fig.axes]).astype(np.int32)[:, ::4, ::4]
+    assert np.abs(got - gold["panels"].astype(np.int32)).max() <= 1
