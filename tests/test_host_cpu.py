@@ -201,3 +201,23 @@ def test_load_classifier_pth_round_trip_vs_reference(golden_dir, tmp_path, capsy
     # freeze_melt on the loaded encoder: only fcmean / fcvar stay trainable (05-train cell 22)
     enc.freeze_melt(fx["clf_keys"], "freeze")
     assert sorted(k for k, p in enc.named_parameters() if p.requires_grad) == sorted(fx["missing"])
+
+
+def test_notebook_cell_1_imports_resolve_through_the_compat_shims():
+    """05-train cell 1 (notebook lines 29-34): ``sys.path.append("../pyfiles/")`` then four ``from <module> import ...``
+    lines.  With the path entry pointed at srgan_amd/compat the same lines import the MI355X implementations."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "style-restricted_gan_amd")
+    code = "\n".join([
+        "import sys", f"sys.path.insert(0, {pkg!r})", f"sys.path.append({os.path.join(pkg, 'srgan_amd', 'compat')!r})",
+        "from util import image_from_output, get_target, cuda2numpy, cuda2cpu, weights_init, load_classifier",
+        "from dataset import get_class_label, FaceDataset",
+        "from model import MinMax, SingleGenerator, SingleDiscriminator_solo_multi, Encoder, Encoder_classifier",
+        "from util_notebook import SRGAN_training, get_output_and_plot",
+        "import srgan_amd.trainer, srgan_amd.model",
+        "assert SRGAN_training is srgan_amd.trainer.SRGAN_training and Encoder is srgan_amd.model.Encoder",
+        "import torch", "t = torch.arange(4.0)", "assert cuda2numpy(t).tolist() == [0, 1, 2, 3] and cuda2cpu(t).device.type == 'cpu'"])
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
