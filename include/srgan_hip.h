@@ -243,6 +243,22 @@ int srgan_preprocess_u8(const unsigned char* src, int B, int Hs, int Ws, int top
                         const int* v_bounds, const int* v_coeffs, int v_ksize, const unsigned char* flip,
                         int minmax, int mean0, float* dst, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- evaluation path (pyfiles/evaluation.py:13-110) ------------------------------------------------
+ * The VGG19-bn feature extractor (evaluation.py:13-36: torchvision's vgg19_bn features + avgpool + classifier[:6]) runs its
+ * 3x3 convolutions (BatchNorm folded in eval mode, bias + ReLU in the epilogue) and Linear layers on srgan_conv2d_fwd; the
+ * one op it needs beyond the train step is nn.MaxPool2d(2, 2): */
+int srgan_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* PRDC (evaluation.py:98-110 -> prdc.compute_prdc, prdc==0.2, Docker/requirements.txt:13), in the steps of that package:
+ * compute_pairwise_distance: dist[i][j] = ||x_i - y_j||_2 for x[N][D], y[M][D] (row-major fp32);
+ * get_kth_value: the k-th smallest entry of every row (1-based, k <= 16) -- with k = nearest_k + 1 on the self-distance
+ *   matrix this is compute_nearest_neighbour_distances (the radii);
+ * compute_prdc: out4 = {precision, recall, density, coverage} from dist[real][fake] and the two radius vectors. */
+int srgan_pairwise_dist(const float* x, int N, const float* y, int M, int D, float* dist, void* stream);
+int srgan_kth_smallest_rows(const float* dist, int N, int M, int k, float* out, void* stream);
+size_t srgan_prdc_workspace(int N, int M);
+int srgan_prdc_from_dist(const float* dist, int N, int M, const float* r_real, const float* r_fake, int nearest_k,
+                         float* out4, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- launch timer for bench.py's roofline leg (no reference counterpart) ---------------------
  * While enabled every implicit-GEMM / weight-gradient launch is bracketed by HIP events on its own
  * stream and tagged with its algorithmic FLOPs (2*N*Ho*Wo*O*kh*kw*I).  Collect after a device sync. */

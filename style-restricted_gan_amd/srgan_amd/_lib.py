@@ -93,6 +93,11 @@ SIGNATURES = {
     "srgan_adam_state_set_lr": (c_int, [P, c_float, P]),
     "srgan_adam_multi_dev": (c_int, [P, c_int, c_longlong, P, P]),
     "srgan_upload_small": (c_int, [P, P, c_size_t, P]),
+    "srgan_maxpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srgan_pairwise_dist": (c_int, [P, c_int, P, c_int, c_int, P, P]),
+    "srgan_kth_smallest_rows": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "srgan_prdc_workspace": (c_size_t, [c_int, c_int]),
+    "srgan_prdc_from_dist": (c_int, [P, c_int, c_int, P, P, c_int, P, P, c_size_t, P]),
 }
 
 _lib = None
