@@ -40,12 +40,14 @@ __global__ __launch_bounds__(256) void pairwise_dist_kernel(const float* __restr
   const bool xv = i0 + lr < N, yv = j0 + lr < M;
   const float* xp = x + (size_t)(xv ? i0 + lr : 0) * D + lk;
   const float* yp = y + (size_t)(yv ? j0 + lr : 0) * D + lk;
-  float acc[4][4];
+  // sum over the feature axis: 16 terms per chunk in a fresh register, the chunk sums added with Kahan compensation -- the
+  // package computes its distances in float64 and rounds once; a plain fp32 running sum over 4096 terms is ~2e-6 off, this
+  // stays within ~2 ulp, so that "d < radius" decisions agree except on genuine fp32 ties
+  float acc[4][4], comp[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-  const bool vec = (D & 3) == 0;
+    for (int b = 0; b < 4; ++b) { acc[a][b] = 0.f; comp[a][b] = 0.f; }
   for (int k0 = 0; k0 < D; k0 += PD_K) {
     float xa[4], ya[4];
 #pragma unroll
@@ -54,11 +56,15 @@ __global__ __launch_bounds__(256) void pairwise_dist_kernel(const float* __restr
       xa[e] = (xv && kv) ? xp[k0 + e] : 0.f;
       ya[e] = (yv && kv) ? yp[k0 + e] : 0.f;
     }
-    (void)vec;
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 4; ++e) { xs[lk + e][lr] = xa[e]; ys[lk + e][lr] = ya[e]; }
     __syncthreads();
+    float part[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part[p][q] = 0.f;
 #pragma unroll
     for (int k = 0; k < PD_K; ++k) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(&xs[k][ty * 4]);
@@ -66,8 +72,17 @@ __global__ __launch_bounds__(256) void pairwise_dist_kernel(const float* __restr
 #pragma unroll
       for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const float d = a[p] - b[q]; acc[p][q] = fmaf(d, d, acc[p][q]); }
+        for (int q = 0; q < 4; ++q) { const float d = a[p] - b[q]; part[p][q] = fmaf(d, d, part[p][q]); }
     }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float yk = part[p][q] - comp[p][q];
+        const float t = acc[p][q] + yk;
+        comp[p][q] = (t - acc[p][q]) - yk;
+        acc[p][q] = t;
+      }
   }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {

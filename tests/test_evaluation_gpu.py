@@ -54,7 +54,7 @@ def test_prdc_kernels_vs_oracle(n, m, d, k):
     dist = torch.empty(n, m, device="cuda")
     _lib.check(lib.srgan_pairwise_dist(ops._ptr(x), n, ops._ptr(y), m, d, ops._ptr(dist), ops._stream()), "pairwise_dist")
     want = oe.pairwise_distance(real, fake)
-    assert np.abs(dist.cpu().numpy() - want).max() <= 2e-6 * want.max()
+    assert np.abs(dist.cpu().numpy() - want).max() <= 5e-7 * want.max()        # chunked + compensated fp32 sum vs float64
     self_d = torch.empty(n, n, device="cuda")
     _lib.check(lib.srgan_pairwise_dist(ops._ptr(x), n, ops._ptr(x), n, d, ops._ptr(self_d), ops._stream()), "pairwise_dist")
     assert float(self_d.diagonal().abs().max()) == 0.0                     # exact zeros: (x - x)^2
