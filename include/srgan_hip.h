@@ -74,6 +74,12 @@ int srgan_conv2d_fwd_packed(const srgan_conv_desc* d, const float* x, const void
                             int act, float slope, void* ws, size_t ws_bytes, void* stream);
 int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* dy, const void* packed, float* dx,
                               void* ws, size_t ws_bytes, void* stream);
+/* dx = (input gradient of the convolution) + res: SingleResidualBlock (model.py:196-201) feeds its input to its first
+ * convolution AND to the skip connection, so the gradient of the block input is the sum of the two paths; handing the skip
+ * path's gradient to the convolution's input-gradient kernel (added in the F(4x4,3x3) epilogue; one in-place pass on the other
+ * dispatches) replaces autograd's separate accumulation pass over the tensor.  res: dense, shape of dx, must not alias dx. */
+int srgan_conv2d_dgrad_packed_add(const srgan_conv_desc* d, const float* dy, const void* packed, const float* res, float* dx,
+                                  void* ws, size_t ws_bytes, void* stream);
 
 /* Many packs in one launch (after an optimiser step every cached operand of the network is stale at once):
  * srgan_conv2d_pack_entry writes one host record (srgan_pack_entry_bytes() bytes) per operand -- it returns 1 for the few
@@ -128,7 +134,8 @@ int srgan_cbin_affine_bwd(const float* c, const float* W, const float* gamma, co
  * The caller fills one host record per layer (srgan_cbin_rec_bytes() bytes each; pointers a pass does not use may be NULL),
  * copies the array to the device and passes it as `table_dev`; outputs of a layer are dense [N][C] blocks.
  * Backward: dscale / dshift must be non-NULL (zeros for absent gradients), `da` is [N][C] scratch per layer, `gamma` is the
- * forward-time copy (row 0 of the saved scale); dc[N][num_con] sums the layers in table order. */
+ * forward-time copy (row 0 of the saved scale); dc[N][num_con] sums the layers in table order (dc may be NULL: the style
+ * code's gradient is only wanted when the code came from the encoder, not for the noise codes of most generator passes). */
 size_t srgan_cbin_rec_bytes(void);
 int srgan_cbin_rec_fill(void* rec, const float* W, const float* b, const float* gamma, const float* beta, float* t,
                         float* scale, float* shift, const float* dscale, const float* dshift, float* dgamma,

@@ -94,6 +94,7 @@ struct WinoParams {
   int cpp;            // mode 1: chunks per input phase (C / 8)
   int act;            // fused activation of the epilogue (SRGAN_ACT_*)
   float slope;
+  const float* res;   // F(4x4,3x3) only: tensor of the destination's shape added in the epilogue (residual gradient), or null
 };
 
 // conv_wino43.hip: F(4x4,3x3) kernel behind wino_run
@@ -108,7 +109,7 @@ bool wino_applicable(const srgan_conv_desc* d, int kind);
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind);
 int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hipStream_t st);
 size_t wino_scratch_bytes(const srgan_conv_desc* d, int kind);
-int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst, int act, float slope, float* scratch, hipStream_t st);
+int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst, int act, float slope, float* scratch, hipStream_t st, const float* res = nullptr, bool* res_done = nullptr);
 bool wino_wgrad_applicable(const srgan_conv_desc* d);
 void wino_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad);
 int wino_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, hipStream_t st);

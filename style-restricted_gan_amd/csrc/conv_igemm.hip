@@ -1406,7 +1406,33 @@ static int dgrad_pack(const srgan_conv_desc* d, const float* w, float* dst, hipS
 }
 
 // `scratch`: room for the padded gradient when the conv is reflect-padded
-static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp, float* dx, float* scratch, hipStream_t st) {
+__global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ r, long long n4, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    reinterpret_cast<f32x4*>(y)[i] += reinterpret_cast<const f32x4*>(r)[i];
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] += r[n4 * 4 + threadIdx.x];
+}
+
+static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp, float* dx, float* scratch, hipStream_t st,
+                     const float* res = nullptr);
+static int dgrad_run_core(const srgan_conv_desc* d, const float* dy, const float* wp, float* dx, float* scratch, hipStream_t st,
+                          const float* res, bool* res_done);
+
+// dx = dgrad(dy) (+ res): the F(4x4,3x3) kernel adds `res` in its epilogue; every other dispatch gets one in-place add pass
+static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp, float* dx, float* scratch, hipStream_t st,
+                     const float* res) {
+  bool done = false;
+  if (int e = dgrad_run_core(d, dy, wp, dx, scratch, st, res, &done)) return e;
+  if (res && !done) {
+    const long long n = (long long)d->N * d->Hi * d->Wi * d->I, n4 = n / 4;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(ceil_div(n4, 256), 8192))),
+                       dim3(256), 0, st, dx, res, n4, n);
+    return check_launch("add_inplace_kernel");
+  }
+  return 0;
+}
+
+static int dgrad_run_core(const srgan_conv_desc* d, const float* dy, const float* wp, float* dx, float* scratch, hipStream_t st,
+                          const float* res, bool* res_done) {
   DgradGeom g = dgrad_geometry(d);
   g.p.src = dy; g.p.wp = wp;
   g.p.dst = g.reflect ? scratch : dx;
@@ -1425,7 +1451,8 @@ static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp,
   }
   if (g.wino) {
     // (F(4,3) needs zero padding, the fold scratch needs reflect padding: the two uses of `scratch` never meet)
-    if (int e = wino_run(d, 1, dy, wp, nullptr, g.p.dst, SRGAN_ACT_NONE, 0.f, g.reflect ? nullptr : scratch, st)) return e;
+    if (int e = wino_run(d, 1, dy, wp, nullptr, g.p.dst, SRGAN_ACT_NONE, 0.f, g.reflect ? nullptr : scratch, st,
+                         g.reflect ? nullptr : res, res_done)) return e;
   } else if (int e = run_igemm(g.p, g.phases, st, conv_flops(d))) {
     return e;
   }
@@ -1548,6 +1575,16 @@ extern "C" int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* 
   const size_t need = srgan_conv2d_packed_scratch(d, 1);
   SRGAN_REQUIRE(need == 0 || (ws && ws_bytes >= need), "conv2d_dgrad_packed: workspace too small (srgan_conv2d_packed_scratch)");
   return dgrad_run(d, dy, (const float*)packed, dx, (float*)ws, as_stream(stream));
+}
+
+extern "C" int srgan_conv2d_dgrad_packed_add(const srgan_conv_desc* d, const float* dy, const void* packed, const float* res,
+                                             float* dx, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(dy && packed && dx && res, "conv2d_dgrad_packed_add: null pointer");
+  SRGAN_REQUIRE(res != dx, "conv2d_dgrad_packed_add: res must not alias dx");
+  const size_t need = srgan_conv2d_packed_scratch(d, 1);
+  SRGAN_REQUIRE(need == 0 || (ws && ws_bytes >= need), "conv2d_dgrad_packed_add: workspace too small (srgan_conv2d_packed_scratch)");
+  return dgrad_run(d, dy, (const float*)packed, dx, (float*)ws, as_stream(stream), res);
 }
 
 namespace srgan {

@@ -839,8 +839,11 @@ int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hi
 
 // dst geometry: kind 0 -> [N][Ho][Wo][O]; kind 1 -> [N][Hd][Wd][I] with Hd = Hi (zero pad) or Hi + 2 (reflect scratch)
 // `scratch`: wino_scratch_bytes(d, kind) bytes (may be null when that is 0)
+// `res` (optional): added to the result in the epilogue where the kernel supports it (F(4x4,3x3)); *res_done tells the caller
+// whether it was, so that it can add the tensor itself otherwise
 int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst,
-             int act, float slope, float* scratch, hipStream_t st) {
+             int act, float slope, float* scratch, hipStream_t st, const float* res, bool* res_done) {
+  if (res_done) *res_done = false;
   WinoParams p{};
   p.act = act; p.slope = slope;
   int C, N, phases;
@@ -880,6 +883,8 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
     SRGAN_REQUIRE(p.pad == 1 && p.Ho == p.H && p.Wo == p.W && p.nchunk >= 2 && p.Cd % 32 == 0 && p.C % 32 == 0,
                   "winograd F(4,3): geometry");
     SRGAN_REQUIRE(scratch, "winograd F(4,3): no scratch for the transformed input");
+    p.res = res;
+    if (res_done) *res_done = res != nullptr;
     wino43_launch(p, scratch, grid, conv_flops_of(d), st);
     return check_launch("wino43_kernel");
   }

@@ -291,12 +291,28 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
       const int eo = tile_o[16 * q + et];
       if (eo >= 0) {
         float* dp = p.dst + (size_t)eo * p.Cd + n;
+        if (p.res) {
+          // input gradient of a residual block's first convolution: the gradient of the skip path rides in here instead of
+          // a separate add pass over the tensor (same whole-line access pattern as the stores)
+          const float* rp = p.res + (size_t)eo * p.Cd + n;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          float y[4];
-          at6(hh[a][0], hh[a][1], hh[a][2], hh[a][3], hh[a][4], hh[a][5], y);
+          for (int a = 0; a < 4; ++a) {
+            float y[4];
+            at6(hh[a][0], hh[a][1], hh[a][2], hh[a][3], hh[a][4], hh[a][5], y);
 #pragma unroll
-          for (int b = 0; b < 4; ++b) dp[(size_t)(a * p.Wo + b) * p.Cd] = apply_act(y[b] + bv, p.act, p.slope);
+            for (int b = 0; b < 4; ++b) {
+              const size_t o = (size_t)(a * p.Wo + b) * p.Cd;
+              dp[o] = apply_act(y[b] + bv, p.act, p.slope) + rp[o];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            float y[4];
+            at6(hh[a][0], hh[a][1], hh[a][2], hh[a][3], hh[a][4], hh[a][5], y);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) dp[(size_t)(a * p.Wo + b) * p.Cd] = apply_act(y[b] + bv, p.act, p.slope);
+          }
         }
       }
     }

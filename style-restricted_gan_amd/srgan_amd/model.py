@@ -175,8 +175,11 @@ class SingleResidualBlock(nn.Module):
 
     def forward(self, x):
         data, con = x[0], x[1]
-        h = self.cn1(self.c1(data), con, ACT_RELU)
-        return self.cn2(self.c2(h), con, ACT_NONE, 0.0, data), con
+        # the block input feeds c1 and the skip connection: conv2d_skip routes the skip path's gradient into c1's
+        # input-gradient kernel (added in its epilogue) instead of a separate accumulation pass
+        y1, skip = ops.conv2d_skip(data, self.c1.weight, None, self.c1.stride[0], self.c1.padding[0], PAD_ZERO)
+        h = self.cn1(y1, con, ACT_RELU)
+        return self.cn2(self.c2(h), con, ACT_NONE, 0.0, skip), con
 
 
 class SingleGenerator(nn.Module):

@@ -357,17 +357,25 @@ def _run_conv_fwd(desc, x, weight, bias, y, act, slope, keep_v=None):
                                     float(slope), _ptr(ws), nb, _stream()), "conv2d_fwd")
 
 
-def _run_conv_dgrad(desc, dy, weight, dx):
+def _run_conv_dgrad(desc, dy, weight, dx, res=None):
+    """dx = input gradient (+ res: the gradient of a skip connection that shares the conv's input, added in the kernel's
+    epilogue where the dispatch supports it)."""
     lib = _lib.load()
     if _pack_cache_on:
         hit, scratch = _packed(desc, weight, 1, ACT_NONE)
         ws = workspace(dy.device, scratch) if scratch else None
+        if res is not None:
+            _lib.check(lib.srgan_conv2d_dgrad_packed_add(ctypes.byref(desc), _ptr(dy), _ptr(hit.buf), _ptr(res), _ptr(dx), _ptr(ws),
+                                                         scratch, _stream()), "conv2d_dgrad_packed_add")
+            return
         _lib.check(lib.srgan_conv2d_dgrad_packed(ctypes.byref(desc), _ptr(dy), _ptr(hit.buf), _ptr(dx), _ptr(ws), scratch,
                                                  _stream()), "conv2d_dgrad_packed")
         return
     ws, nb = _conv_ws(desc, dy.device)
     _lib.check(lib.srgan_conv2d_dgrad(ctypes.byref(desc), _ptr(dy), _ptr(weight), _ptr(dx), _ptr(ws), nb,
                                       _stream()), "conv2d_dgrad")
+    if res is not None:
+        _lib.check(lib.srgan_add(_ptr(dx), _ptr(res), _ptr(dx), dx.numel(), _stream()), "add")
 
 
 def _run_conv_wgrad(desc, x, dy, dw, dbias, v_image=None):
@@ -387,8 +395,12 @@ def _act_bwd(y, gy, act, slope):
 
 
 class _Conv2dFn(Function):
+    """``skip=True``: also returns the input itself as a second output -- the tensor a residual connection should use.  Its
+    gradient then arrives in THIS backward next to the conv output's, and the input-gradient kernel adds it in its epilogue
+    (``srgan_conv2d_dgrad_packed_add``) instead of autograd accumulating the two paths with a separate pass."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, pad_mode, act, slope):
+    def forward(ctx, x, weight, bias, stride, pad, pad_mode, act, slope, skip=False):
         x = to_nhwc(x)
         _require_gpu(weight, "conv2d weight")
         n, i, hi, wi = x.shape
@@ -411,19 +423,26 @@ class _Conv2dFn(Function):
         ctx.weight = weight            # by reference: read at backward time (torch 1.4 semantics)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
+        if skip:
+            return y, x
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x, y = ctx.saved_tensors
+        weight = ctx.weight
+        dx = dw = db = None
+        if gy is None:                     # only the skip path was used downstream
+            return (to_nhwc(gskip) if gskip is not None else None), None, None, None, None, None, None, None, None
         gy = to_nhwc(gy)
         if ctx.act != ACT_NONE:
             gy = _act_bwd(y, gy, ctx.act, ctx.slope)
-        weight = ctx.weight
-        dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _run_conv_dgrad(ctx.desc, gy, weight, dx)
+            res = to_nhwc(gskip) if gskip is not None else None
+            if res is not None and res.data_ptr() == dx.data_ptr():
+                res = res.clone()
+            _run_conv_dgrad(ctx.desc, gy, weight, dx, res)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
             desc = ConvDesc.from_buffer_copy(ctx.desc)
@@ -431,11 +450,16 @@ class _Conv2dFn(Function):
             if ctx.has_bias:
                 db = torch.empty(weight.shape[0], dtype=torch.float32, device=weight.device)
             _run_conv_wgrad(desc, x, gy, dw, db, ctx.v_image)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0):
     return _Conv2dFn.apply(x, weight, bias, stride, padding, pad_mode, act, slope)
+
+
+def conv2d_skip(x, weight, bias=None, stride=1, padding=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0):
+    """-> (conv2d(x, ...), x): use the second result for a skip connection around the convolution (see _Conv2dFn)."""
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, pad_mode, act, slope, True)
 
 
 class _ConvTranspose2dFn(Function):
@@ -648,7 +672,7 @@ class _CbinAffineMultiFn(Function):
             recs.append((rec, dscale, dshift))
             res += [dW, db, dgamma, dbeta]
         table = _cbin_table([r[0] for r in recs], dev)
-        dc = torch.empty(n, nc, dtype=torch.float32, device=dev)
+        dc = torch.empty(n, nc, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         _lib.check(lib.srgan_cbin_affine_multi_bwd(_ptr(c), _ptr(table), L, n, max(ctx.chs), nc, _ptr(dc), _stream()),
                    "cbin_affine_multi_bwd")
         return (dc, *res)

@@ -142,6 +142,38 @@ def test_conv2d_f43_weight_gradient_from_kept_image(ops, case, dispatch):
         close(bd.grad, b.grad, 5e-5)
 
 
+@pytest.mark.parametrize("case", [(32, 64, 32, 32, 64), (3, 64, 8, 12, 64), (2, 16, 9, 7, 16), (2, 256, 32, 32, 256)])
+@pytest.mark.parametrize("packed", [True, False])
+def test_conv2d_skip_gradient_rides_in_the_dgrad_epilogue(ops, case, packed, dispatch):
+    """conv2d_skip returns (conv(x), x); the gradient of the second result (the residual connection of SingleResidualBlock,
+    model.py:196-201) is added by the input-gradient kernel -- the F(4x4,3x3) epilogue, or one in-place pass on the other
+    dispatches -- with and without the packed-weight scope."""
+    n, i, h, w, o = case
+    torch.set_num_threads(16)
+    x = rnd(n, i, h, w, seed=21).requires_grad_(True)
+    wt = (rnd(o, i, 3, 3, seed=22) / np.sqrt(i * 9)).requires_grad_(True)
+    yr = F.conv2d(x, wt, None, 1, 1)
+    gy, gs = rnd(*yr.shape, seed=23), rnd(n, i, h, w, seed=24)
+    ((yr * gy).sum() + (x * gs).sum()).backward()
+    xd = x.detach().cuda().requires_grad_(True)
+    wd = wt.detach().cuda().requires_grad_(True)
+    ops.invalidate_packed()
+    import contextlib
+    with (ops.pack_cache() if packed else contextlib.nullcontext()):
+        y, skip = ops.conv2d_skip(xd, wd, None, 1, 1, ops.PAD_ZERO)
+        assert skip.shape == xd.shape and torch.equal(skip, xd)
+        ((y * gy.cuda()).sum() + (skip * gs.cuda()).sum()).backward()
+    ops.invalidate_packed()
+    close(y, yr)
+    close(xd.grad, x.grad)
+    close(wd.grad, wt.grad, 5e-5)
+    # only the skip path used: the gradient passes straight through
+    xe = x.detach().cuda().requires_grad_(True)
+    _, skip = ops.conv2d_skip(xe, wd.detach(), None, 1, 1, ops.PAD_ZERO)
+    (skip * gs.cuda()).sum().backward()
+    close(xe.grad, gs)
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
