@@ -392,7 +392,8 @@ struct WinoWgradParams {
   int pad, reflect;
   int TH, TW;          // tile grid per image
   int groups;          // ceil(TH * TW / 8): 8-tile position groups per image
-  int groups_per_split, splits;
+  int groups_per_split, splits;   // splits = (splits over tile-position groups) x bsplits
+  int bsplits, nb_per;             // split of the batch: a workgroup walks images [b0, b0 + nb_per) of its groups
   int o_tiles, i_tiles, Opad;
 };
 
@@ -467,10 +468,12 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
   const auto rs_d = uniform_rsrc(p.dy, d_img * (unsigned)p.NB);
 
   // load cursor (two chunks ahead of the multiply): group lg, image lb
-  const int g0 = split * p.groups_per_split;
+  const int gsplit = split / p.bsplits, bsplit = split - gsplit * p.bsplits;
+  const int g0 = gsplit * p.groups_per_split;
   const int g1 = min(g0 + p.groups_per_split, p.groups);
-  const int nk = max(g1 - g0, 0) * p.NB;
-  int lg = g0, lb = 0;
+  const int b0 = bsplit * p.nb_per, b1 = min(b0 + p.nb_per, p.NB);
+  const int nk = max(g1 - g0, 0) * max(b1 - b0, 0);
+  int lg = g0, lb = b0;
   set_group(lg);
   float dx[16], dd[ND];
   // (the loads of a chunk are issued in five parts: the texture path takes ~20 cycles per gather instruction of a CU, so
@@ -485,8 +488,8 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
 #pragma unroll
       for (int i = 0; i < ND; ++i)
         dd[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, offd[i], lb * d_img, 0));
-      if (++lb == p.NB) {      // next tile-position group (wave-uniform, once per NB chunks)
-        lb = 0;
+      if (++lb == b1) {        // next tile-position group (wave-uniform, once per batch range)
+        lb = b0;
         ++lg;
         set_group(lg);
       }
@@ -924,13 +927,39 @@ static int wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
   splits = std::min(splits, p->groups);
   p->groups_per_split = (int)ceil_div(p->groups, splits);
   p->splits = (int)ceil_div(p->groups, p->groups_per_split);
-  const long long blocks = (long long)tiles * p->splits, chunks = (long long)p->groups_per_split * d->N;
+  p->bsplits = 1; p->nb_per = d->N;
+  long long blocks = (long long)tiles * p->splits, chunks = (long long)p->groups_per_split * d->N;
   const double ts = wino_threshold_scale();
+  // few tile positions (the discriminator's 32x32 / 16x16 maps at batch 64): the groups alone do not fill the device, so the
+  // K range (groups x images) is cut along the batch as well: the (group splits, batch splits) pair with the most
+  // workgroups within one device round wins, ties go to the longer K range per workgroup, then to the longer batch range
+  static const int min_chunks_b = std::getenv("SRGAN_WGRAD_BSPLIT_MIN_CHUNKS") ? std::atoi(std::getenv("SRGAN_WGRAD_BSPLIT_MIN_CHUNKS")) : 24;
+  if (variant == 2 && min_chunks_b > 0 && blocks < 192) {
+    const int S = std::max(1, 256 / tiles);
+    long long best_blocks = blocks, best_chunks = chunks;
+    int best_gps = p->groups_per_split, best_gs = p->splits, best_bs = 1, best_nb = d->N;
+    for (int gs = 1; gs <= std::min(p->groups, S); ++gs) {
+      const int gps = (int)ceil_div(p->groups, gs), gse = (int)ceil_div(p->groups, gps);
+      const int bs = std::max(1, std::min(d->N, S / gse));
+      const int nb = (int)ceil_div(d->N, bs), bse = (int)ceil_div(d->N, nb);
+      const long long bl = (long long)tiles * gse * bse, ch = (long long)gps * nb;
+      if (ch < min_chunks_b) continue;
+      // (ties in both: the longer batch range -- the gather offsets are rebuilt every time a workgroup moves to its next group)
+      if (bl > best_blocks || (bl == best_blocks && (ch > best_chunks || (ch == best_chunks && nb > best_nb)))) {
+        best_blocks = bl; best_chunks = ch; best_gps = gps; best_gs = gse; best_bs = bse; best_nb = nb;
+      }
+    }
+    if (best_bs > 1) {
+      p->groups_per_split = best_gps; p->bsplits = best_bs; p->nb_per = best_nb;
+      p->splits = best_gs * best_bs;
+      blocks = best_blocks; chunks = best_chunks;
+    }
+  }
   if (variant == 1) {
     if (blocks < 16 * ts || chunks < 4 * ts) return 0;      // too few workgroups / too short a K range: implicit GEMM instead
   } else {
     static const int min_blocks = std::getenv("SRGAN_WGRAD_S2_MIN_BLOCKS") ? std::atoi(std::getenv("SRGAN_WGRAD_S2_MIN_BLOCKS")) : 192;
-    if (blocks < min_blocks * ts || chunks < 48 * ts) return 0;    // measured: the discriminator's small maps stay faster on the implicit GEMM
+    if (blocks < min_blocks * ts || chunks < (p->bsplits > 1 ? min_chunks_b : 48) * ts) return 0;    // measured: the discriminator's smallest maps stay faster on the implicit GEMM
   }
   return variant;
 }

@@ -65,6 +65,8 @@ CONV_CASES = [
     (8, 128, 40, 44, 128, 4, 2, 1, False, True),  # F(3x3,2x2) Winograd of a 4x4 stride-2 layer: fwd and input gradient, ragged 3x3 tiles
     (48, 128, 58, 62, 128, 4, 2, 1, False, True), # same + its Winograd weight gradient (needs >= 192 workgroups, >= 48 chunks), ragged tiles
     (32, 64, 32, 32, 64, 4, 2, 1, False, False),  # same, one cout tile, many images per tile-position group
+    (64, 64, 64, 64, 128, 4, 2, 1, False, False), # D trunk at batch 64: Winograd weight gradient split over groups AND images (16 x 2)
+    (50, 128, 32, 32, 256, 4, 2, 1, False, False),# same: 5 groups x 8 batch ranges, ragged last range (50 = 7 x 7 + 1)
     (2, 3, 24, 70, 64, 7, 1, 3, False, False),    # RGB 7x7 layer: input gradient through the narrow-output kernel (flipped filter)
     (2, 3, 12, 13, 32, 5, 1, 2, False, True),     # same route, generic narrow kernel (5x5), bias
     (2, 64, 20, 72, 3, 7, 1, 3, False, True),     # RGB head through the 7x1 row convolution + shift-add, bias, ragged rows
