@@ -61,7 +61,18 @@ constexpr int W4BLK = 36 * 512;   // floats of one (tile block, chunk) image: [3
 __global__ __launch_bounds__(512) void wino43_input_kernel(WinoParams p, float* vimg) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cgs = p.C / 32;
-  const int m_tile = blockIdx.x / cgs, cg = blockIdx.x - m_tile * cgs;
+  // The channel groups of one tile block read 128-byte pieces of the SAME 1 KB pixel lines.  Consecutive workgroup ids go
+  // round-robin to the 8 XCDs, so with m_tile = id / cgs the pieces of a line would be fetched through 8 different L2s at
+  // different times; remapped, all channel groups of tile block m run back to back on XCD m % 8.
+  int m_tile, cg;
+  if ((p.m_tiles & 7) == 0) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    cg = k % cgs;
+    m_tile = (k / cgs) * 8 + xcd;
+  } else {
+    m_tile = blockIdx.x / cgs;
+    cg = blockIdx.x - m_tile * cgs;
+  }
   const int quad = lane & 7, tl = wave * 8 + (lane >> 3);
   const int t = m_tile * W4T + tl;
   const bool tv = t < p.T;

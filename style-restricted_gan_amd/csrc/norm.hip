@@ -509,16 +509,34 @@ __device__ __forceinline__ f32x4 slab_sum(f32x4 v, f32x4 (*sh)[8], int q, int wa
   return t;
 }
 
+// Slab kernels: (slab, image) of a workgroup.  The slabs of ONE image are 128-byte (or 64-byte) pieces of the same 1 KB pixel
+// lines; the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so with the plain (x = slab, y = image) grid
+// the pieces of a line are fetched by 8 different L2s at 8 different times.  Remapped, all slabs of image n run on XCD n % 8,
+// back to back: the line's pieces arrive at one L2 within a short window (SRGAN_NORM_PLAIN_GRID=1: the old mapping).
+__device__ __forceinline__ void slab_coords(int nslab, int N, int remap, int& slab, int& n) {
+  const int L = blockIdx.y * gridDim.x + blockIdx.x;
+  if (remap && (N & 7) == 0) {
+    const int xcd = L & 7, k = L >> 3;
+    slab = k % nslab;
+    n = (k / nslab) * 8 + xcd;
+  } else {
+    slab = L % nslab;
+    n = L / nslab;
+  }
+}
+
 // forward: 512 threads over HW x 32 channels (8 lanes per pixel: whole 128-byte lines; 16-channel slabs with 256 threads were
 // measured slower here, 45.6 vs 34.7 us on the 32x32x256 trunk, while they help the backward below)
 template <int R>
 __global__ __launch_bounds__(512) void in_fwd_slab(const float* __restrict__ x, const float* __restrict__ scale,
                                                    const float* __restrict__ shift, const float* __restrict__ res,
                                                    float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-                                                   int HW, int C, float eps, int act, float slope) {
+                                                   int HW, int C, float eps, int act, float slope, int remap) {
   __shared__ f32x4 sh[8][8];
   const int q = threadIdx.x & 7, ty = threadIdx.x >> 3, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 32 + q * 4, n = blockIdx.y;
+  int slab, n;
+  slab_coords(gridDim.x, gridDim.y, remap, slab, n);
+  const int c = slab * 32 + q * 4;
   const size_t base = (size_t)n * HW * C + c;
   f32x4 v[R];
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -572,10 +590,12 @@ __global__ __launch_bounds__(256) void in_bwd_slab(const float* __restrict__ x, 
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     float* __restrict__ dx, float* __restrict__ dscale,
-                                                    float* __restrict__ dshift, int HW, int C, int act, float slope) {
+                                                    float* __restrict__ dshift, int HW, int C, int act, float slope, int remap) {
   __shared__ f32x4 sh[4][8];
   const int q = threadIdx.x & 3, ty = threadIdx.x >> 2, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 16 + q * 4, n = blockIdx.y;
+  int slab, n;
+  slab_coords(gridDim.x, gridDim.y, remap, slab, n);
+  const int c = slab * 16 + q * 4;
   const int nc = n * C + c;
   const size_t base = (size_t)n * HW * C + c;
   const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + nc), rs = *reinterpret_cast<const f32x4*>(rstd + nc);
@@ -626,6 +646,11 @@ int apply_grid(int hwc4, int N) {
   return (int)std::max<long long>(1, std::min(per_image, want));
 }
 
+int slab_remap() {
+  static const int on = std::getenv("SRGAN_NORM_PLAIN_GRID") == nullptr;
+  return on;
+}
+
 // single-pass kernels: whole 32-channel groups, a slab of <= 1024 pixels, enough workgroups to cover the device
 bool slab_fast(int N, int HW, int C) {
   static const bool off = std::getenv("SRGAN_NO_NORM_SLAB") != nullptr;
@@ -663,7 +688,7 @@ extern "C" int srgan_instnorm_fwd(const float* x, const float* scale, const floa
   if (slab_fast(N, HW, C)) {
     const dim3 gs((unsigned)(C / 32), (unsigned)N);
     const int rows = (HW + 63) / 64;
-#define SRGAN_FWD_SLAB(R) hipLaunchKernelGGL(in_fwd_slab<R>, gs, dim3(512), 0, st, x, scale, shift, res, y, mean, rstd, HW, C, eps, act, slope)
+#define SRGAN_FWD_SLAB(R) hipLaunchKernelGGL(in_fwd_slab<R>, gs, dim3(512), 0, st, x, scale, shift, res, y, mean, rstd, HW, C, eps, act, slope, slab_remap())
     if (rows <= 1) SRGAN_FWD_SLAB(1);
     else if (rows <= 2) SRGAN_FWD_SLAB(2);
     else if (rows <= 4) SRGAN_FWD_SLAB(4);
@@ -704,7 +729,7 @@ extern "C" int srgan_instnorm_bwd(const float* x, const float* dy, const float* 
   if (slab_fast(N, HW, C)) {
     const dim3 gs((unsigned)(C / 16), (unsigned)N);
     const int rows = (HW + 63) / 64;
-#define SRGAN_BWD_SLAB(R) hipLaunchKernelGGL(in_bwd_slab<R>, gs, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dx, dscale, dshift, HW, C, act, slope)
+#define SRGAN_BWD_SLAB(R) hipLaunchKernelGGL(in_bwd_slab<R>, gs, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dx, dscale, dshift, HW, C, act, slope, slab_remap())
     if (rows <= 1) SRGAN_BWD_SLAB(1);
     else if (rows <= 2) SRGAN_BWD_SLAB(2);
     else if (rows <= 4) SRGAN_BWD_SLAB(4);

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
-K, B, STEPS = 2, 4, 2
+K, B, STEPS = 2, 4, 3
 
 
 def _free_port():
@@ -30,7 +30,7 @@ def _noise_source(rank, world):
     return fn
 
 
-def _run(rank, world, out_q=None, kl=0.0):
+def _run(rank, world, out_q=None, kl=0.0, graph=False):
     from oracle import trainer as otrainer
     from tests.common import build_hip_nets
     from srgan_amd.trainer import SRGAN_training
@@ -44,6 +44,8 @@ def _run(rank, world, out_q=None, kl=0.0):
     sg = SRGAN_training([G, D, E], opts, [nn.MSELoss(), nn.MSELoss()], dict(otrainer.DEFAULT_LBD, KL=kl), K, "cuda",
                         np.eye(4), B, "mu", 8)
     sg.opt_sche_initialization()
+    if graph:
+        sg.enable_graph()
     sg.noise_fn = _noise_source(rank, world)
     per = B // world
     losses = []
@@ -59,11 +61,13 @@ def _run(rank, world, out_q=None, kl=0.0):
     return losses, state, terms
 
 
-def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False):
+def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False, graph=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SRGAN_DP_DEVICE="0", SRGAN_DP_BACKEND=backend)
     if force:
         os.environ["SRGAN_DP_FORCE"] = "1"
+    if graph:
+        os.environ["SRGAN_DP_GRAPH"] = "1"
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "style-restricted_gan_amd")):
@@ -73,7 +77,7 @@ def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False):
     from srgan_amd import dp
     dp.init_from_env()
     assert dp.world_size() == world and dp.is_distributed()
-    _run(rank, world, out_q, kl)
+    _run(rank, world, out_q, kl, graph)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -110,17 +114,19 @@ def test_two_ranks_equal_one_process(kl):
         assert d <= 1e-5, (key, d)        # 4 optimiser steps of at most lr=1e-4 each; observed ~2e-6
 
 
-def test_rccl_path_one_rank_equals_plain_step():
+@pytest.mark.parametrize("graph", [False, True])
+def test_rccl_path_one_rank_equals_plain_step(graph):
     """The real RCCL calls on the test box's one GPU: a one-rank ``nccl`` process group with SRGAN_DP_FORCE=1 takes the whole
     data-parallel path -- hook-driven buckets with the G and E reducers armed together, in-place all-reduce of the flat buffers
     on the communication stream (asynchronous: only the ready / done events order it against the compute stream), the mu
     all-gather inside autograd, gradients bound to bucket slices, parameters without gradient left at None -- and must
     reproduce the plain single-process step.  (Two ranks cannot share a device under RCCL; the 2-rank arithmetic is the gloo
-    test above.)"""
+    test above.)  graph=True: the same with the step captured into a hipGraph (SRGAN_DP_GRAPH=1): the RCCL all-reduces and the
+    all-gather are recorded on their forked communication stream and replayed."""
     ref_losses, ref_state, ref_terms = _run(0, 1)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), q, 0.0, "nccl", True))
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), q, 0.0, "nccl", True, graph))
     p.start()
     rank, losses, state, terms = q.get(timeout=240)
     p.join(timeout=120)
