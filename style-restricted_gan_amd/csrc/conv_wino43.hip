@@ -120,6 +120,9 @@ __global__ __launch_bounds__(512) void wino43_input_kernel(WinoParams p, float* 
 // ---- multiply + output transform ----
 // WinoParams as in conv_wino.hip with TH = Ho / 4, TW = Wo / 4, n_tiles = Cd / 32, nchunk = C / 8, pad = 1;
 // u = [n_tiles][nchunk][36 pos][64 lanes][4]: lane (lr, lh) holds output channel lr, reduce channels 4 lh .. 4 lh + 3.
+// RES: the epilogue adds p.res (input gradient of a residual block's first convolution: the skip path's gradient rides in
+// here).  A separate instantiation: a run-time branch in the epilogue cost every launch ~6 us (146 -> 154 us average).
+template <bool RES>
 __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* vimg) {
   // V image, double-buffered: [buf][36 pos][2 channel quads][64 tiles x 4 ch + 16 pad]: a lane's MFMA fragment is one 16-B
   // slot, a 16-lane read group covers 256 contiguous bytes; the copy writes 1 KB per wave instruction.
@@ -275,6 +278,17 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (q > 0) __syncthreads();                  // the previous pass has been read
+      // RES: this pass's 16 values of the skip gradient are requested FIRST, so that their latency hides behind the LDS
+      // exchange and the output transform (loaded next to the stores they took 32 us per launch at batch 32)
+      float rv[16];
+      if constexpr (RES) {
+        const int eo_r = tile_o[16 * q + et];
+        const float* rp = p.res + (size_t)(eo_r >= 0 ? eo_r : 0) * p.Cd + n;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) rv[a * 4 + b] = eo_r >= 0 ? rp[(size_t)(a * p.Wo + b) * p.Cd] : 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int g = i + ODD, a = g >> 1, h = g & 1;
@@ -302,19 +316,13 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
       const int eo = tile_o[16 * q + et];
       if (eo >= 0) {
         float* dp = p.dst + (size_t)eo * p.Cd + n;
-        if (p.res) {
-          // input gradient of a residual block's first convolution: the gradient of the skip path rides in here instead of
-          // a separate add pass over the tensor (same whole-line access pattern as the stores)
-          const float* rp = p.res + (size_t)eo * p.Cd + n;
+        if constexpr (RES) {
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
             float y[4];
             at6(hh[a][0], hh[a][1], hh[a][2], hh[a][3], hh[a][4], hh[a][5], y);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const size_t o = (size_t)(a * p.Wo + b) * p.Cd;
-              dp[o] = apply_act(y[b] + bv, p.act, p.slope) + rp[o];
-            }
+            for (int b = 0; b < 4; ++b) dp[(size_t)(a * p.Wo + b) * p.Cd] = apply_act(y[b] + bv, p.act, p.slope) + rv[a * 4 + b];
           }
         } else {
 #pragma unroll
@@ -549,7 +557,8 @@ int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops
   }
   if (only != 1) {
     ProfToken tok = prof_begin(18, flops, st);
-    hipLaunchKernelGGL(wino43_kernel, dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
+    if (p.res) hipLaunchKernelGGL(wino43_kernel<true>, dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
+    else hipLaunchKernelGGL(wino43_kernel<false>, dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
     prof_end(tok, st);
   }
   return 0;
