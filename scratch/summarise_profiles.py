@@ -5,7 +5,7 @@ import csv, glob, json, os, re, shutil, sys, collections
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ev = os.path.join(root, "gpurun_out", "ev")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
 
 
 def prof_name(n):
@@ -57,7 +57,7 @@ def counter(sub, name):
 
 fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
 out = {"_doc": "Per-launch averages of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py "
-               "--steps 2 --warmup 1 --no-cpu-baseline`; hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (KB*1024): on gfx950 "
+               "--steps 2 --warmup 1 --graph off --no-cpu-baseline --no-micro`; hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (KB*1024): on gfx950 "
                "FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact.",
        "kernels": {}}
 for k in sorted(fetch):
@@ -71,7 +71,7 @@ json.dump(out, open(os.path.join(root, "profiles", tag.split("_")[0] + "_pmc_tra
 if glob.glob(os.path.join(ev, "mfma", "*", "*counter_collection.csv")):
     busy, gui = counter("mfma", "SQ_VALU_MFMA_BUSY_CYCLES"), counter("mfma", "GRBM_GUI_ACTIVE")
     util = {"_doc": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over `python3 bench.py --steps 2 --warmup 1 "
-                    "--no-cpu-baseline`; per kernel: sum over launches of MFMA busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8). "
+                    "--graph off --no-cpu-baseline --no-micro`; per kernel: sum over launches of MFMA busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8). "
                     "Launches shorter than ~0.3 ms over-count GUI cycles (MI355X_MICROARCH.md, DVFS), so small kernels read low.",
             "kernels": {}}
     for k in sorted(busy):
@@ -81,7 +81,8 @@ if glob.glob(os.path.join(ev, "mfma", "*", "*counter_collection.csv")):
     json.dump(util, open(os.path.join(root, "profiles", tag.split("_")[0] + "_pmc_mfma.json"), "w"), indent=1)
 stats = newest(os.path.join(ev, "stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(root, "profiles", tag + "_bench_steps5_kernel_stats.csv"))
-for src, dst in (("bench_plain.json", tag + "_bench_steps5.json"), ("bench_under_rocprof.json", tag + "_bench_steps5_under_rocprof.json")):
+for src, dst in (("bench_plain.json", tag + "_bench_steps20.json"), ("bench_eager.json", tag + "_bench_steps20_eager.json"),
+                 ("bench_under_rocprof.json", tag + "_bench_steps5_under_rocprof.json")):
     p = os.path.join(ev, src)
     if os.path.exists(p):
         line = open(p).read().strip().splitlines()[-1]
