@@ -74,6 +74,17 @@ int srgan_conv2d_fwd_packed(const srgan_conv_desc* d, const float* x, const void
                             int act, float slope, void* ws, size_t ws_bytes, void* stream);
 int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* dy, const void* packed, float* dx,
                               void* ws, size_t ws_bytes, void* stream);
+/* conv3x3(act(instance_norm(x) * scale + shift)) without the intermediate tensor: inside SingleResidualBlock (model.py:196-201:
+ * c1 -> cn1 -> ReLU -> c2) the normalised activation is read by c2 only.  srgan_instnorm_fwd_v = srgan_instnorm_fwd (same
+ * statistics, same expression, mean / rstd saved for the backward) whose output is written directly as the transformed-input
+ * ("V") image of the F(4x4,3x3) layer `d` (v_bytes >= srgan_conv2d_packed_scratch(d, 0)); srgan_conv2d_fwd_from_v then runs
+ * that layer's multiply + output transform on it, and srgan_conv2d_wgrad_v its weight gradient.  Applicable
+ * (srgan_instnorm_conv_v_applicable != 0) to 32x32 maps with Cin % 32 == 0 whose forward dispatches to F(4x4,3x3). */
+int srgan_instnorm_conv_v_applicable(const srgan_conv_desc* d);
+int srgan_instnorm_fwd_v(const srgan_conv_desc* d, const float* x, const float* scale, const float* shift, float* mean,
+                         float* rstd, void* v_image, size_t v_bytes, float eps, int act, float slope, void* stream);
+int srgan_conv2d_fwd_from_v(const srgan_conv_desc* d, const void* v_image, const void* packed, const float* bias, float* y,
+                            int act, float slope, void* stream);
 /* dx = (input gradient of the convolution) + res: SingleResidualBlock (model.py:196-201) feeds its input to its first
  * convolution AND to the skip connection, so the gradient of the block input is the sum of the two paths; handing the skip
  * path's gradient to the convolution's input-gradient kernel (added in the F(4x4,3x3) epilogue; one in-place pass on the other

@@ -99,7 +99,10 @@ struct WinoParams {
 
 // conv_wino43.hip: F(4x4,3x3) kernel behind wino_run
 size_t wino43_scratch_floats(long long T, int C);
-int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops, hipStream_t st);
+int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops, hipStream_t st, bool v_ready = false);
+// instance norm + activation of a 32x32 map written straight as the V image of the following F(4x4,3x3) layer (conv_wino43.hip)
+int in_fwd_slab_v_launch(const float* x, const float* scale, const float* shift, float* mean, float* rstd, float* vimg, int N,
+                         int C, float eps, int act, float slope, hipStream_t st);
 // F(4x4,3x3) weight gradient from the forward's V image (conv_wino43.hip; geometry and dispatch in conv_wino.hip)
 struct Wino43WgradGeom { int NB, H, W, C, O, ntc, splits, chunks_per_split; size_t v_bytes, z_bytes, slab_bytes; };
 bool wino43_wgrad_geometry(const srgan_conv_desc* d, Wino43WgradGeom* g);      // false: not applicable
@@ -109,7 +112,8 @@ bool wino_applicable(const srgan_conv_desc* d, int kind);
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind);
 int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hipStream_t st);
 size_t wino_scratch_bytes(const srgan_conv_desc* d, int kind);
-int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst, int act, float slope, float* scratch, hipStream_t st, const float* res = nullptr, bool* res_done = nullptr);
+int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst, int act, float slope, float* scratch, hipStream_t st, const float* res = nullptr, bool* res_done = nullptr, bool v_ready = false);
+bool wino43_fwd_applicable(const srgan_conv_desc* d);      // the forward of d runs on F(4x4,3x3)
 bool wino_wgrad_applicable(const srgan_conv_desc* d);
 void wino_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad);
 int wino_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, hipStream_t st);

@@ -1577,6 +1577,32 @@ extern "C" int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* 
   return dgrad_run(d, dy, (const float*)packed, dx, (float*)ws, as_stream(stream));
 }
 
+// ---- instance norm + activation feeding an F(4x4,3x3) layer without materialising the normalised tensor ----
+extern "C" int srgan_instnorm_conv_v_applicable(const srgan_conv_desc* d) {
+  if (validate(d) != 0) return 0;
+  return d->Hi == 32 && d->Wi == 32 && d->I % 32 == 0 && d->kh == 3 && d->stride == 1 && d->pad == 1 &&
+         d->pad_mode == SRGAN_PAD_ZERO && fwd_path(d, SRGAN_ACT_NONE) == PATH_WINO && wino43_fwd_applicable(d) ? 1 : 0;
+}
+
+extern "C" int srgan_instnorm_fwd_v(const srgan_conv_desc* d, const float* x, const float* scale, const float* shift, float* mean,
+                                    float* rstd, void* v_image, size_t v_bytes, float eps, int act, float slope, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(x && mean && rstd && v_image, "instnorm_fwd_v: null pointer");
+  SRGAN_REQUIRE((scale == nullptr) == (shift == nullptr), "instnorm_fwd_v: scale and shift go together");
+  SRGAN_REQUIRE(srgan_instnorm_conv_v_applicable(d), "instnorm_fwd_v: layer not applicable (32x32 map into an F(4x4,3x3) layer)");
+  SRGAN_REQUIRE(v_bytes >= srgan_conv2d_packed_scratch(d, 0), "instnorm_fwd_v: V image too small (srgan_conv2d_packed_scratch)");
+  return in_fwd_slab_v_launch(x, scale, shift, mean, rstd, static_cast<float*>(v_image), d->N, d->I, eps, act, slope, as_stream(stream));
+}
+
+extern "C" int srgan_conv2d_fwd_from_v(const srgan_conv_desc* d, const void* v_image, const void* packed, const float* bias,
+                                       float* y, int act, float slope, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(v_image && packed && y, "conv2d_fwd_from_v: null pointer");
+  SRGAN_REQUIRE(fwd_path(d, act) == PATH_WINO && wino43_fwd_applicable(d), "conv2d_fwd_from_v: layer does not run on F(4x4,3x3)");
+  return wino_run(d, 0, nullptr, (const float*)packed, bias, y, act, slope, const_cast<float*>(static_cast<const float*>(v_image)),
+                  as_stream(stream), nullptr, nullptr, true);
+}
+
 extern "C" int srgan_conv2d_dgrad_packed_add(const srgan_conv_desc* d, const float* dy, const void* packed, const float* res,
                                              float* dx, void* ws, size_t ws_bytes, void* stream) {
   if (int e = validate(d)) return e;

@@ -844,8 +844,10 @@ int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hi
 // `scratch`: wino_scratch_bytes(d, kind) bytes (may be null when that is 0)
 // `res` (optional): added to the result in the epilogue where the kernel supports it (F(4x4,3x3)); *res_done tells the caller
 // whether it was, so that it can add the tensor itself otherwise
+bool wino43_fwd_applicable(const srgan_conv_desc* d) { return wino_variant(d, 0) == 3; }
+
 int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst,
-             int act, float slope, float* scratch, hipStream_t st, const float* res, bool* res_done) {
+             int act, float slope, float* scratch, hipStream_t st, const float* res, bool* res_done, bool v_ready) {
   if (res_done) *res_done = false;
   WinoParams p{};
   p.act = act; p.slope = slope;
@@ -888,9 +890,10 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
     SRGAN_REQUIRE(scratch, "winograd F(4,3): no scratch for the transformed input");
     p.res = res;
     if (res_done) *res_done = res != nullptr;
-    wino43_launch(p, scratch, grid, conv_flops_of(d), st);
+    wino43_launch(p, scratch, grid, conv_flops_of(d), st, v_ready);
     return check_launch("wino43_kernel");
   }
+  SRGAN_REQUIRE(!v_ready, "winograd: a prepared V image only serves the F(4x4,3x3) path");
   ProfToken tok = prof_begin(variant == 1 ? 14 : 16, conv_flops_of(d), st);
   if (variant == 1) hipLaunchKernelGGL(wino_kernel<0>, dim3((unsigned)grid), dim3(512), 0, st, p);
   else if (kind == 0) hipLaunchKernelGGL(wino_kernel<1>, dim3((unsigned)grid), dim3(512), 0, st, p);

@@ -117,6 +117,118 @@ __global__ __launch_bounds__(512) void wino43_input_kernel(WinoParams p, float* 
   }
 }
 
+// ---- instance norm + activation + input transform in one pass (32x32 maps: the generator's residual trunk) ----
+// SingleResidualBlock (model.py:196-201): conv -> CBIN -> ReLU -> conv.  The normalised activation h between the two
+// convolutions has exactly one reader -- the second convolution's input transform -- and the F(4x4,3x3) weight gradient reads
+// that transform's V image, not h.  So h is never written: one workgroup holds the (image, 32-channel) slab of the conv output
+// in registers like in_fwd_slab (statistics by shuffles + one LDS exchange, exact two-pass variance, same normalise / affine /
+// activation expression), parks the normalised slab in LDS (1024 pixels x 36 floats: the 4-float pad spreads the 8 tiles of a
+// wave over the banks) and transforms it from there as wino43_input_kernel does: thread = (tile, 4 channels), 36 ds_read_b128
+// (out-of-image taps are zeros: the padding applies to h), B^T d B in registers, 36 16-byte stores in the multiply kernel's
+// LDS image order.  Reads 1 x and writes 2.25 x the tensor instead of (1 + 1) + (1 + 2.25) x, one launch instead of two.
+// 64 tiles per image = one tile block, so m_tile = image and channel group = slab.
+constexpr int NV_LD = 36;
+template <int NW>
+__device__ __forceinline__ f32x4 slab_sum43(f32x4 v, f32x4 (*sh)[8], int q, int wave) {
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) < 8) sh[wave][q] = v;
+  __syncthreads();
+  f32x4 t = sh[0][q];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) t += sh[w][q];
+  return t;
+}
+
+__global__ __launch_bounds__(512) void in_fwd_slab_v_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, float* __restrict__ vimg, int N, int C,
+                                                            float eps, int act, float slope) {
+  constexpr int HW = 1024, R = 16;
+  __shared__ __attribute__((aligned(16))) float hb[HW * NV_LD];
+  __shared__ f32x4 sh[8][8];
+  const int tid = threadIdx.x, q = tid & 7, ty = tid >> 3, wave = tid >> 6, lane = tid & 63;
+  // XCD-aware order (see in_fwd_slab): the 8 channel slabs of one image run back to back on one XCD
+  const int nslab = C / 32;
+  int slab, n;
+  {
+    const int L = blockIdx.x;
+    if ((N & 7) == 0) { const int xcd = L & 7, k = L >> 3; slab = k % nslab; n = (k / nslab) * 8 + xcd; }
+    else { slab = L % nslab; n = L / nslab; }
+  }
+  const int c = slab * 32 + q * 4;
+  const size_t base = (size_t)n * HW * C + c;
+  f32x4 v[R];
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    v[j] = *reinterpret_cast<const f32x4*>(x + base + (size_t)(ty + 64 * j) * C);
+    s += v[j];
+  }
+  const float inv = 1.f / (float)HW;
+  const f32x4 mu = slab_sum43<8>(s, sh, q, wave) * inv;
+  f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const f32x4 d = v[j] - mu;
+    m2 += d * d;
+  }
+  const f32x4 var = slab_sum43<8>(m2, sh, q, wave) * inv;
+  f32x4 rs;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) rs[e] = 1.0f / sqrtf(var[e] + eps);
+  const int nc = n * C + c;
+  if (ty == 0) {
+    *reinterpret_cast<f32x4*>(mean + nc) = mu;
+    *reinterpret_cast<f32x4*>(rstd + nc) = rs;
+  }
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+  if (scale) {
+    sc = *reinterpret_cast<const f32x4*>(scale + nc);
+    sf = *reinterpret_cast<const f32x4*>(shift + nc);
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    f32x4 o = ((v[j] - mu) * rs) * sc + sf;                 // the expression of in_fwd_slab / in_apply / the backward's mask
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = apply_act(o[e], act, slope);
+    *reinterpret_cast<f32x4*>(&hb[(ty + 64 * j) * NV_LD + q * 4]) = o;
+  }
+  __syncthreads();
+  // transform role: tile tl of the image (8 x 8 tiles of 4 x 4 pixels), channel quad
+  const int quad = lane & 7, tl = wave * 8 + (lane >> 3);
+  const int Y = 4 * (tl >> 3), X = 4 * (tl & 7);
+  f32x4 d[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) {
+      const int yy = Y - 1 + r, xx = X - 1 + cc;
+      const bool ok = (unsigned)yy < 32u && (unsigned)xx < 32u;
+      d[r][cc] = ok ? *reinterpret_cast<const f32x4*>(&hb[(yy * 32 + xx) * NV_LD + quad * 4]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+  for (int cc = 0; cc < 6; ++cc) bt6(d[0][cc], d[1][cc], d[2][cc], d[3][cc], d[4][cc], d[5][cc]);
+  const int nchunk = C / W4C;
+  float* out = vimg + ((size_t)n * nchunk + slab * 4 + (quad >> 1)) * W4BLK + (quad & 1) * 256 + tl * 4;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]);
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) *reinterpret_cast<f32x4*>(out + (r * 6 + cc) * 512) = d[r][cc];
+  }
+}
+
+int in_fwd_slab_v_launch(const float* x, const float* scale, const float* shift, float* mean, float* rstd, float* vimg, int N,
+                         int C, float eps, int act, float slope, hipStream_t st) {
+  hipLaunchKernelGGL(in_fwd_slab_v_kernel, dim3((unsigned)(N * (C / 32))), dim3(512), 0, st, x, scale, shift, mean, rstd, vimg, N, C,
+                     eps, act, slope);
+  return check_launch("in_fwd_slab_v_kernel");
+}
+
 // ---- multiply + output transform ----
 // WinoParams as in conv_wino.hip with TH = Ho / 4, TW = Wo / 4, n_tiles = Cd / 32, nchunk = C / 8, pad = 1;
 // u = [n_tiles][nchunk][36 pos][64 lanes][4]: lane (lr, lh) holds output channel lr, reduce channels 4 lh .. 4 lh + 3.
@@ -547,10 +659,10 @@ __global__ __launch_bounds__(512) void wino43_wgrad_kernel(Wino43WgradParams p) 
 size_t wino43_scratch_floats(long long T, int C) { return (size_t)ceil_div(T, (long long)W4T) * (C / W4C) * W4BLK; }
 
 // `flops`: the layer's ALGORITHMIC FLOPs, booked on the multiply kernel; the input transform is HBM-bound and has its own slot
-int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops, hipStream_t st) {
+int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops, hipStream_t st, bool v_ready) {
   // SRGAN_W43_ONLY=1 / 2 (timing experiments only): launch just the input transform / just the multiply kernel
   static const int only = std::getenv("SRGAN_W43_ONLY") ? std::atoi(std::getenv("SRGAN_W43_ONLY")) : 0;
-  if (only != 2) {
+  if (only != 2 && !v_ready) {      // v_ready: the caller's V image already holds B^T d B (in_fwd_slab_v_kernel wrote it)
     ProfToken tok = prof_begin(19, 0.0, st);
     hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)(p.m_tiles * (p.C / 32))), dim3(512), 0, st, p, vimg);
     prof_end(tok, st);

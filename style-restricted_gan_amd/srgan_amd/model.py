@@ -125,11 +125,14 @@ class CBINorm2d(nn.Module):
     def forward(self, input, ConInfor, act=ACT_NONE, slope=0.0, res=None):
         """(IN(x) + tanh(Linear(c))) * weight + bias, with optional fused activation / residual."""
         self._check_input_dim(input)
-        if isinstance(ConInfor, PrecomputedCon):       # the network computed every layer's affine in one launch
-            scale, shift = ConInfor.affine[id(self)]
-            return ops.instance_norm_act(input, scale, shift, res, act, slope, self.eps)
-        scale, shift = ops.cbin_affine(ConInfor, *self.affine_params(input.device))
+        scale, shift = self.scale_shift(ConInfor, input.device)
         return ops.instance_norm_act(input, scale, shift, res, act, slope, self.eps)
+
+    def scale_shift(self, ConInfor, device):
+        """Per-sample (scale, shift) [N, C] of the layer: y = IN(x) * scale + shift."""
+        if isinstance(ConInfor, PrecomputedCon):       # the network computed every layer's affine in one launch
+            return ConInfor.affine[id(self)]
+        return ops.cbin_affine(ConInfor, *self.affine_params(device))
 
     def affine_params(self, device):
         lin = self.ConBias[0]
@@ -178,8 +181,14 @@ class SingleResidualBlock(nn.Module):
         # the block input feeds c1 and the skip connection: conv2d_skip routes the skip path's gradient into c1's
         # input-gradient kernel (added in its epilogue) instead of a separate accumulation pass
         y1, skip = ops.conv2d_skip(data, self.c1.weight, None, self.c1.stride[0], self.c1.padding[0], PAD_ZERO)
-        h = self.cn1(y1, con, ACT_RELU)
-        return self.cn2(self.c2(h), con, ACT_NONE, 0.0, skip), con
+        if ops.norm_act_conv_fusable(y1, self.c2.weight):
+            # cn1 + ReLU + c2 without the normalised tensor: the norm kernel writes c2's transformed-input image directly
+            self.cn1._check_input_dim(y1)
+            scale, shift = self.cn1.scale_shift(con, y1.device)
+            y2 = ops.instance_norm_act_conv(y1, scale, shift, self.c2.weight, ACT_RELU, 0.0, self.cn1.eps)
+        else:
+            y2 = self.c2(self.cn1(y1, con, ACT_RELU))
+        return self.cn2(y2, con, ACT_NONE, 0.0, skip), con
 
 
 class SingleGenerator(nn.Module):

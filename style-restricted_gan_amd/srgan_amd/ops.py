@@ -552,6 +552,91 @@ def instance_norm_act(x, scale=None, shift=None, res=None, act=ACT_NONE, slope=0
     return _InstNormFn.apply(x, scale, shift, res, act, slope, eps)
 
 
+class _NormActConvFn(Function):
+    """conv3x3(act(instance_norm(x) * scale + shift), weight) for a 32x32 map feeding an F(4x4,3x3) layer, without the
+    normalised tensor: the norm kernel writes the convolution's transformed-input (V) image directly
+    (``srgan_instnorm_fwd_v``), the multiply runs on it (``srgan_conv2d_fwd_from_v``) and the weight gradient re-uses it
+    (``srgan_conv2d_wgrad_v``).  Backward = the three kernels of the unfused chain: input gradient of the convolution, its
+    weight gradient, instance-norm backward.  Same kept semantics as _Conv2dFn (weight by reference, read at backward time)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, weight, act, slope, eps):
+        lib = _lib.load()
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        o = weight.shape[0]
+        desc = _conv_desc(n, h, w, c, h, w, o, 3, 3, 1, 1, PAD_ZERO, weight)
+        hit, scratch = _packed(desc, weight, 0, ACT_NONE)
+        keep = None
+        if ctx.needs_input_grad[3]:
+            nv = lib.srgan_conv2d_wgrad_v_bytes(ctypes.byref(desc))
+            if nv:
+                keep = torch.empty(max(nv, scratch), dtype=torch.uint8, device=x.device)
+        v = keep if keep is not None else workspace(x.device, scratch)
+        mean = torch.empty(n * c, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _lib.check(lib.srgan_instnorm_fwd_v(ctypes.byref(desc), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(v),
+                                            v.numel(), float(eps), act, float(slope), _stream()), "instnorm_fwd_v")
+        y = nhwc_empty(n, o, h, w, x.device)
+        _lib.check(lib.srgan_conv2d_fwd_from_v(ctypes.byref(desc), _ptr(v), _ptr(hit.buf), None, _ptr(y), ACT_NONE, 0.0, _stream()),
+                   "conv2d_fwd_from_v")
+        ctx.desc, ctx.weight, ctx.v_image = desc, weight, keep
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(x, scale, shift, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, scale, shift, mean, rstd = ctx.saved_tensors
+        lib = _lib.load()
+        gy = to_nhwc(gy)
+        weight = ctx.weight
+        n, c, h, w = x.shape
+        dw = None
+        if ctx.needs_input_grad[3]:
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
+            desc = ConvDesc.from_buffer_copy(ctx.desc)
+            desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
+            if ctx.v_image is not None:
+                _run_conv_wgrad(desc, None, gy, dw, None, ctx.v_image)
+            else:       # no V kept (layer outside the F(4x4,3x3) weight-gradient geometry): recompute the normalised input
+                hx = _InstNormFn.apply(x.detach(), scale, shift, None, ctx.act, ctx.slope, 1e-5)
+                _run_conv_wgrad(desc, hx, gy, dw, None)
+        dx = dscale = dshift = None
+        if ctx.needs_input_grad[0] or (scale is not None and ctx.needs_input_grad[1]):
+            dh = torch.empty_like(x)
+            _run_conv_dgrad(ctx.desc, gy, weight, dh)
+            dx = torch.empty_like(x)
+            dscale = torch.empty(n, c, dtype=torch.float32, device=x.device)
+            dshift = torch.empty_like(dscale)
+            nb = lib.srgan_instnorm_workspace(n, h * w, c)
+            ws = workspace(x.device, nb)
+            _lib.check(lib.srgan_instnorm_bwd(_ptr(x), _ptr(dh), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                              _ptr(dscale), _ptr(dshift), n, h * w, c, ctx.act, float(ctx.slope), _ptr(ws), nb,
+                                              _stream()), "instnorm_bwd")
+            if scale is None:
+                dscale = dshift = None
+        return dx, dscale, dshift, dw, None, None, None
+
+
+def norm_act_conv_fusable(x, weight):
+    """True when ``instance_norm_act_conv`` applies: packed-weight scope, 32x32 map, the conv dispatches to F(4x4,3x3)."""
+    if not (_pack_cache_on and x.is_cuda and x.dim() == 4 and weight.dim() == 4 and weight.shape[2] == 3 and weight.shape[3] == 3):
+        return False
+    if _os.environ.get("SRGAN_NO_NORM_CONV_FUSION"):
+        return False
+    n, c, h, w = x.shape
+    if (h, w) != (32, 32) or weight.shape[1] != c:
+        return False
+    desc = _conv_desc(n, h, w, c, h, w, weight.shape[0], 3, 3, 1, 1, PAD_ZERO, weight)
+    return bool(_lib.load().srgan_instnorm_conv_v_applicable(ctypes.byref(desc)))
+
+
+def instance_norm_act_conv(x, scale, shift, weight, act=ACT_NONE, slope=0.0, eps=1e-5):
+    """conv2d(act(instance_norm(x) * scale[n,c] + shift[n,c]), weight, stride 1, pad 1) -- see _NormActConvFn."""
+    return _NormActConvFn.apply(x, scale, shift, weight, act, slope, eps)
+
+
 class _CbinAffineFn(Function):
     @staticmethod
     def forward(ctx, c, W, b, gamma, beta):

@@ -176,6 +176,56 @@ def test_conv2d_skip_gradient_rides_in_the_dgrad_epilogue(ops, case, packed, dis
     close(xe.grad, gs)
 
 
+@pytest.mark.parametrize("n,c,o,affine", [(32, 256, 256, True), (4, 64, 64, True), (3, 64, 96, False)])
+def test_instance_norm_act_conv_equals_the_unfused_chain(ops, n, c, o, affine):
+    """instance_norm_act_conv (norm + ReLU written straight as the F(4x4,3x3) V image, multiply, weight gradient from V) against
+    the chain it replaces on the HIP path -- bit-identical forward (same expression, same V values) -- and against PyTorch-CPU."""
+    import os
+    torch.set_num_threads(16)
+    x = rnd(n, c, 32, 32, seed=31)
+    wt = rnd(o, c, 3, 3, seed=32) / np.sqrt(c * 9)
+    sc = (torch.rand(n, c, generator=torch.Generator().manual_seed(33)) + 0.5) if affine else None
+    sh = rnd(n, c, seed=34) * 0.3 if affine else None
+    gy = rnd(n, o, 32, 32, seed=35)
+    res = {}
+    os.environ["SRGAN_WINOGRAD_THRESHOLD_SCALE"] = "0"          # small batches: force the F(4x4,3x3) dispatch
+    try:
+        for mode in ("fused", "chain"):
+            xd, wd = x.cuda().requires_grad_(True), wt.cuda().requires_grad_(True)
+            scd = sc.cuda().requires_grad_(True) if affine else None
+            shd = sh.cuda().requires_grad_(True) if affine else None
+            ops.invalidate_packed()
+            with ops.pack_cache():
+                if mode == "fused":
+                    assert ops.norm_act_conv_fusable(xd, wd)
+                    y = ops.instance_norm_act_conv(xd, scd, shd, wd, ops.ACT_RELU, 0.0, 1e-5)
+                else:
+                    y = ops.conv2d(ops.instance_norm_act(xd, scd, shd, None, ops.ACT_RELU, 0.0, 1e-5), wd, None, 1, 1)
+                y.backward(gy.cuda())
+            res[mode] = (y.detach(), xd.grad, wd.grad, scd.grad if affine else None, shd.grad if affine else None)
+    finally:
+        os.environ.pop("SRGAN_WINOGRAD_THRESHOLD_SCALE", None)
+        ops.invalidate_packed()
+    assert torch.equal(res["fused"][0], res["chain"][0])
+    for a, b in zip(res["fused"][1:], res["chain"][1:]):
+        if a is not None:
+            assert torch.equal(a, b)
+    # and against the PyTorch-CPU reference of the chain
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    hr = F.instance_norm(xr, eps=1e-5)
+    if affine:
+        scr, shr = sc.clone().requires_grad_(True), sh.clone().requires_grad_(True)
+        hr = hr * scr[:, :, None, None] + shr[:, :, None, None]
+    yr = F.conv2d(torch.relu(hr), wr, None, 1, 1)
+    yr.backward(gy)
+    close(res["fused"][0], yr, 1e-4)
+    close(res["fused"][1], xr.grad, 2e-4)
+    close(res["fused"][2], wr.grad, 1e-4)
+    if affine:
+        close(res["fused"][3], scr.grad, 2e-4)
+        close(res["fused"][4], shr.grad, 2e-4)
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
