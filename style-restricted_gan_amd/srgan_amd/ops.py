@@ -379,7 +379,7 @@ def _run_conv_dgrad(desc, dy, weight, dx, res=None):
 
 
 def _run_conv_wgrad(desc, x, dy, dw, dbias, v_image=None):
-    ws, nb = _conv_ws(desc, x.device)
+    ws, nb = _conv_ws(desc, dy.device)
     if v_image is not None:
         _lib.check(_lib.load().srgan_conv2d_wgrad_v(ctypes.byref(desc), _ptr(v_image), _ptr(dy), _ptr(dw), _ptr(dbias), _ptr(ws),
                                                     nb, _stream()), "conv2d_wgrad_v")
