@@ -30,17 +30,23 @@ def _noise_source(rank, world):
     return fn
 
 
-def _run(rank, world, out_q=None, kl=0.0, graph=False):
+def _run(rank, world, out_q=None, kl=0.0, graph=False, recipe=None):
     from oracle import trainer as otrainer
     from tests.common import build_hip_nets
     from srgan_amd.trainer import SRGAN_training
-    from srgan_amd import optim as hoptim
+    from srgan_amd import optim as hoptim, ops
     G, D, E = build_hip_nets("T")
+    if recipe == "config2":          # BASELINE configs[2]: pretrained-E recipe (trunk frozen for optE) + bf16 convolutions + DP
+        ops.set_compute_dtype("bf16")
+        keys = [k_ for k_ in E.state_dict().keys() if not k_.startswith(("fcmean", "fcvar"))]
+        E.freeze_melt(keys, "freeze")
     torch.manual_seed(0)
     # Adam with a large eps is nearly linear in the gradient: without it the first steps are lr*sign(g) and
     # rounding-level differences between the two reduction orders are amplified to O(lr) parameter differences,
     # which would hide (or fake) a real data-parallel discrepancy.
-    opts = [hoptim.Adam(net.parameters(), lr=1e-4, betas=(0.5, 0.999), eps=1e-2) for net in (G, D, E)]
+    opts = [hoptim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-4, betas=(0.5, 0.999), eps=1e-2) for net in (G, D, E)]
+    if recipe == "config2":
+        E.freeze_melt(keys, "melt")
     sg = SRGAN_training([G, D, E], opts, [nn.MSELoss(), nn.MSELoss()], dict(otrainer.DEFAULT_LBD, KL=kl), K, "cuda",
                         np.eye(4), B, "mu", 8)
     sg.opt_sche_initialization()
@@ -61,7 +67,7 @@ def _run(rank, world, out_q=None, kl=0.0, graph=False):
     return losses, state, terms
 
 
-def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False, graph=False):
+def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False, graph=False, recipe=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SRGAN_DP_DEVICE="0", SRGAN_DP_BACKEND=backend)
     if force:
@@ -77,7 +83,7 @@ def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False, graph
     from srgan_amd import dp
     dp.init_from_env()
     assert dp.world_size() == world and dp.is_distributed()
-    _run(rank, world, out_q, kl, graph)
+    _run(rank, world, out_q, kl, graph, recipe)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -135,3 +141,30 @@ def test_rccl_path_one_rank_equals_plain_step(graph):
     for key, v in state.items():
         d = float(np.abs(v - ref_state[key]).max())
         assert d <= 1e-6, (key, d)
+
+
+def test_config2_recipe_two_ranks_equal_one_process():
+    """BASELINE configs[2] in its stated form at tier-T widths: the pretrained-E recipe (encoder trunk outside optE) AND the bf16
+    convolution mode AND two data-parallel ranks, against the single-process step of the same recipe."""
+    from srgan_amd import ops
+    try:
+        ref_losses, ref_state, ref_terms = _run(0, 1, recipe="config2")
+    finally:
+        ops.set_compute_dtype("fp32")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 0.0, "gloo", False, False, "config2")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    dp_losses = (np.array(res[0][1]) + np.array(res[1][1])) / 2
+    np.testing.assert_allclose(dp_losses, np.array(ref_losses), rtol=1e-3)
+    for key, v in res[0][2].items():
+        d = float(np.abs(v - ref_state[key]).max())
+        assert d <= 2e-5, (key, d)
+    trunk = [k for k in ref_state if k.startswith("E.layers")]
+    assert trunk and all(np.array_equal(res[0][2][k], ref_state[k]) for k in trunk)      # the frozen-for-optE trunk did not move

@@ -39,19 +39,29 @@ def _state(sg):
     return {f"{n}.{k}": v.detach().clone() for n, net in (("G", sg.G), ("D", sg.D), ("E", sg.E)) for k, v in net.state_dict().items()}
 
 
-@pytest.mark.parametrize("tier,batch,k,steps", [("T", 4, 3, 5), ("F", 2, 2, 4)])
-def test_graph_replay_is_bit_identical_to_eager(tier, batch, k, steps):
+@pytest.mark.parametrize("tier,batch,k,steps,size,dtype", [("T", 4, 3, 5, 128, "fp32"), ("F", 2, 2, 4, 128, "fp32"),
+                                                          ("T256", 2, 2, 4, 256, "bf16")])     # configs[4]: 256x256 + bf16 + hipGraph
+def test_graph_replay_is_bit_identical_to_eager(tier, batch, k, steps, size, dtype):
+    from srgan_amd import ops
+    ops.set_compute_dtype(dtype)
+    try:
+        _graph_vs_eager(tier, batch, k, steps, size)
+    finally:
+        ops.set_compute_dtype("fp32")
+
+
+def _graph_vs_eager(tier, batch, k, steps, size):
     def hook(sg, s):
         if s == 3:                 # an epoch boundary: ExponentialLR moves lr on the host; the device record must follow
             sg.scheG.step(), sg.scheD.step(), sg.scheE.step()
 
     eager = _trainer(tier, batch, k, seed=2)
-    ref = _steps(eager, batch, 128, steps, 500, hook)
+    ref = _steps(eager, batch, size, steps, 500, hook)
     ref_state = _state(eager)
     ref_steps = {n: [st["step"] for st in opt.state.values()] for n, opt in (("G", eager.optG), ("D", eager.optD), ("E", eager.optE))}
 
     sg = _trainer(tier, batch, k, seed=2).enable_graph()
-    got = _steps(sg, batch, 128, steps, 500, hook)
+    got = _steps(sg, batch, size, steps, 500, hook)
     assert sg.graph_active
     np.testing.assert_array_equal(got, ref)                      # losses and every loss term, all steps
     for key, v in _state(sg).items():
@@ -59,7 +69,7 @@ def test_graph_replay_is_bit_identical_to_eager(tier, batch, k, steps):
     for n, opt in (("G", sg.optG), ("D", sg.optD), ("E", sg.optE)):
         assert [st["step"] for st in opt.state.values()] == ref_steps[n]     # host-side counters follow the replays
     # the tensors the notebooks read after a step are live views of the graph's memory
-    assert sg.target_image.shape == (batch, 3, 128, 128) and sg.recon_image.shape == (batch, 3, 128, 128)
+    assert sg.target_image.shape == (batch, 3, size, size) and sg.recon_image.shape == (batch, 3, size, size)
     assert torch.isfinite(sg.recon_image).all()
 
 
