@@ -126,16 +126,18 @@ __global__ __launch_bounds__(512) void wino43_input_kernel(WinoParams p, float* 
 // wave over the banks) and transforms it from there as wino43_input_kernel does: thread = (tile, 4 channels), 36 ds_read_b128
 // (out-of-image taps are zeros: the padding applies to h), B^T d B in registers, 36 16-byte stores in the multiply kernel's
 // LDS image order.  Reads 1 x and writes 2.25 x the tensor instead of (1 + 1) + (1 + 2.25) x, one launch instead of two.
-// 64 tiles per image = one tile block, so m_tile = image and channel group = slab.
-constexpr int NV_LD = 36;
+// 64 tiles per image = one tile block, so m_tile = image; a 16-channel slab = two 8-channel chunks of the V image.
+// 16-channel slabs, 256 threads (4 lanes per pixel), 64 KB of LDS: two workgroups share a CU, so one's load / reduce phases
+// overlap the other's transform / store phases (a 32-channel, 512-thread, 148 KB version measured the same: ~29 us per launch at
+// batch 32 = 3.7 TB/s).  Unpadded 64-byte LDS rows: the 8 tiles of a wave collide on 16 banks, ~1 us of the launch.
 template <int NW>
-__device__ __forceinline__ f32x4 slab_sum43(f32x4 v, f32x4 (*sh)[8], int q, int wave) {
+__device__ __forceinline__ f32x4 slab_sum43_q4(f32x4 v, f32x4 (*sh)[4], int q, int wave) {
 #pragma unroll
-  for (int o = 8; o < 64; o <<= 1)
+  for (int o = 4; o < 64; o <<= 1)
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
   __syncthreads();
-  if ((threadIdx.x & 63) < 8) sh[wave][q] = v;
+  if ((threadIdx.x & 63) < 4) sh[wave][q] = v;
   __syncthreads();
   f32x4 t = sh[0][q];
 #pragma unroll
@@ -143,23 +145,22 @@ __device__ __forceinline__ f32x4 slab_sum43(f32x4 v, f32x4 (*sh)[8], int q, int 
   return t;
 }
 
-__global__ __launch_bounds__(512) void in_fwd_slab_v_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, float* __restrict__ mean,
-                                                            float* __restrict__ rstd, float* __restrict__ vimg, int N, int C,
-                                                            float eps, int act, float slope) {
-  constexpr int HW = 1024, R = 16;
-  __shared__ __attribute__((aligned(16))) float hb[HW * NV_LD];
-  __shared__ f32x4 sh[8][8];
-  const int tid = threadIdx.x, q = tid & 7, ty = tid >> 3, wave = tid >> 6, lane = tid & 63;
-  // XCD-aware order (see in_fwd_slab): the 8 channel slabs of one image run back to back on one XCD
-  const int nslab = C / 32;
+__global__ __launch_bounds__(256, 2) void in_fwd_slab_v16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, float* __restrict__ mean,
+                                                                 float* __restrict__ rstd, float* __restrict__ vimg, int N, int C,
+                                                                 float eps, int act, float slope) {
+  constexpr int HW = 1024, R = 16, LD = 16;
+  __shared__ __attribute__((aligned(16))) float hb[HW * LD];
+  __shared__ f32x4 sh[4][4];
+  const int tid = threadIdx.x, q = tid & 3, ty = tid >> 2, wave = tid >> 6, lane = tid & 63;
+  const int nslab = C / 16;
   int slab, n;
   {
     const int L = blockIdx.x;
     if ((N & 7) == 0) { const int xcd = L & 7, k = L >> 3; slab = k % nslab; n = (k / nslab) * 8 + xcd; }
     else { slab = L % nslab; n = L / nslab; }
   }
-  const int c = slab * 32 + q * 4;
+  const int c = slab * 16 + q * 4;
   const size_t base = (size_t)n * HW * C + c;
   f32x4 v[R];
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -169,14 +170,14 @@ __global__ __launch_bounds__(512) void in_fwd_slab_v_kernel(const float* __restr
     s += v[j];
   }
   const float inv = 1.f / (float)HW;
-  const f32x4 mu = slab_sum43<8>(s, sh, q, wave) * inv;
+  const f32x4 mu = slab_sum43_q4<4>(s, sh, q, wave) * inv;
   f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const f32x4 d = v[j] - mu;
     m2 += d * d;
   }
-  const f32x4 var = slab_sum43<8>(m2, sh, q, wave) * inv;
+  const f32x4 var = slab_sum43_q4<4>(m2, sh, q, wave) * inv;
   f32x4 rs;
 #pragma unroll
   for (int e = 0; e < 4; ++e) rs[e] = 1.0f / sqrtf(var[e] + eps);
@@ -192,14 +193,14 @@ __global__ __launch_bounds__(512) void in_fwd_slab_v_kernel(const float* __restr
   }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
-    f32x4 o = ((v[j] - mu) * rs) * sc + sf;                 // the expression of in_fwd_slab / in_apply / the backward's mask
+    f32x4 o = ((v[j] - mu) * rs) * sc + sf;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = apply_act(o[e], act, slope);
-    *reinterpret_cast<f32x4*>(&hb[(ty + 64 * j) * NV_LD + q * 4]) = o;
+    *reinterpret_cast<f32x4*>(&hb[(ty + 64 * j) * LD + q * 4]) = o;
   }
   __syncthreads();
-  // transform role: tile tl of the image (8 x 8 tiles of 4 x 4 pixels), channel quad
-  const int quad = lane & 7, tl = wave * 8 + (lane >> 3);
+  // transform role: thread = (tile, channel quad of the 16): 64 tiles x 4 quads
+  const int quad = lane & 3, tl = wave * 16 + (lane >> 2);
   const int Y = 4 * (tl >> 3), X = 4 * (tl & 7);
   f32x4 d[6][6];
 #pragma unroll
@@ -208,12 +209,12 @@ __global__ __launch_bounds__(512) void in_fwd_slab_v_kernel(const float* __restr
     for (int cc = 0; cc < 6; ++cc) {
       const int yy = Y - 1 + r, xx = X - 1 + cc;
       const bool ok = (unsigned)yy < 32u && (unsigned)xx < 32u;
-      d[r][cc] = ok ? *reinterpret_cast<const f32x4*>(&hb[(yy * 32 + xx) * NV_LD + quad * 4]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      d[r][cc] = ok ? *reinterpret_cast<const f32x4*>(&hb[(yy * 32 + xx) * LD + quad * 4]) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
   for (int cc = 0; cc < 6; ++cc) bt6(d[0][cc], d[1][cc], d[2][cc], d[3][cc], d[4][cc], d[5][cc]);
   const int nchunk = C / W4C;
-  float* out = vimg + ((size_t)n * nchunk + slab * 4 + (quad >> 1)) * W4BLK + (quad & 1) * 256 + tl * 4;
+  float* out = vimg + ((size_t)n * nchunk + slab * 2 + (quad >> 1)) * W4BLK + (quad & 1) * 256 + tl * 4;
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
     bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]);
@@ -224,8 +225,8 @@ __global__ __launch_bounds__(512) void in_fwd_slab_v_kernel(const float* __restr
 
 int in_fwd_slab_v_launch(const float* x, const float* scale, const float* shift, float* mean, float* rstd, float* vimg, int N,
                          int C, float eps, int act, float slope, hipStream_t st) {
-  hipLaunchKernelGGL(in_fwd_slab_v_kernel, dim3((unsigned)(N * (C / 32))), dim3(512), 0, st, x, scale, shift, mean, rstd, vimg, N, C,
-                     eps, act, slope);
+  hipLaunchKernelGGL(in_fwd_slab_v16_kernel, dim3((unsigned)(N * (C / 16))), dim3(256), 0, st, x, scale, shift, mean, rstd, vimg, N,
+                       C, eps, act, slope);
   return check_launch("in_fwd_slab_v_kernel");
 }
 
