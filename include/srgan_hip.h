@@ -85,6 +85,22 @@ int srgan_instnorm_fwd_v(const srgan_conv_desc* d, const float* x, const float* 
                          float* rstd, void* v_image, size_t v_bytes, float eps, int act, float slope, void* stream);
 int srgan_conv2d_fwd_from_v(const srgan_conv_desc* d, const void* v_image, const void* packed, const float* bias, float* y,
                             int act, float slope, void* stream);
+/* The backward counterpart.  `d` describes a convolution whose OUTPUT y is normalised (y -> (CB)IN -> activation): the gradient
+ * dy w.r.t. y, produced by the norm's backward, is read by exactly two kernels -- the convolution's input gradient and its
+ * F(4x4,3x3) weight gradient -- each through a transform.  srgan_instnorm_bwd_vz = srgan_instnorm_bwd (same dscale / dshift,
+ * same dy values) that writes those two transforms instead of dy: v_image (srgan_conv2d_packed_scratch(d, 1) bytes) for
+ * srgan_conv2d_dgrad_from_v (multiply + output transform, optional skip-path gradient `res` as in ..._dgrad_packed_add), z_image
+ * (srgan_instnorm_bwd_vz_z_bytes(d) bytes) for srgan_conv2d_wgrad_vz (with the V image the forward kept).  x = y (the conv
+ * output the forward normalised), dy = gradient w.r.t. the norm's output. */
+int srgan_instnorm_bwd_vz_applicable(const srgan_conv_desc* d);
+size_t srgan_instnorm_bwd_vz_z_bytes(const srgan_conv_desc* d);
+int srgan_instnorm_bwd_vz(const srgan_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
+                          const float* mean, const float* rstd, float* dscale, float* dshift, void* v_image, size_t v_bytes,
+                          void* z_image, size_t z_bytes, int act, float slope, void* stream);
+int srgan_conv2d_dgrad_from_v(const srgan_conv_desc* d, const void* v_image, const void* packed, const float* res, float* dx,
+                              void* stream);
+int srgan_conv2d_wgrad_vz(const srgan_conv_desc* d, const float* v_image, const float* z_image, float* dw, void* ws,
+                          size_t ws_bytes, void* stream);
 /* dx = (input gradient of the convolution) + res: SingleResidualBlock (model.py:196-201) feeds its input to its first
  * convolution AND to the skip connection, so the gradient of the block input is the sum of the two paths; handing the skip
  * path's gradient to the convolution's input-gradient kernel (added in the F(4x4,3x3) epilogue; one in-place pass on the other

@@ -106,7 +106,12 @@ int in_fwd_slab_v_launch(const float* x, const float* scale, const float* shift,
 // F(4x4,3x3) weight gradient from the forward's V image (conv_wino43.hip; geometry and dispatch in conv_wino.hip)
 struct Wino43WgradGeom { int NB, H, W, C, O, ntc, splits, chunks_per_split; size_t v_bytes, z_bytes, slab_bytes; };
 bool wino43_wgrad_geometry(const srgan_conv_desc* d, Wino43WgradGeom* g);      // false: not applicable
-int wino43_wgrad_launch(const Wino43WgradGeom& g, const float* vimg, const float* dy, float* zimg, float* slab, double flops, hipStream_t st);
+int wino43_wgrad_launch(const Wino43WgradGeom& g, const float* vimg, const float* dy, float* zimg, float* slab, double flops, hipStream_t st, bool z_ready = false);
+// instance-norm backward of a 32x32 map writing the two F(4x4,3x3) transforms of its result instead of the result (conv_wino43.hip)
+int in_bwd_slab_vz_launch(const float* x, const float* gup, const float* scale, const float* shift, const float* mean,
+                          const float* rstd, float* dscale, float* dshift, float* vimg, float* zimg, int N, int C, int act,
+                          float slope, hipStream_t st);
+bool wino43_dgrad_applicable(const srgan_conv_desc* d);    // the input gradient of d runs on F(4x4,3x3)
 // conv_wino.hip: Winograd F(2x2,3x3) for 3x3 stride-1 pad-1 layers; kind 0 = forward, 1 = input gradient
 bool wino_applicable(const srgan_conv_desc* d, int kind);
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind);

@@ -1603,6 +1603,46 @@ extern "C" int srgan_conv2d_fwd_from_v(const srgan_conv_desc* d, const void* v_i
                   as_stream(stream), nullptr, nullptr, true);
 }
 
+// ---- instance-norm backward feeding the F(4x4,3x3) input-gradient and weight-gradient kernels of the preceding convolution ----
+// d describes that convolution (its OUTPUT is what the norm normalises).
+extern "C" int srgan_instnorm_bwd_vz_applicable(const srgan_conv_desc* d) {
+  if (validate(d) != 0) return 0;
+  Wino43WgradGeom g{};
+  const DgradGeom dg = dgrad_geometry(d);
+  return d->Ho == 32 && d->Wo == 32 && d->Hi == 32 && d->Wi == 32 && d->O % 32 == 0 && d->kh == 3 && d->stride == 1 && d->pad == 1 &&
+         d->pad_mode == SRGAN_PAD_ZERO && dg.wino && !dg.reflect && wino43_dgrad_applicable(d) && wino43_wgrad_geometry(d, &g) ? 1 : 0;
+}
+
+extern "C" size_t srgan_instnorm_bwd_vz_z_bytes(const srgan_conv_desc* d) {
+  if (validate(d) != 0) return 0;
+  Wino43WgradGeom g{};
+  return wino43_wgrad_geometry(d, &g) ? g.z_bytes : 0;
+}
+
+extern "C" int srgan_instnorm_bwd_vz(const srgan_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
+                                     const float* mean, const float* rstd, float* dscale, float* dshift, void* v_image, size_t v_bytes,
+                                     void* z_image, size_t z_bytes, int act, float slope, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(x && dy && mean && rstd && dscale && dshift && v_image && z_image, "instnorm_bwd_vz: null pointer");
+  SRGAN_REQUIRE((scale == nullptr) == (shift == nullptr), "instnorm_bwd_vz: scale and shift go together");
+  SRGAN_REQUIRE(srgan_instnorm_bwd_vz_applicable(d), "instnorm_bwd_vz: layer not applicable");
+  SRGAN_REQUIRE(v_bytes >= srgan_conv2d_packed_scratch(d, 1) && z_bytes >= srgan_instnorm_bwd_vz_z_bytes(d),
+                "instnorm_bwd_vz: image buffers too small (srgan_conv2d_packed_scratch(d, 1), srgan_instnorm_bwd_vz_z_bytes)");
+  return in_bwd_slab_vz_launch(x, dy, scale, shift, mean, rstd, dscale, dshift, static_cast<float*>(v_image),
+                               static_cast<float*>(z_image), d->N, d->O, act, slope, as_stream(stream));
+}
+
+extern "C" int srgan_conv2d_dgrad_from_v(const srgan_conv_desc* d, const void* v_image, const void* packed, const float* res,
+                                         float* dx, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(v_image && packed && dx, "conv2d_dgrad_from_v: null pointer");
+  SRGAN_REQUIRE(res != dx, "conv2d_dgrad_from_v: res must not alias dx");
+  const DgradGeom dg = dgrad_geometry(d);
+  SRGAN_REQUIRE(dg.wino && !dg.reflect && wino43_dgrad_applicable(d), "conv2d_dgrad_from_v: the input gradient does not run on F(4x4,3x3)");
+  return wino_run(d, 1, nullptr, (const float*)packed, nullptr, dx, SRGAN_ACT_NONE, 0.f,
+                  const_cast<float*>(static_cast<const float*>(v_image)), as_stream(stream), res, nullptr, true);
+}
+
 extern "C" int srgan_conv2d_dgrad_packed_add(const srgan_conv_desc* d, const float* dy, const void* packed, const float* res,
                                              float* dx, void* ws, size_t ws_bytes, void* stream) {
   if (int e = validate(d)) return e;
@@ -1641,6 +1681,22 @@ extern "C" int srgan_conv2d_wgrad_v(const srgan_conv_desc* d, const float* v_ima
   WgradPlan w = plan_wgrad(d);
   w.splits = g.splits; w.Cdpad = d->O; w.NNpad = 9 * d->I;
   return finish_wgrad(d, w, dy, dw, dbias, ws, st);
+}
+
+// The same with the Z image (A dy A^T) already written by srgan_instnorm_bwd_vz.
+extern "C" int srgan_conv2d_wgrad_vz(const srgan_conv_desc* d, const float* v_image, const float* z_image, float* dw, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(v_image && z_image && dw && ws, "conv2d_wgrad_vz: null pointer");
+  SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_wgrad_vz: workspace too small");
+  Wino43WgradGeom g{};
+  SRGAN_REQUIRE(wino43_wgrad_geometry(d, &g), "conv2d_wgrad_vz: layer not applicable");
+  hipStream_t st = as_stream(stream);
+  if (int e = wino43_wgrad_launch(g, v_image, nullptr, const_cast<float*>(z_image), (float*)ws, conv_flops(d), st, true)) return e;
+  if (int e = check_launch("wino43_wgrad_kernel")) return e;
+  WgradPlan w = plan_wgrad(d);
+  w.splits = g.splits; w.Cdpad = d->O; w.NNpad = 9 * d->I;
+  return finish_wgrad(d, w, nullptr, dw, nullptr, ws, st);
 }
 
 namespace srgan {

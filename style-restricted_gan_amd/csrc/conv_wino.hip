@@ -845,6 +845,7 @@ int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hi
 // `res` (optional): added to the result in the epilogue where the kernel supports it (F(4x4,3x3)); *res_done tells the caller
 // whether it was, so that it can add the tensor itself otherwise
 bool wino43_fwd_applicable(const srgan_conv_desc* d) { return wino_variant(d, 0) == 3; }
+bool wino43_dgrad_applicable(const srgan_conv_desc* d) { return d->pad_mode == SRGAN_PAD_ZERO && wino_variant(d, 1) == 3; }
 
 int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst,
              int act, float slope, float* scratch, hipStream_t st, const float* res, bool* res_done, bool v_ready) {

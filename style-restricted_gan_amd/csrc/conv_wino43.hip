@@ -230,6 +230,138 @@ int in_fwd_slab_v_launch(const float* x, const float* scale, const float* shift,
   return check_launch("in_fwd_slab_v_kernel");
 }
 
+// ---- instance-norm BACKWARD writing both transforms of its result (32x32 maps, residual trunk) ----
+// dy = gradient w.r.t. the output of a convolution c that is followed by (CB)IN (+ activation).  dy has exactly two readers: c's
+// input-gradient kernel (through B^T dy B, the V image of the transposed problem) and c's F(4x4,3x3) weight gradient (through
+// Z = A dy A^T).  So dy is never written: the slab kernel of in_bwd_slab (x-hat and the masked upstream gradient in registers,
+// two plane sums, dy = rstd * scale * (g - mean(g) - x-hat * mean(g x-hat))) parks dy in LDS and writes BOTH images from there,
+// in the layouts wino43_input_kernel and wino43_dy_kernel produce.  Reads x, g (2x) and writes 2.25x + 2.25x the tensor instead
+// of [2 + 1] + [1 + 2.25] + [1 + 2.25]; one launch instead of three.
+__global__ __launch_bounds__(256, 2) void in_bwd_slab_vz_kernel(const float* __restrict__ x, const float* __restrict__ gup,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                float* __restrict__ dscale, float* __restrict__ dshift,
+                                                                float* __restrict__ vimg, float* __restrict__ zimg, int N, int C,
+                                                                int act, float slope) {
+  constexpr int HW = 1024, R = 16, LD = 16;
+  __shared__ __attribute__((aligned(16))) float hb[HW * LD];
+  __shared__ f32x4 sh[4][4];
+  const int tid = threadIdx.x, q = tid & 3, ty = tid >> 2, wave = tid >> 6, lane = tid & 63;
+  const int nslab = C / 16;
+  int slab, n;
+  {
+    const int L = blockIdx.x;
+    if ((N & 7) == 0) { const int xcd = L & 7, k = L >> 3; slab = k % nslab; n = (k / nslab) * 8 + xcd; }
+    else { slab = L % nslab; n = L / nslab; }
+  }
+  const int c = slab * 16 + q * 4;
+  const int nc = n * C + c;
+  const size_t base = (size_t)n * HW * C + c;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + nc), rs = *reinterpret_cast<const f32x4*>(rstd + nc);
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+  if (scale) {
+    sc = *reinterpret_cast<const f32x4*>(scale + nc);
+    sf = *reinterpret_cast<const f32x4*>(shift + nc);
+  }
+  {
+    f32x4 xh[R], g[R];
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int r = ty + 64 * j;
+      xh[j] = (*reinterpret_cast<const f32x4*>(x + base + (size_t)r * C) - mu) * rs;
+      g[j] = *reinterpret_cast<const f32x4*>(gup + base + (size_t)r * C);
+      const f32x4 z = xh[j] * sc + sf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[j][e] *= act_grad(z[e], act, slope);
+      a += g[j];
+      b += g[j] * xh[j];
+    }
+    a = slab_sum43_q4<4>(a, sh, q, wave);
+    b = slab_sum43_q4<4>(b, sh, q, wave);
+    if (ty == 0) {
+      *reinterpret_cast<f32x4*>(dshift + nc) = a;
+      *reinterpret_cast<f32x4*>(dscale + nc) = b;
+    }
+    const float inv_hw = 1.f / (float)HW;
+    const f32x4 mg = a * inv_hw, mgx = b * inv_hw, k = rs * sc;
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      *reinterpret_cast<f32x4*>(&hb[(ty + 64 * j) * LD + q * 4]) = k * (g[j] - mg - xh[j] * mgx);     // = in_bwd_slab's dx
+  }
+  __syncthreads();
+  // (1) V image of the transposed problem (the input-gradient kernel's B operand): as in_fwd_slab_v16_kernel
+  {
+    const int quad = lane & 3, tl = wave * 16 + (lane >> 2);
+    const int Y = 4 * (tl >> 3), X = 4 * (tl & 7);
+    f32x4 d[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) {
+        const int yy = Y - 1 + r, xx = X - 1 + cc;
+        const bool ok = (unsigned)yy < 32u && (unsigned)xx < 32u;
+        d[r][cc] = ok ? *reinterpret_cast<const f32x4*>(&hb[(yy * 32 + xx) * LD + quad * 4]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) bt6(d[0][cc], d[1][cc], d[2][cc], d[3][cc], d[4][cc], d[5][cc]);
+    const int nchunk = C / W4C;
+    float* out = vimg + ((size_t)n * nchunk + slab * 2 + (quad >> 1)) * W4BLK + (quad & 1) * 256 + tl * 4;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]);
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) *reinterpret_cast<f32x4*>(out + (r * 6 + cc) * 512) = d[r][cc];
+    }
+  }
+  // (2) Z = A dy A^T in the A-operand register image of wino43_wgrad_kernel: [32-o block][8-tile chunk][36][lane = half * 32 + o][4 tiles]
+  //     thread = (channel o16 of the slab, tile half lh, tile chunk tc of the image): 4 tiles each
+  {
+    const int o16 = tid & 15, lh = (tid >> 4) & 1, tc = tid >> 5;
+    float z[36][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = tc * 8 + lh * 4 + j;
+      const int Y = 4 * (t >> 3), X = 4 * (t & 7);
+      float e[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) e[a][b] = hb[((Y + a) * 32 + X + b) * LD + o16];
+      float h[6][4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float v0 = e[0][b], v1 = e[1][b], v2 = e[2][b], v3 = e[3][b];
+        const float s02 = v0 + v2, s13 = v1 + v3, q02 = v0 + 4.f * v2, q13 = 2.f * v1 + 8.f * v3;
+        h[0][b] = v0; h[1][b] = s02 + s13; h[2][b] = s02 - s13; h[3][b] = q02 + q13; h[4][b] = q02 - q13; h[5][b] = v3;
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const float v0 = h[r][0], v1 = h[r][1], v2 = h[r][2], v3 = h[r][3];
+        const float s02 = v0 + v2, s13 = v1 + v3, q02 = v0 + 4.f * v2, q13 = 2.f * v1 + 8.f * v3;
+        z[r * 6 + 0][j] = v0; z[r * 6 + 1][j] = s02 + s13; z[r * 6 + 2][j] = s02 - s13;
+        z[r * 6 + 3][j] = q02 + q13; z[r * 6 + 4][j] = q02 - q13; z[r * 6 + 5][j] = v3;
+      }
+    }
+    const int ntc = N * 8;
+    const int zlane = lh * 32 + (slab & 1) * 16 + o16;
+    float* out = zimg + ((size_t)((slab >> 1) * ntc + n * 8 + tc) * 36) * 256 + zlane * 4;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+      const f32x4 v = {z[k][0], z[k][1], z[k][2], z[k][3]};
+      *reinterpret_cast<f32x4*>(out + k * 256) = v;
+    }
+  }
+}
+
+int in_bwd_slab_vz_launch(const float* x, const float* gup, const float* scale, const float* shift, const float* mean,
+                          const float* rstd, float* dscale, float* dshift, float* vimg, float* zimg, int N, int C, int act,
+                          float slope, hipStream_t st) {
+  hipLaunchKernelGGL(in_bwd_slab_vz_kernel, dim3((unsigned)(N * (C / 16))), dim3(256), 0, st, x, gup, scale, shift, mean, rstd, dscale,
+                     dshift, vimg, zimg, N, C, act, slope);
+  return check_launch("in_bwd_slab_vz_kernel");
+}
+
 // ---- multiply + output transform ----
 // WinoParams as in conv_wino.hip with TH = Ho / 4, TW = Wo / 4, n_tiles = Cd / 32, nchunk = C / 8, pad = 1;
 // u = [n_tiles][nchunk][36 pos][64 lanes][4]: lane (lr, lh) holds output channel lr, reduce channels 4 lh .. 4 lh + 3.
@@ -679,11 +811,11 @@ int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops
 
 // Weight gradient from the forward's V image.  g: geometry from wino43_wgrad_geometry (conv_wino.hip); zimg: Z scratch.
 int wino43_wgrad_launch(const Wino43WgradGeom& g, const float* vimg, const float* dy, float* zimg, float* slab, double flops,
-                        hipStream_t st) {
+                        hipStream_t st, bool z_ready) {
   Wino43DyParams q{};
   q.dy = dy; q.zimg = zimg; q.NB = g.NB; q.H = g.H; q.W = g.W; q.O = g.O; q.TH = g.H / 4; q.TW = g.W / 4;
   q.T = g.NB * q.TH * q.TW; q.ntc = g.ntc; q.o_blocks = g.O / 32;
-  {
+  if (!z_ready) {      // z_ready: in_bwd_slab_vz_kernel already wrote Z
     ProfToken tok = prof_begin(23, 0.0, st);
     hipLaunchKernelGGL(wino43_dy_kernel, dim3((unsigned)ceil_div((long long)q.ntc * q.o_blocks, 8)), dim3(512), 0, st, q);
     prof_end(tok, st);

@@ -39,6 +39,11 @@ SIGNATURES = {
     "srgan_instnorm_conv_v_applicable": (c_int, [_DESC]),
     "srgan_instnorm_fwd_v": (c_int, [_DESC, P, P, P, P, P, P, c_size_t, c_float, c_int, c_float, P]),
     "srgan_conv2d_fwd_from_v": (c_int, [_DESC, P, P, P, P, c_int, c_float, P]),
+    "srgan_instnorm_bwd_vz_applicable": (c_int, [_DESC]),
+    "srgan_instnorm_bwd_vz_z_bytes": (c_size_t, [_DESC]),
+    "srgan_instnorm_bwd_vz": (c_int, [_DESC, P, P, P, P, P, P, P, P, P, c_size_t, P, c_size_t, c_int, c_float, P]),
+    "srgan_conv2d_dgrad_from_v": (c_int, [_DESC, P, P, P, P, P]),
+    "srgan_conv2d_wgrad_vz": (c_int, [_DESC, P, P, P, P, c_size_t, P]),
     "srgan_conv2d_wgrad": (c_int, [_DESC, P, P, P, P, P, c_size_t, P]),
     "srgan_conv2d_wgrad_v_bytes": (c_size_t, [_DESC]),
     "srgan_conv2d_wgrad_v": (c_int, [_DESC, P, P, P, P, P, c_size_t, P]),

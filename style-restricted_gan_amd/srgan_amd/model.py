@@ -178,6 +178,14 @@ class SingleResidualBlock(nn.Module):
 
     def forward(self, x):
         data, con = x[0], x[1]
+        if data.is_cuda and isinstance(self.cn1, CBINorm2d) and self.cn1.affine:
+            s1, h1 = self.cn1.scale_shift(con, data.device)
+            s2, h2 = self.cn2.scale_shift(con, data.device)
+            if ops.res_block_fusable(data, self.c1.weight, self.c2.weight, s1, s2):
+                # the whole block as one autograd node: neither the normalised activation nor the gradients w.r.t. the two
+                # conv outputs are ever written (ops._ResBlockFn)
+                self.cn1._check_input_dim(data)
+                return ops.residual_block(data, s1, h1, s2, h2, self.c1.weight, self.c2.weight, self.cn1.eps), con
         # the block input feeds c1 and the skip connection: conv2d_skip routes the skip path's gradient into c1's
         # input-gradient kernel (added in its epilogue) instead of a separate accumulation pass
         y1, skip = ops.conv2d_skip(data, self.c1.weight, None, self.c1.stride[0], self.c1.padding[0], PAD_ZERO)

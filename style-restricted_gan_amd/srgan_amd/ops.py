@@ -619,6 +619,128 @@ class _NormActConvFn(Function):
         return dx, dscale, dshift, dw, None, None, None
 
 
+class _ResBlockFn(Function):
+    """SingleResidualBlock (pyfiles/model.py:196-201) as ONE autograd node on 32x32 maps whose convolutions run on F(4x4,3x3):
+
+        y1 = c1(x);  y2 = c2(relu(cbin1(y1)));  out = cbin2(y2) + x
+
+    Forward: c1 keeps its transformed input V0; cbin1 + ReLU is written straight as c2's transformed input V1
+    (``srgan_instnorm_fwd_v``); cbin2 + skip in the slab norm kernel.  Backward: each norm backward writes the two transforms of
+    its result -- the input-gradient kernel's image and the weight-gradient kernel's Z image -- instead of the result
+    (``srgan_instnorm_bwd_vz``), the multiplies run on them (``srgan_conv2d_dgrad_from_v`` / ``srgan_conv2d_wgrad_vz`` with V1 /
+    V0), and the skip path's gradient is added in c1's input-gradient epilogue.  Six launches fewer than the chain and the
+    gradients w.r.t. y1 / y2 are never written or re-read.  Weights are held by reference and read at backward time (stale-graph
+    semantics of SURVEY.md Appendix C-1), the packed operands come from the packed-weight scope."""
+
+    @staticmethod
+    def forward(ctx, x, s1, h1, s2, h2, w1, w2, eps):
+        lib = _lib.load()
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        dev = x.device
+        d1 = _conv_desc(n, h, w, c, h, w, w1.shape[0], 3, 3, 1, 1, PAD_ZERO, w1)
+        d2 = _conv_desc(n, h, w, w1.shape[0], h, w, w2.shape[0], 3, 3, 1, 1, PAD_ZERO, w2)
+        need_w = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
+        hit1, sc1 = _packed(d1, w1, 0, ACT_NONE)
+        hit2, sc2 = _packed(d2, w2, 0, ACT_NONE)
+        v0 = torch.empty(max(sc1, 16), dtype=torch.uint8, device=dev) if need_w else workspace(dev, sc1)
+        y1 = nhwc_empty(n, w1.shape[0], h, w, dev)
+        _lib.check(lib.srgan_conv2d_fwd_packed(ctypes.byref(d1), _ptr(x), _ptr(hit1.buf), None, _ptr(y1), ACT_NONE, 0.0, _ptr(v0), sc1,
+                                               _stream()), "conv2d_fwd_packed")
+        v1 = torch.empty(max(sc2, 16), dtype=torch.uint8, device=dev) if need_w else workspace(dev, sc2)
+        c1 = w1.shape[0]
+        mean1 = torch.empty(n * c1, dtype=torch.float32, device=dev)
+        rstd1 = torch.empty_like(mean1)
+        _lib.check(lib.srgan_instnorm_fwd_v(ctypes.byref(d2), _ptr(y1), _ptr(s1), _ptr(h1), _ptr(mean1), _ptr(rstd1), _ptr(v1), sc2,
+                                            float(eps), ACT_RELU, 0.0, _stream()), "instnorm_fwd_v")
+        y2 = nhwc_empty(n, w2.shape[0], h, w, dev)
+        _lib.check(lib.srgan_conv2d_fwd_from_v(ctypes.byref(d2), _ptr(v1), _ptr(hit2.buf), None, _ptr(y2), ACT_NONE, 0.0, _stream()),
+                   "conv2d_fwd_from_v")
+        c2 = w2.shape[0]
+        out = torch.empty_like(y2)
+        mean2 = torch.empty(n * c2, dtype=torch.float32, device=dev)
+        rstd2 = torch.empty_like(mean2)
+        nb = lib.srgan_instnorm_workspace(n, h * w, c2)
+        ws = workspace(dev, nb)
+        _lib.check(lib.srgan_instnorm_fwd(_ptr(y2), _ptr(s2), _ptr(h2), _ptr(x), _ptr(out), _ptr(mean2), _ptr(rstd2), n, h * w, c2,
+                                          float(eps), ACT_NONE, 0.0, _ptr(ws), nb, _stream()), "instnorm_fwd")
+        ctx.d1, ctx.d2, ctx.w1, ctx.w2 = d1, d2, w1, w2
+        ctx.v0, ctx.v1 = (v0, v1) if need_w else (None, None)
+        ctx.save_for_backward(y1, y2, s1, h1, s2, h2, mean1, rstd1, mean2, rstd2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        y1, y2, s1, h1, s2, h2, mean1, rstd1, mean2, rstd2 = ctx.saved_tensors
+        g = to_nhwc(g)
+        n, c2, h, w = y2.shape
+        c1 = y1.shape[1]
+        dev = g.device
+        d1, d2, w1, w2 = ctx.d1, ctx.d2, ctx.w1, ctx.w2
+        st = _stream()
+
+        def norm_bwd_vz(desc, y, gup, sc, sh, mean, rstd, act, ch):
+            vb = lib.srgan_conv2d_packed_scratch(ctypes.byref(desc), 1)
+            zb = lib.srgan_instnorm_bwd_vz_z_bytes(ctypes.byref(desc))
+            vimg = torch.empty(vb, dtype=torch.uint8, device=dev)
+            zimg = torch.empty(zb, dtype=torch.uint8, device=dev)
+            dsc = torch.empty(n, ch, dtype=torch.float32, device=dev)
+            dsh = torch.empty_like(dsc)
+            _lib.check(lib.srgan_instnorm_bwd_vz(ctypes.byref(desc), _ptr(y), _ptr(gup), _ptr(sc), _ptr(sh), _ptr(mean), _ptr(rstd),
+                                                 _ptr(dsc), _ptr(dsh), _ptr(vimg), vb, _ptr(zimg), zb, act, 0.0, st), "instnorm_bwd_vz")
+            return vimg, zimg, dsc, dsh
+
+        def wgrad_vz(desc, weight, v_fwd, zimg):
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+            dd = ConvDesc.from_buffer_copy(desc)
+            dd.sO, dd.sI, dd.sH, dd.sW = dw.stride()
+            ws, nb = _conv_ws(dd, dev)
+            _lib.check(lib.srgan_conv2d_wgrad_vz(ctypes.byref(dd), _ptr(v_fwd), _ptr(zimg), _ptr(dw), _ptr(ws), nb, st), "conv2d_wgrad_vz")
+            return dw
+
+        def dgrad_from_v(desc, weight, vimg, res, ch):
+            hit, _ = _packed(desc, weight, 1, ACT_NONE)
+            dx = nhwc_empty(n, ch, h, w, dev)
+            _lib.check(lib.srgan_conv2d_dgrad_from_v(ctypes.byref(desc), _ptr(vimg), _ptr(hit.buf), _ptr(res), _ptr(dx), st),
+                       "conv2d_dgrad_from_v")
+            return dx
+
+        # cbin2 backward -> c2's two images; c2 weight gradient (with V1) and input gradient
+        vimg, zimg, ds2, dh2 = norm_bwd_vz(d2, y2, g, s2, h2, mean2, rstd2, ACT_NONE, c2)
+        dw2 = wgrad_vz(d2, w2, ctx.v1, zimg) if (ctx.needs_input_grad[6] and ctx.v1 is not None) else None
+        dh = dgrad_from_v(d2, w2, vimg, None, c1)
+        # cbin1 + ReLU backward -> c1's two images; c1 weight gradient (with V0); input gradient + the skip path's gradient
+        vimg, zimg, ds1, dh1 = norm_bwd_vz(d1, y1, dh, s1, h1, mean1, rstd1, ACT_RELU, c1)
+        dw1 = wgrad_vz(d1, w1, ctx.v0, zimg) if (ctx.needs_input_grad[5] and ctx.v0 is not None) else None
+        dx = dgrad_from_v(d1, w1, vimg, g, d1.I) if ctx.needs_input_grad[0] else None
+        return dx, ds1, dh1, ds2, dh2, dw1, dw2, None
+
+
+def res_block_fusable(x, w1, w2, s1, s2):
+    """True when ``residual_block`` applies: packed-weight scope, 32x32 map, affine (scale, shift) pairs present, both
+    convolutions 3x3 square-channel layers whose forward, input gradient and weight gradient all dispatch to F(4x4,3x3)."""
+    if not (_pack_cache_on and x.is_cuda and x.dim() == 4 and s1 is not None and s2 is not None):
+        return False
+    if _os.environ.get("SRGAN_NO_RESBLOCK_FUSION"):
+        return False
+    n, c, h, w = x.shape
+    if (h, w) != (32, 32) or tuple(w1.shape) != (c, c, 3, 3) or tuple(w2.shape) != (c, c, 3, 3):
+        return False
+    lib = _lib.load()
+    for wt in (w1, w2):
+        desc = _conv_desc(n, h, w, c, h, w, c, 3, 3, 1, 1, PAD_ZERO, wt)
+        if not (lib.srgan_instnorm_conv_v_applicable(ctypes.byref(desc)) and lib.srgan_instnorm_bwd_vz_applicable(ctypes.byref(desc))
+                and lib.srgan_conv2d_wgrad_v_bytes(ctypes.byref(desc))):
+            return False
+    return True
+
+
+def residual_block(x, s1, h1, s2, h2, w1, w2, eps=1e-5):
+    """cbin2(c2(relu(cbin1(c1(x))))) + x with (scale, shift) = (s1, h1), (s2, h2) -- see _ResBlockFn."""
+    return _ResBlockFn.apply(x, s1, h1, s2, h2, w1, w2, eps)
+
+
 def norm_act_conv_fusable(x, weight):
     """True when ``instance_norm_act_conv`` applies: packed-weight scope, 32x32 map, the conv dispatches to F(4x4,3x3)."""
     if not (_pack_cache_on and x.is_cuda and x.dim() == 4 and weight.dim() == 4 and weight.shape[2] == 3 and weight.shape[3] == 3):

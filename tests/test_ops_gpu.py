@@ -228,6 +228,52 @@ def test_instance_norm_act_conv_equals_the_unfused_chain(ops, n, c, o, affine):
         close(res["fused"][4], shr.grad, 2e-4)
 
 
+@pytest.mark.parametrize("n,c", [(32, 256), (4, 64), (3, 128)])
+def test_residual_block_fused_node_vs_chain_and_cpu(ops, n, c):
+    """ops.residual_block (one autograd node: V images in the forward, norm backwards writing the input-gradient / weight-gradient
+    transforms, skip gradient in the epilogue) against the chain of separate ops on the HIP path and against PyTorch-CPU:
+    output and all seven gradients."""
+    import os
+    torch.set_num_threads(16)
+    g = torch.Generator().manual_seed(41)
+    x = rnd(n, c, 32, 32, seed=41)
+    w1, w2 = rnd(c, c, 3, 3, seed=42) / np.sqrt(c * 9), rnd(c, c, 3, 3, seed=43) / np.sqrt(c * 9)
+    s1, s2 = torch.rand(n, c, generator=g) + 0.5, torch.rand(n, c, generator=g) + 0.5
+    h1, h2 = rnd(n, c, seed=44) * 0.3, rnd(n, c, seed=45) * 0.3
+    gy = rnd(n, c, 32, 32, seed=46)
+    os.environ["SRGAN_WINOGRAD_THRESHOLD_SCALE"] = "0"
+    res = {}
+    try:
+        for mode in ("fused", "chain"):
+            t = [v.cuda().requires_grad_(True) for v in (x, s1, h1, s2, h2, w1, w2)]
+            ops.invalidate_packed()
+            with ops.pack_cache():
+                if mode == "fused":
+                    assert ops.res_block_fusable(t[0], t[5], t[6], t[1], t[3])
+                    y = ops.residual_block(*t)
+                else:
+                    y1 = ops.conv2d(t[0], t[5], None, 1, 1)
+                    hh = ops.instance_norm_act(y1, t[1], t[2], None, ops.ACT_RELU)
+                    y2 = ops.conv2d(hh, t[6], None, 1, 1)
+                    y = ops.instance_norm_act(y2, t[3], t[4], t[0], ops.ACT_NONE)
+                y.backward(gy.cuda())
+            res[mode] = [y.detach()] + [v.grad for v in t]
+    finally:
+        os.environ.pop("SRGAN_WINOGRAD_THRESHOLD_SCALE", None)
+        ops.invalidate_packed()
+    for a, b in zip(res["fused"], res["chain"]):
+        close(a, b, 5e-5)
+    r = [v.clone().requires_grad_(True) for v in (x, s1, h1, s2, h2, w1, w2)]
+    y1 = F.conv2d(r[0], r[5], None, 1, 1)
+    hh = torch.relu(F.instance_norm(y1, eps=1e-5) * r[1][:, :, None, None] + r[2][:, :, None, None])
+    y2 = F.conv2d(hh, r[6], None, 1, 1)
+    yr = F.instance_norm(y2, eps=1e-5) * r[3][:, :, None, None] + r[4][:, :, None, None] + r[0]
+    yr.backward(gy)
+    close(res["fused"][0], yr, 1e-4)
+    for a, b in zip(res["fused"][1:], r):
+        close(a, b.grad, 3e-4)
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
