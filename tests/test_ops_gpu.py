@@ -270,8 +270,11 @@ def test_residual_block_fused_node_vs_chain_and_cpu(ops, n, c):
     yr = F.instance_norm(y2, eps=1e-5) * r[3][:, :, None, None] + r[4][:, :, None, None] + r[0]
     yr.backward(gy)
     close(res["fused"][0], yr, 1e-4)
-    for a, b in zip(res["fused"][1:], r):
-        close(a, b.grad, 3e-4)
+    # 8.4 M ReLU inputs at the largest size: a few lie within fp32 rounding of zero and take the other branch on the CPU (the HIP
+    # chain above, which shares the forward's rounding, agrees to 5e-5) -- flip-tolerant comparison, tests/common.py
+    from tests.common import close_grad
+    for name, a, b in zip(("dx", "ds1", "dh1", "ds2", "dh2", "dw1", "dw2"), res["fused"][1:], r):
+        close_grad(a, b.grad, 3e-4, what=name)
 
 
 def _bf16_round(t):
