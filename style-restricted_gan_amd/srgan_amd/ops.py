@@ -12,6 +12,7 @@ the reference's train step relies on, util_notebook.py:664-690); activations, no
 and the CBIN gamma copy are the forward-time values.
 """
 import ctypes
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -165,12 +166,30 @@ def graph_keepalive():
 
 
 class _Packed:
-    __slots__ = ("buf", "weight", "desc", "kind", "act", "version", "fresh", "ptr", "scratch")
+    """A cached packed operand.  The parameter is held WEAKLY: when a network is dropped (a notebook re-run, a sweep, the test
+    suite building many trainers) its entries die with it and are purged at the next scope entry, instead of pinning the weight,
+    its packed device buffer and a slot of every later refresh for the life of the process."""
+    __slots__ = ("buf", "_wref", "desc", "kind", "act", "version", "fresh", "ptr", "scratch")
 
     def __init__(self, buf, weight, desc, kind, act, scratch):
-        self.buf, self.weight, self.desc, self.kind, self.act = buf, weight, desc, kind, act
+        self.buf, self._wref, self.desc, self.kind, self.act = buf, weakref.ref(weight), desc, kind, act
         self.scratch = scratch                 # bytes of per-call scratch the packed run wants (shared workspace)
         self.version, self.fresh, self.ptr = weight._version, True, weight.data_ptr()
+
+    @property
+    def weight(self):
+        return self._wref()
+
+
+def _purge_dead_packed():
+    dead = [k for k, h in _pack_cache.items() if h.weight is None]
+    if not dead:
+        return
+    for k in dead:
+        del _pack_cache[k]
+    for k in [k for k, g in _geo_cache.items() if g[0].weight is None]:
+        del _geo_cache[k]
+    _tables.clear()
 
 
 class pack_cache:
@@ -185,6 +204,8 @@ class pack_cache:
         global _pack_cache_on
         self._prev = _pack_cache_on
         _pack_cache_on = True
+        if not self._prev:
+            _purge_dead_packed()
         if self._refresh and not self._prev and _pack_cache:
             # entries persist between scopes; a ``.data`` update made outside (no version bump) would go unseen, so the
             # whole cache is re-packed on entry -- one multi-pack launch
@@ -303,7 +324,7 @@ def refresh_packed(params, force=False):
     tab = _tables.get(tkey)
     if tab is None:
         ids = set(tkey)
-        hits = [h for k, h in _pack_cache.items() if k[0] in ids]
+        hits = [h for k, h in _pack_cache.items() if k[0] in ids and h.weight is not None]
         for h in hits:
             # the layout of an operand follows the kernel dispatch (compute mode, SRGAN_* switches): an entry made under another
             # dispatch gets a buffer of the size the current one wants before anything is packed into it

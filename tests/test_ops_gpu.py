@@ -277,6 +277,31 @@ def test_residual_block_fused_node_vs_chain_and_cpu(ops, n, c):
         close_grad(a, b.grad, 3e-4, what=name)
 
 
+def test_packed_cache_releases_dead_networks(ops):
+    """The packed-operand cache holds parameters weakly: operands of a network that no longer exists are dropped at the next
+    scope entry (they used to pin the weight, its packed buffer and a slot of every later refresh for the life of the process)."""
+    import gc
+    ops.invalidate_packed()
+    x = rnd(2, 32, 12, 12, seed=1).cuda()
+
+    def use(seed):
+        w = (rnd(64, 32, 3, 3, seed=seed) / 17).cuda().requires_grad_(True)
+        with ops.pack_cache():
+            ops.conv2d(x, w, None, 1, 1).sum().backward()
+        return w
+
+    w_live = use(2)
+    n_live = len(ops._pack_cache)
+    assert n_live >= 1                                   # the forward operand (x needs no gradient, so no input-gradient operand)
+    w_dead = use(3)
+    assert len(ops._pack_cache) == 2 * n_live
+    del w_dead
+    gc.collect()
+    with ops.pack_cache():
+        assert len(ops._pack_cache) == n_live and all(h.weight is w_live for h in ops._pack_cache.values())
+    ops.invalidate_packed()
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
