@@ -221,3 +221,24 @@ def test_notebook_cell_1_imports_resolve_through_the_compat_shims():
         "import torch", "t = torch.arange(4.0)", "assert cuda2numpy(t).tolist() == [0, 1, 2, 3] and cuda2cpu(t).device.type == 'cpu'"])
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_non_mse_class_criterion_leaves_the_fused_paths():
+    """The fused discriminator loss kernel is softmax + MSE.  Any other ``criterion_class`` must not be silently replaced by it:
+    the trainer then takes the generic path, whose loss helpers refuse criteria without a HIP kernel (05-train cell 13 passes
+    nn.MSELoss for both)."""
+    import torch.nn as nn
+    from srgan_amd import losses as hl, model
+    from srgan_amd.trainer import SRGAN_training
+    G = model.SingleGenerator(3, 4, 2, 2, 1, "instance", num_con=12)
+    D = model.SingleDiscriminator_solo_multi(3, 4, 2, 4, "instance", 4)
+    E = model.Encoder(3, 8, 4, 4, "instance", 4, "cpu")
+    lbd = {"class": 1.0, "cycle": 5.0, "idt": 5.0, "reg": 0.5, "idt_reg": 0.5, "KL": 0.0, "batch_KL": 0.0, "corr_enc": 0.0, "hist": 0.0}
+    ok = SRGAN_training([G, D, E], [None, None, None], [nn.MSELoss(), nn.MSELoss()], lbd, 1, "cpu", np.eye(4), 4, "mu", 8)
+    assert ok._class_is_mse() and ok._fused_paths()
+    for crit in (nn.L1Loss(), nn.MSELoss(reduction="sum"), nn.CrossEntropyLoss()):
+        sg = SRGAN_training([G, D, E], [None, None, None], [nn.MSELoss(), crit], lbd, 1, "cpu", np.eye(4), 4, "mu", 8)
+        assert not sg._class_is_mse() and not sg._fused_paths()
+        with pytest.raises(NotImplementedError, match="nn.MSELoss"):
+            hl.get_domainloss_D([torch.zeros(2, 4)], torch.zeros(2, 4), crit)
+    assert ok._noise_kinds() == ["randn"] + ["normal"] * 2 + ["normal"] * 3
