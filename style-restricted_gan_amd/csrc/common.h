@@ -137,6 +137,8 @@ bool narrow_applicable(const srgan_conv_desc* d);
 size_t narrow_workspace(const srgan_conv_desc* d);
 int narrow_pack(const srgan_conv_desc* d, const float* w, float* wp, hipStream_t st);
 int narrow_fwd_packed(const srgan_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, hipStream_t st);
+int narrow_fwd_strided(const srgan_conv_desc* f, int pad_x, const float* x, const float* wp, float* y, int Hd, int Wd, int oy_off,
+                       int ox_off, hipStream_t st);
 bool narrow_wave_applicable(const srgan_conv_desc* d);
 int narrow_wave_fwd(const srgan_conv_desc* d, const float* x, const float* wp, int Kpad, const float* bias, float* y, hipStream_t st);
 bool dense_head_applicable(const srgan_conv_desc* d);

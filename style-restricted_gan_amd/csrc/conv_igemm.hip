@@ -1342,7 +1342,50 @@ static bool rgbin_dgrad_desc(const srgan_conv_desc* d, srgan_conv_desc* f, long 
   return rgbin_applicable(f);
 }
 
-struct DgradGeom { IgemmParams p; int phases; bool reflect, wino, narrow, rgbin; int Hd, Wd; size_t packed_elems; };
+struct DgradGeom { IgemmParams p; int phases; bool reflect, wino, narrow, rgbin, narrow_s2; int Hd, Wd; size_t packed_elems; };
+
+// Input gradient of a STRIDE-2 zero-padded conv with <= 4 input channels (the encoder's 7x7 / stride-2 RGB layer inside phase 2,
+// D's 4x4 / stride-2 RGB layers inside phase 1): the implicit GEMM pads the 3 channels to a 32-wide MFMA tile (6.7 TFLOP/s,
+// 0.69 ms for one launch of the step).  Row parity pp of the input pixel selects the taps ky = ky0 + 2a (ky0 = (pp + pad) & 1),
+// so phase image (pp, qq) = dx[2u + pp][2v + qq] is a STRIDE-1 narrow-output convolution of dy with the flipped sub-filter:
+//   dx_pq[u][v][c] = sum_{o, a', b'} dy[u + a' - pad_y][v + b' - pad_x][o] * w[o][c][ky0 + 2 (na - 1 - a')][kx0 + 2 (nb - 1 - b')]
+// with pad_y = (na - 1) - (pp + pad - ky0) / 2: four launches of conv_narrow.hip's generic kernel that scatter their pixels with
+// stride 2 into dx.  Returns false when the layer does not qualify.
+static bool narrow_s2_phase(const srgan_conv_desc* d, int pp, int qq, srgan_conv_desc* f, long long* w_off, int* pad_x,
+                            size_t* packed_off) {
+  static const bool off = std::getenv("SRGAN_NO_NARROW_S2") != nullptr;
+  if (off || d->stride != 2 || d->pad_mode != SRGAN_PAD_ZERO || d->I > 4 || d->O % 16 != 0 || d->kh != d->kw || d->kh < 2 ||
+      d->kh > 8 || d->Hi < 2 || d->Wi < 2)
+    return false;
+  size_t off_elems = 0;
+  for (int ph = 0; ph < 4; ++ph) {
+    const int p1 = ph >> 1, q1 = ph & 1;
+    const int ky0 = (p1 + d->pad) & 1, kx0 = (q1 + d->pad) & 1;
+    const int na = (d->kh - ky0 + 1) / 2, nb = (d->kw - kx0 + 1) / 2;
+    if (p1 == pp && q1 == qq) {
+      *f = *d;
+      f->Hi = d->Ho; f->Wi = d->Wo; f->I = d->O; f->O = d->I;
+      f->Ho = (d->Hi - pp + 1) / 2; f->Wo = (d->Wi - qq + 1) / 2;
+      f->kh = na; f->kw = nb; f->stride = 1;
+      f->pad = (na - 1) - (pp + d->pad - ky0) / 2;
+      *pad_x = (nb - 1) - (qq + d->pad - kx0) / 2;
+      f->sO = d->sI; f->sI = d->sO; f->sH = -2 * d->sH; f->sW = -2 * d->sW;
+      *w_off = (long long)(ky0 + 2 * (na - 1)) * d->sH + (long long)(kx0 + 2 * (nb - 1)) * d->sW;
+      *packed_off = off_elems;
+      return f->Ho > 0 && f->Wo > 0 && na > 0 && nb > 0 && f->pad >= 0 && *pad_x >= 0;
+    }
+    off_elems += (size_t)d->O * na * nb * 4;
+  }
+  return false;
+}
+static size_t narrow_s2_packed_elems(const srgan_conv_desc* d) {
+  size_t n = 0;
+  for (int ph = 0; ph < 4; ++ph) {
+    const int ky0 = ((ph >> 1) + d->pad) & 1, kx0 = ((ph & 1) + d->pad) & 1;
+    n += (size_t)d->O * ((d->kh - ky0 + 1) / 2) * ((d->kw - kx0 + 1) / 2) * 4;
+  }
+  return n;
+}
 
 static DgradGeom dgrad_geometry(const srgan_conv_desc* d) {
   DgradGeom g{};
@@ -1372,6 +1415,10 @@ static DgradGeom dgrad_geometry(const srgan_conv_desc* d) {
   if (g.narrow) g.packed_elems = rowconv_applicable(&f) ? rowconv_packed_elems(&f) : (size_t)f.I * f.kh * f.kw * 4;
   g.rgbin = !g.wino && !g.narrow && rgbin_dgrad_desc(d, &f, &w_off);
   if (g.rgbin) g.packed_elems = rgbin_packed_elems(&f);
+  int px;
+  size_t po;
+  g.narrow_s2 = !g.wino && !g.narrow && !g.rgbin && narrow_s2_phase(d, 0, 0, &f, &w_off, &px, &po);
+  if (g.narrow_s2) g.packed_elems = narrow_s2_packed_elems(d);
   return g;
 }
 
@@ -1398,6 +1445,17 @@ static int dgrad_pack(const srgan_conv_desc* d, const float* w, float* dst, hipS
     long long w_off;
     rgbin_dgrad_desc(d, &f, &w_off);
     return rgbin_pack(&f, w + w_off, dst, st);
+  }
+  if (g.narrow_s2) {
+    for (int ph = 0; ph < 4; ++ph) {
+      srgan_conv_desc f;
+      long long w_off;
+      int px;
+      size_t po;
+      if (!narrow_s2_phase(d, ph >> 1, ph & 1, &f, &w_off, &px, &po)) { set_error("narrow stride-2 dgrad: phase geometry"); return -1; }
+      if (int e = narrow_pack(&f, w + w_off, dst + po, st)) return e;
+    }
+    return 0;
   }
   const PackParams q = dgrad_pack_params(d, g, w, dst);
   long long total = (long long)g.packed_elems;
@@ -1448,6 +1506,17 @@ static int dgrad_run_core(const srgan_conv_desc* d, const float* dy, const float
     long long w_off;
     rgbin_dgrad_desc(d, &f, &w_off);
     return rgbin_run(&f, dy, wp, nullptr, dx, SRGAN_ACT_NONE, 0.f, st);
+  }
+  if (g.narrow_s2) {
+    for (int ph = 0; ph < 4; ++ph) {
+      srgan_conv_desc f;
+      long long w_off;
+      int px;
+      size_t po;
+      if (!narrow_s2_phase(d, ph >> 1, ph & 1, &f, &w_off, &px, &po)) { set_error("narrow stride-2 dgrad: phase geometry"); return -1; }
+      if (int e = narrow_fwd_strided(&f, px, dy, wp + po, dx, d->Hi, d->Wi, ph >> 1, ph & 1, st)) return e;
+    }
+    return 0;
   }
   if (g.wino) {
     // (F(4,3) needs zero padding, the fold scratch needs reflect padding: the two uses of `scratch` never meet)
@@ -1520,7 +1589,7 @@ extern "C" int srgan_conv2d_pack_entry(const srgan_conv_desc* d, int kind, int a
     else { pe.type = 0; pe.ig = fwd_pack_params(d, path, w, (float*)packed); }
   } else {
     const DgradGeom g = dgrad_geometry(d);
-    if (g.narrow || g.rgbin) return 1;
+    if (g.narrow || g.rgbin || g.narrow_s2) return 1;
     if (g.wino) { pe.type = 1; wino_pack_params(d, 1, w, (float*)packed, &pe.wn); }
     else { pe.type = 0; pe.ig = dgrad_pack_params(d, g, w, (float*)packed); }
   }

@@ -26,6 +26,9 @@ struct NarrowParams {
   float* slab;         // wgrad: [blocks][4][T*Ci]
   int N, H, W, Ci, Ho, Wo, CO, kh, kw, pad;
   int tiles_x, tiles_y, tiles_per_block, splits;   // wgrad work split
+  // generic forward only: column padding (rows use `pad`) and the placement of output pixel (oy, ox) in the destination image:
+  // dst[n][oy * oy_mul + oy_off][ox * ox_mul + ox_off] of an Hd x Wd image (the phase images of a stride-2 input gradient)
+  int pad_x, Hd, Wd, oy_mul, ox_mul, oy_off, ox_off;
 };
 
 // stage the halo tile of channels [c0, c0+16) for output tile origin (oy0, ox0) of image n
@@ -35,7 +38,7 @@ __device__ __forceinline__ void stage_tile(const NarrowParams& p, float* tile, i
   for (int idx = threadIdx.x; idx < total; idx += 256) {
     const int q = idx & 3, pix = idx >> 2;
     const int ty = pix / tw, tx = pix - ty * tw;
-    const int y = oy0 + ty - p.pad, x = ox0 + tx - p.pad;
+    const int y = oy0 + ty - p.pad, x = ox0 + tx - p.pad_x;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
       v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(n * p.H + y) * p.W + x) * p.Ci + c0 + q * 4);
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void narrow_conv_fwd_kernel(NarrowParams p) {
   }
   const int oy = oy0 + py, ox = ox0 + px;
   if (oy < p.Ho && ox < p.Wo) {
-    float* dst = p.y + ((size_t)(n * p.Ho + oy) * p.Wo + ox) * CO;
+    float* dst = p.y + ((size_t)(n * p.Hd + oy * p.oy_mul + p.oy_off) * p.Wd + ox * p.ox_mul + p.ox_off) * CO;
 #pragma unroll
     for (int o = 0; o < CO; ++o) dst[o] = acc[o];
   }
@@ -323,6 +326,7 @@ int narrow_wave_fwd(const srgan_conv_desc* d, const float* x, const float* wp, i
   p.x = x; p.wp = wp; p.bias = bias; p.y = y;
   p.N = d->N; p.H = d->Hi; p.W = d->Wi; p.Ci = d->I; p.Ho = d->Ho; p.Wo = d->Wo; p.CO = d->O;
   p.kh = d->kh; p.kw = d->kw; p.pad = d->pad;
+  p.pad_x = d->pad; p.Hd = d->Ho; p.Wd = d->Wo; p.oy_mul = p.ox_mul = 1; p.oy_off = p.ox_off = 0;
   const long long M = (long long)d->N * d->Ho * d->Wo;
   dim3 grid((unsigned)ceil_div(M, 4));
   switch (d->O) {
@@ -368,6 +372,7 @@ int narrow_fwd_packed(const srgan_conv_desc* d, const float* x, const float* wp,
   p.x = x; p.wp = wp; p.bias = bias; p.y = y;
   p.N = d->N; p.H = d->Hi; p.W = d->Wi; p.Ci = d->I; p.Ho = d->Ho; p.Wo = d->Wo; p.CO = d->O;
   p.kh = d->kh; p.kw = d->kw; p.pad = d->pad;
+  p.pad_x = d->pad; p.Hd = d->Ho; p.Wd = d->Wo; p.oy_mul = p.ox_mul = 1; p.oy_off = p.ox_off = 0;
   if (narrow4_applicable(d)) {
     const size_t sh4 = (size_t)N2_CH * (N2_ROWS + 6) * (N2_COLS + 8) * sizeof(float);
     dim3 g4((unsigned)ceil_div(d->Wo, N2_COLS), (unsigned)ceil_div(d->Ho, N2_ROWS), (unsigned)d->N);
@@ -385,12 +390,33 @@ int narrow_fwd_packed(const srgan_conv_desc* d, const float* x, const float* wp,
   return check_launch("narrow_conv_fwd_kernel");
 }
 
+// One phase image of a stride-2 input gradient (conv_igemm.hip, narrow_s2_*): the generic kernel with separate row / column
+// padding and its output pixels scattered with stride 2 into the Hd x Wd destination.  wp from narrow_pack(f, ...).
+int narrow_fwd_strided(const srgan_conv_desc* f, int pad_x, const float* x, const float* wp, float* y, int Hd, int Wd, int oy_off,
+                       int ox_off, hipStream_t st) {
+  NarrowParams p{};
+  p.x = x; p.wp = wp; p.bias = nullptr; p.y = y;
+  p.N = f->N; p.H = f->Hi; p.W = f->Wi; p.Ci = f->I; p.Ho = f->Ho; p.Wo = f->Wo; p.CO = f->O;
+  p.kh = f->kh; p.kw = f->kw; p.pad = f->pad;
+  p.pad_x = pad_x; p.Hd = Hd; p.Wd = Wd; p.oy_mul = p.ox_mul = 2; p.oy_off = oy_off; p.ox_off = ox_off;
+  const size_t shmem = (size_t)(NT_H + f->kh - 1) * (NT_W + f->kw - 1) * NPIX * sizeof(float);
+  dim3 grid((unsigned)ceil_div(f->Wo, NT_W), (unsigned)ceil_div(f->Ho, NT_H), (unsigned)f->N);
+  switch (f->O) {
+    case 1: hipLaunchKernelGGL(narrow_conv_fwd_kernel<1>, grid, dim3(256), shmem, st, p); break;
+    case 2: hipLaunchKernelGGL(narrow_conv_fwd_kernel<2>, grid, dim3(256), shmem, st, p); break;
+    case 3: hipLaunchKernelGGL(narrow_conv_fwd_kernel<3>, grid, dim3(256), shmem, st, p); break;
+    default: hipLaunchKernelGGL(narrow_conv_fwd_kernel<4>, grid, dim3(256), shmem, st, p); break;
+  }
+  return check_launch("narrow_conv_fwd_kernel (phase)");
+}
+
 // returns the number of slabs written ([slabs][4][T*I]) through *n_slabs
 int narrow_wgrad(const srgan_conv_desc* d, const float* x, const float* dy, void* ws, int* n_slabs, hipStream_t st) {
   NarrowParams p{};
   p.x = x; p.dy = dy; p.slab = (float*)ws;
   p.N = d->N; p.H = d->Hi; p.W = d->Wi; p.Ci = d->I; p.Ho = d->Ho; p.Wo = d->Wo; p.CO = d->O;
   p.kh = d->kh; p.kw = d->kw; p.pad = d->pad;
+  p.pad_x = d->pad; p.Hd = d->Ho; p.Wd = d->Wo; p.oy_mul = p.ox_mul = 1; p.oy_off = p.ox_off = 0;
   p.tiles_x = (int)ceil_div(d->Wo, NT_W); p.tiles_y = (int)ceil_div(d->Ho, NT_H);
   const int tiles = p.tiles_x * p.tiles_y;
   int splits = 1;

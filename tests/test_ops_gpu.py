@@ -75,6 +75,10 @@ CONV_CASES = [
     (2, 3, 40, 33, 128, 7, 1, 3, False, True),    # RGB-input 7x7 layer on the MFMA (LDS halo): ragged tiles, 2 channel blocks, bias
     (9, 3, 128, 128, 64, 7, 1, 3, False, False),  # RGB-input layer: MFMA weight gradient, 288 pixel tiles on 256 persistent workgroups
     (3, 64, 32, 64, 3, 7, 1, 3, False, False),    # RGB-output layer: MFMA weight gradient (swapped roles, flipped taps), 12 tiles
+    (2, 3, 32, 40, 64, 7, 2, 1, False, True),     # E first layer at even sizes: input gradient as four stride-1 phase convs (3 / 4 taps)
+    (3, 3, 33, 31, 32, 7, 2, 1, False, False),    # same, odd sizes (phase images of different heights / widths)
+    (2, 4, 18, 22, 48, 6, 2, 2, False, False),    # same route: 4 input channels, 6x6 taps, pad 2
+    (2, 3, 16, 16, 16, 5, 2, 0, False, False),    # same route: odd kernel, no padding
 ]
 
 
