@@ -108,6 +108,8 @@ struct IgemmParams {
   float slope;
   int M;               // NB*Hg*Wg
   int m_tiles, n_tiles;
+  int ksplit, kt_per_split;      // split-K (blockIdx.z): K tiles [z * kt_per_split, ...) -> partial sums into dst + z * split_stride
+  long long split_stride;
 };
 
 constexpr int BK = 32;
@@ -165,7 +167,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
   __syncthreads();
 
   const float* wp = p.wp + (size_t)phase * p.Npad * p.Kpad + (size_t)n0 * p.Kpad;
-  const int nk = p.Kpad / BK;
+  // split-K: this workgroup multiplies K tiles [kt0, kt0 + nk) only and writes raw partial sums into its own slab
+  const int kt0 = p.ksplit > 1 ? (int)blockIdx.z * p.kt_per_split : 0;
+  const int nk = p.ksplit > 1 ? max(min(p.Kpad / BK - kt0, p.kt_per_split), 0) : p.Kpad / BK;
 
   // staging registers
   constexpr int A_VEC_IT = BM / RP;      // float4 per thread (VEC)
@@ -235,6 +239,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     }
   }
   int tap_y = 0, tap_x = 0, tap_c = 0;       // position of the NEXT tile to load (VEC path)
+  if (VEC && kt0 > 0) {
+    const int k0 = kt0 * BK, t = k0 / p.Cs;
+    tap_c = k0 - t * p.Cs;
+    tap_y = t / p.Tx;
+    tap_x = t - tap_y * p.Tx;
+  }
   // generic path: per-row window origin and linear element offset of the thread's BM/RG rows
   int g_y[VEC ? 1 : A_SC_IT], g_x[VEC ? 1 : A_SC_IT], g_lin[VEC ? 1 : A_SC_IT];
   if constexpr (!VEC) {
@@ -248,7 +258,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     }
   }
 
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](int kt_rel) {
+    const int kt = kt0 + kt_rel;
     const int k0 = kt * BK;
     if constexpr (VEC) {
       const unsigned seg16 = (tid & 7) * 16;
@@ -391,6 +402,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i][e], bf[slot][j][e], acc[i][j], 0, 0, 0);
   };
 
+  if (nk > 0) {
   if constexpr (BF) {
     // 8 MFMAs (2 K-steps of 16) per wave and K tile: 256 matrix cycles against ~1000 of loads / LDS / barrier -- the loop
     // is bound by data movement, so it is kept simple: fragments of the whole tile first, then the next tile's stores
@@ -448,8 +460,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     mfma_step(1);
   }
   }
+  }
 
   // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float* const dst_base = p.ksplit > 1 ? p.dst + (size_t)blockIdx.z * p.split_stride : p.dst;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * TN * 32 + j * 32 + lr;
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         if (nok && o >= 0) {
           float v = acc[i][j][e] + bv;
           v = apply_act(v, p.act, p.slope);
-          p.dst[(size_t)o * p.Cd + n] = v;
+          dst_base[(size_t)o * p.Cd + n] = v;
         }
       }
     }
@@ -925,12 +939,15 @@ __global__ void colsum_partial_kernel(const float* a, float* part, int M, int C,
   for (int m = m0; m < m1; ++m) s += a[(size_t)m * C + c];
   part[(size_t)blockIdx.y * C + c] = s;
 }
-__global__ void colsum_final_kernel(const float* part, float* out, int C, int nparts) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one WAVE per column: lane l sums partials l, l + 64, ... (fixed assignment), then a shuffle tree -- deterministic, and the
+// up-to-1024 partials no longer sit in one thread's serial chain (18 us per launch, 25 launches per step)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, float* out, int C, int nparts) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (c >= C) return;
   float s = 0.f;
-  for (int i = 0; i < nparts; ++i) s += part[(size_t)i * C + c];
-  out[c] = s;
+  for (int i = lane; i < nparts; i += 64) s += part[(size_t)i * C + c];
+  s = wave_sum(s);
+  if (lane == 0) out[c] = s;
 }
 
 // ---- host side ----------------------------------------------------------------------------
@@ -955,7 +972,7 @@ template <int BM, int BN, int WM, int WN>
 int launch_igemm(const IgemmParams& p, int phases, bool vec, hipStream_t st, double flops) {
   constexpr int tile_id = (BM == 256 && BN == 64) ? 6 : (BM == 256) ? 5 : (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 128 && BN == 32) ? 2 : 3;
   ProfScope scope(tile_id * 2 + (vec ? 1 : 0), flops, st);
-  dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)phases, 1);
+  dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)phases, (unsigned)std::max(p.ksplit, 1));
   if (vec && compute_bf16())
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, true>), grid, dim3(WM * WN * 64), 0, st, p);
   else if (vec)
@@ -965,7 +982,78 @@ int launch_igemm(const IgemmParams& p, int phases, bool vec, hipStream_t st, dou
   return check_launch("igemm_kernel");
 }
 
-int run_igemm(IgemmParams p, int phases, hipStream_t st, double flops) {
+int run_igemm_tiles(IgemmParams p, int phases, hipStream_t st, double flops);
+int run_igemm(IgemmParams p, int phases, hipStream_t st, double flops, float* slab = nullptr);
+
+// ---- split-K for layers with few pixel tiles and long K loops (the encoder's 7x7 / 3x3 maps, the discriminators' 8x8 / 4x4
+// maps): 64-200 four-wave workgroups walking 64-144 K tiles leave most SIMDs with one wave and nothing to hide its loads
+// behind (22-48 TFLOP/s).  The K range is cut into `ksplit` pieces (grid z), every piece writes raw partial sums into its own
+// destination-shaped slab, and splitk_reduce_kernel adds the slabs in split order (deterministic), the bias and the activation.
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int ksplit, long long n4, long long stride,
+                                     const float* __restrict__ bias, int Cd, int act, float slope, float* __restrict__ dst) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(slab + i * 4);
+    for (int k = 1; k < ksplit; ++k) v += *reinterpret_cast<const f32x4*>(slab + (size_t)k * stride + i * 4);
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + (i * 4) % Cd);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
+    *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+  }
+}
+
+struct SplitKPlan { int ksplit, kt_per_split; long long dst_elems; };
+
+static TileChoice final_tile(const IgemmParams& p) {
+  TileChoice tc = choose_tile(p.M, p.Cd);
+  const bool vec = (p.Cs % BK) == 0;
+  if (tc.BM == 256 && !vec) tc = {128, tc.BN};
+  return tc;
+}
+
+static SplitKPlan plan_splitk(const IgemmParams& p, int phases) {
+  SplitKPlan s{1, 0, (long long)p.NB * p.Hd * p.Wd * p.Cd};
+  static const bool off = std::getenv("SRGAN_NO_SPLITK") != nullptr;
+  static const int target = std::getenv("SRGAN_SPLITK_TARGET") ? std::atoi(std::getenv("SRGAN_SPLITK_TARGET")) : 768;
+  const TileChoice tc = final_tile(p);
+  if (off || tc.BM == 256 || (p.Cd & 3) != 0 || s.dst_elems >= (1LL << 28)) return s;
+  const long long wgs = ceil_div(p.M, tc.BM) * ceil_div(p.Cd, tc.BN) * phases;
+  const int nk = p.Kpad / BK;
+  long long ks = std::min<long long>(8, std::min<long long>(target / std::max<long long>(wgs, 1), nk / 8));
+  if (ks < 2) return s;
+  s.kt_per_split = (int)ceil_div(nk, ks);
+  s.ksplit = (int)ceil_div(nk, s.kt_per_split);
+  if (s.ksplit < 2) s.ksplit = 1;
+  return s;
+}
+
+static size_t splitk_bytes(const IgemmParams& p, int phases) {
+  const SplitKPlan s = plan_splitk(p, phases);
+  return s.ksplit > 1 ? (size_t)s.ksplit * s.dst_elems * sizeof(float) : 0;
+}
+
+// `slab`: splitk_bytes(p, phases) bytes of scratch, or null (then the layer runs unsplit)
+int run_igemm(IgemmParams p, int phases, hipStream_t st, double flops, float* slab) {
+  const SplitKPlan sk = slab ? plan_splitk(p, phases) : SplitKPlan{1, 0, 0};
+  float* const real_dst = p.dst;
+  const float* const real_bias = p.bias;
+  const int real_act = p.act;
+  if (sk.ksplit > 1) {
+    p.ksplit = sk.ksplit; p.kt_per_split = sk.kt_per_split; p.split_stride = sk.dst_elems;
+    p.dst = slab; p.bias = nullptr; p.act = SRGAN_ACT_NONE;
+  } else {
+    p.ksplit = 1; p.kt_per_split = 0; p.split_stride = 0;
+  }
+  if (int e = run_igemm_tiles(p, phases, st, flops)) return e;
+  if (sk.ksplit > 1) {
+    const long long n4 = sk.dst_elems / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(ceil_div(n4, 256), 4096))),
+                       dim3(256), 0, st, (const float*)slab, sk.ksplit, n4, sk.dst_elems, real_bias, p.Cd, real_act, p.slope, real_dst);
+    return check_launch("splitk_reduce_kernel");
+  }
+  return 0;
+}
+
+int run_igemm_tiles(IgemmParams p, int phases, hipStream_t st, double flops) {
   TileChoice tc = choose_tile(p.M, p.Cd);
   p.m_tiles = (int)ceil_div(p.M, tc.BM);
   p.n_tiles = (int)ceil_div(p.Cd, tc.BN);
@@ -1138,12 +1226,16 @@ size_t pack_bytes(const srgan_conv_desc* d) {
 
 using namespace srgan;
 
+namespace srgan { static size_t conv_splitk_bytes(const srgan_conv_desc* d, int kind); }
+
 extern "C" size_t srgan_conv2d_workspace(const srgan_conv_desc* d) {
   if (validate(d) != 0) return 0;
   size_t bytes = pack_bytes(d);
   // reflect dgrad: padded-gradient temp
   if (d->pad_mode == SRGAN_PAD_REFLECT)
     bytes += (size_t)d->N * (d->Hi + 2 * d->pad) * (d->Wi + 2 * d->pad) * d->I * sizeof(float);
+  // split-K slabs of the implicit-GEMM forward / input gradient, behind the packed operand (and the reflect temp)
+  bytes += 256 + std::max(conv_splitk_bytes(d, 0), conv_splitk_bytes(d, 1));
   // F(4x4,3x3) layers: the transformed-input image, behind the packed operand (64-float aligned)
   bytes = std::max(bytes, (size_t)round_up((long long)pack_bytes(d), 256) + std::max(wino_scratch_bytes(d, 0), wino_scratch_bytes(d, 1)));
   WgradPlan w = plan_wgrad(d);
@@ -1313,7 +1405,7 @@ static int fwd_run(const srgan_conv_desc* d, const float* x, const float* wp, co
   p.src = x; p.bias = bias; p.dst = y; p.act = act; p.slope = slope; p.wp = wp;
   if (path == PATH_DENSE) return dense_head_fwd(d, x, wp, p.Kpad, bias, y, st);
   if (path == PATH_WAVE) return narrow_wave_fwd(d, x, wp, p.Kpad, bias, y, st);
-  return run_igemm(p, 1, st, conv_flops(d));
+  return run_igemm(p, 1, st, conv_flops(d), scratch);      // scratch (may be null): room for split-K slabs
 }
 
 // ---- input gradient / transposed-conv forward ----
@@ -1470,6 +1562,21 @@ __global__ void add_inplace_kernel(float* __restrict__ y, const float* __restric
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] += r[n4 * 4 + threadIdx.x];
 }
 
+// bytes of split-K slabs the implicit-GEMM forward (kind 0) / input gradient (kind 1) of d wants (0: another kernel family
+// serves it, or the layer is not split)
+static size_t conv_splitk_bytes(const srgan_conv_desc* d, int kind) {
+  if (kind == 0) {
+    const FwdPath path = fwd_path(d, SRGAN_ACT_NONE);
+    if (path != PATH_IGEMM) return 0;
+    IgemmParams p{};
+    fwd_geometry(d, path, p);
+    return splitk_bytes(p, 1);
+  }
+  const DgradGeom g = dgrad_geometry(d);
+  if (g.wino || g.narrow || g.rgbin || g.narrow_s2) return 0;
+  return splitk_bytes(g.p, g.phases);
+}
+
 static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp, float* dx, float* scratch, hipStream_t st,
                      const float* res = nullptr);
 static int dgrad_run_core(const srgan_conv_desc* d, const float* dy, const float* wp, float* dx, float* scratch, hipStream_t st,
@@ -1522,8 +1629,10 @@ static int dgrad_run_core(const srgan_conv_desc* d, const float* dy, const float
     // (F(4,3) needs zero padding, the fold scratch needs reflect padding: the two uses of `scratch` never meet)
     if (int e = wino_run(d, 1, dy, wp, nullptr, g.p.dst, SRGAN_ACT_NONE, 0.f, g.reflect ? nullptr : scratch, st,
                          g.reflect ? nullptr : res, res_done)) return e;
-  } else if (int e = run_igemm(g.p, g.phases, st, conv_flops(d))) {
-    return e;
+  } else {
+    // split-K slabs sit behind the padded-gradient temp of a reflect layer
+    float* slab = scratch ? (g.reflect ? scratch + round_up((long long)d->N * g.Hd * g.Wd * d->I, 64) : scratch) : nullptr;
+    if (int e = run_igemm(g.p, g.phases, st, conv_flops(d), slab)) return e;
   }
   if (g.reflect) {
     long long n = (long long)d->N * d->Hi * d->Wi * d->I;
@@ -1623,9 +1732,9 @@ extern "C" unsigned long long srgan_conv2d_pack_signature(const srgan_conv_desc*
 
 extern "C" size_t srgan_conv2d_packed_scratch(const srgan_conv_desc* d, int kind) {
   if (validate(d) != 0) return 0;
-  if (kind == 1 && d->pad_mode == SRGAN_PAD_REFLECT) return srgan_conv2d_workspace(d);      // padded-gradient temp
+  if (kind == 1 && d->pad_mode == SRGAN_PAD_REFLECT) return srgan_conv2d_workspace(d);      // padded-gradient temp (+ split-K slabs)
   if (kind == 0 ? fwd_path(d, SRGAN_ACT_NONE) == PATH_WINO : dgrad_geometry(d).wino) return wino_scratch_bytes(d, kind);
-  return 0;
+  return conv_splitk_bytes(d, kind);      // implicit-GEMM layers with few pixel tiles: split-K slabs (0 for everything else)
 }
 
 extern "C" int srgan_conv2d_fwd_packed(const srgan_conv_desc* d, const float* x, const void* packed, const float* bias,
@@ -1801,7 +1910,7 @@ static int finish_wgrad(const srgan_conv_desc* d, const WgradPlan& w, const floa
     dim3 g1((unsigned)ceil_div(d->O, 64), (unsigned)nparts);
     hipLaunchKernelGGL(colsum_partial_kernel, g1, dim3(64), 0, st, dy, part, M, d->O, rpb);
     if (int e3 = check_launch("colsum_partial_kernel")) return e3;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(d->O, 64)), dim3(64), 0, st, (const float*)part, dbias, d->O, nparts);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(d->O, 4)), dim3(256), 0, st, (const float*)part, dbias, d->O, nparts);
     return check_launch("colsum_final_kernel");
   }
   return 0;
