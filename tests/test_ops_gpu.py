@@ -120,6 +120,51 @@ def test_conv2d_fwd_bwd(ops, case, dispatch):
         close(bd.grad, b.grad, 5e-5)
 
 
+def _random_conv_cases(n_cases, seed):
+    """Seeded random layer geometries across every dispatch family (narrow / RGB / stride-2 phases / split-K / Winograd / GEMM)."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < n_cases:
+        k = int(rng.choice([1, 3, 3, 4, 4, 5, 7]))
+        s_ = int(rng.choice([1, 1, 2]))
+        i = int(rng.choice([3, 4, 16, 32, 48, 64, 96, 128, 256]))
+        o = int(rng.choice([1, 3, 4, 16, 32, 64, 96, 128, 512]))
+        h, w = int(rng.randint(max(k, 3), 41)), int(rng.randint(max(k, 3), 41))
+        p_ = int(rng.randint(0, k // 2 + 1))
+        reflect = bool(s_ == 1 and 0 < p_ < min(h, w) and k == 3 and rng.rand() < 0.4)
+        n = int(rng.randint(1, 7))
+        if (h + 2 * p_ - k) // s_ + 1 < 1 or (w + 2 * p_ - k) // s_ + 1 < 1 or n * i * h * w > 3_000_000:
+            continue
+        cases.append((n, i, h, w, o, k, s_, p_, reflect, bool(rng.rand() < 0.5)))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_conv_cases(48, seed=20260410))
+def test_conv2d_random_geometries(ops, case, dispatch):
+    """The same check as test_conv2d_fwd_bwd on seeded random geometries, inside a packed-weight scope (the trainer's mode: packed
+    operands, split-K slabs, kept V images) -- corners of the dispatch that the hand-picked cases may miss."""
+    n, i, h, w, o, k, s, p, reflect, has_bias = case
+    torch.set_num_threads(16)
+    x = rnd(n, i, h, w, seed=1).requires_grad_(True)
+    wt = (rnd(o, i, k, k, seed=2) / np.sqrt(i * k * k)).requires_grad_(True)
+    b = (rnd(o, seed=3) * 0.1).requires_grad_(True) if has_bias else None
+    yr = F.conv2d(F.pad(x, (p, p, p, p), mode="reflect"), wt, b, s, 0) if reflect else F.conv2d(x, wt, b, s, p)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+    xd, wd = x.detach().cuda().requires_grad_(True), wt.detach().cuda().requires_grad_(True)
+    bd = b.detach().cuda().requires_grad_(True) if has_bias else None
+    ops.invalidate_packed()
+    with ops.pack_cache():
+        y = ops.conv2d(xd, wd, bd, s, p, ops.PAD_REFLECT if reflect else ops.PAD_ZERO)
+        y.backward(gy.cuda())
+    ops.invalidate_packed()
+    close(y, yr)
+    close(xd.grad, x.grad)
+    close(wd.grad, wt.grad, 5e-5)
+    if has_bias:
+        close(bd.grad, b.grad, 5e-5)
+
+
 @pytest.mark.parametrize("case", [(32, 64, 32, 32, 128, True), (3, 64, 8, 12, 96, True), (5, 128, 16, 16, 64, False),
                                   (2, 256, 32, 32, 256, False)])
 def test_conv2d_f43_weight_gradient_from_kept_image(ops, case, dispatch):
