@@ -18,13 +18,15 @@ nested under batch_KL; the n/(n-1) double correction with the constructor's batc
 is the reporting sum; CPU-generator RNG order (k x randn, then normal_ x2, then normal_ x3).
 """
 import contextlib
+import gc
+import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.optim as optim
 
-from . import dp, ops
+from . import _lib, dp, ops
 from .losses import class_encode, get_domainloss_D, get_loss_D, histogram_imitation
 from .model import SingleGenerator, _cpu_normal_like, host_to_device
 from .optim import Adam
@@ -510,11 +512,14 @@ class _StepGraph:
             # a buffer the recording points at was replaced (compute-mode switch, invalidate_packed, optimiser re-seeded):
             # forget the graph; this step runs eagerly with the new buffers, the next one records again
             self.graph, self.key, self._keep = None, None, None
+            self.x = self.noise = self.out = None
         return self.key is not None and self._key(source_image, label) == self.key and source_image.is_cuda
 
     def note_eager_step(self, source_image, label):
         if self.key is None and source_image.is_cuda:
             self.key = self._key(source_image, label)
+        # the eager step left every packed operand fresh: writes from here on (load_state_dict, copy_) must be noticed
+        self._versions = sum(p._version for p in self._all_params())
 
     # -- what the captured body reads -----------------------------------------------------------------------------
     def onehot(self, which):
@@ -574,7 +579,6 @@ class _StepGraph:
         sg.__dict__.get("_label_cache", {}).clear()
         for opt in (sg.optG, sg.optD, sg.optE):
             opt._keep_alive = None
-        import gc
         gc.collect()
         g = torch.cuda.CUDAGraph()
         sg._g_active = True
@@ -614,12 +618,10 @@ class _StepGraph:
 
 
 def _dp_graph_allowed():
-    import os
     return os.environ.get("SRGAN_DP_GRAPH") == "1"
 
 
 def lib_prof_off():
-    from . import _lib
     _lib.load().srgan_prof_enable(0)     # HIP-event brackets cannot be recorded into a capture
 
 

@@ -92,6 +92,20 @@ def test_graph_mode_survives_outside_weight_writes_and_other_shapes():
         assert torch.equal(v, _state(eager)[key]), key
 
 
+def test_weights_written_between_warmup_and_capture_are_repacked():
+    """load_state_dict after the eager warm-up step and BEFORE the step that records the graph: the recording must multiply the
+    new weights, not the operands the eager step packed."""
+    batch, k = 4, 2
+    eager = _trainer("T", batch, k, seed=6)
+    sg = _trainer("T", batch, k, seed=6).enable_graph()
+    np.testing.assert_array_equal(_steps(eager, batch, 128, 1, 800), _steps(sg, batch, 128, 1, 800))     # warm-up (eager in both)
+    for t in (eager, sg):
+        t.G.load_state_dict({k_: v * 0.75 for k_, v in t.G.state_dict().items()})
+        t.D.load_state_dict({k_: v * 1.25 for k_, v in t.D.state_dict().items()})
+    np.testing.assert_array_equal(_steps(eager, batch, 128, 3, 810), _steps(sg, batch, 128, 3, 810))
+    assert sg.graph_active
+
+
 def test_enable_graph_refuses_what_it_cannot_capture():
     from srgan_amd.trainer import SRGAN_training
     G, D, E = build_hip_nets("T")
