@@ -47,7 +47,15 @@ def init_from_env(backend=None):
     if (ws > 1 or os.environ.get("SRGAN_DP_FORCE") == "1") and not (dist.is_available() and dist.is_initialized()):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rk, world_size=ws)
+        backend = backend or ("nccl" if use_gpu else "gloo")
+        dist.init_process_group(backend, rank=rk, world_size=ws)
+        if backend == "nccl":
+            # create the RCCL communicator HERE, on the main thread and on this rank's device: otherwise the first collective
+            # -- a bucket all-reduce issued from an autograd hook in the backward thread of step 0 -- would also be the one
+            # that initialises it
+            warm = torch.zeros(1, device=device)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize(device)
     return rk, ws, device
 
 
