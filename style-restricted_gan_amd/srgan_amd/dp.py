@@ -83,6 +83,19 @@ def unwrap(net):
     return net.module if hasattr(net, "module") and isinstance(getattr(net, "module"), nn.Module) else net
 
 
+# Segmented step recording (trainer._StepGraph under data parallelism): while a step is being RECORDED into hipGraphs the
+# collectives are not issued -- each one ends the graph segment being recorded, is remembered as a host callable over static
+# device buffers, and a new segment begins.  A replay launches segment, collective, segment, ...: the collectives stay the
+# plain eager RCCL calls (nothing of RCCL is captured), everything between them is one graph launch.
+_recorder = None
+
+
+def set_recorder(rec):
+    """rec: object with ``cut(comm)`` (end the current graph segment, run ``comm()`` after it on every replay) or None."""
+    global _recorder
+    _recorder = rec
+
+
 class _AllGatherRows(torch.autograd.Function):
     """Concatenate each rank's [B_local, d] rows in rank order; backward hands every rank the rows of the
     incoming gradient that belong to it (the gathered loss is evaluated redundantly on every rank)."""
@@ -91,6 +104,12 @@ class _AllGatherRows(torch.autograd.Function):
     def forward(ctx, x):
         ws = dist.get_world_size()
         ctx.rows, ctx.rank = x.shape[0], dist.get_rank()
+        if _recorder is not None:
+            src = x.contiguous()
+            out = torch.empty((ws * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            parts = list(out.chunk(ws, 0))
+            _recorder.cut(lambda: dist.all_gather(parts, src))
+            return out
         parts = [torch.empty_like(x) for _ in range(ws)]
         dist.all_gather(parts, x.contiguous())
         return torch.cat(parts, 0)
@@ -209,7 +228,7 @@ class GradReducer:
                                "(a parameter's requires_grad changed between arm() and the backward?)")
         bk.count += 1
         bk.hit[j] = True
-        if bk.count == bk.expected:
+        if bk.count == bk.expected and _recorder is None:      # while recording, buckets are sent after the backward (start())
             self._launch(b)
 
     def _launch(self, b):
@@ -230,7 +249,10 @@ class GradReducer:
             if holes:
                 torch._foreach_zero_(holes)
         avg = _backend_has_avg()
-        if on_gpu:
+        if _recorder is not None:
+            # recording: the flatten above is part of the graph segment; the all-reduce is issued between segments (finish())
+            _recorder.pending.append((bk.flat, avg))
+        elif on_gpu:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=bk.flat.device)
             bk.ready.record(torch.cuda.current_stream(bk.flat.device))
@@ -264,8 +286,14 @@ class GradReducer:
             return
         work, armed = self._pending
         self._pending = None
+        recording = _recorder is not None
+        if recording and _recorder.pending:
+            # every bucket flattened since the last cut (this reducer's and those of reducers started with it) goes out here,
+            # in the order it was flattened -- the same on every rank
+            flats, _recorder.pending = list(_recorder.pending), []
+            _recorder.cut(lambda: _all_reduce_avg(flats))
         for bk in work:
-            if bk.done is not None:
+            if bk.done is not None and not recording:
                 torch.cuda.current_stream(bk.flat.device).wait_event(bk.done)
             for j, (p, v) in enumerate(zip(bk.params, bk.views)):
                 if p.grad is None and armed and not bk.hit[j]:
@@ -275,6 +303,15 @@ class GradReducer:
     def reduce(self):
         self.start()
         self.finish()
+
+
+def _all_reduce_avg(flats):
+    """Eager in-place average of flat buckets on the CURRENT stream (between two graph segments of a recorded step)."""
+    ws = dist.get_world_size()
+    for flat, avg in flats:
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
+        if not avg:
+            flat.mul_(1.0 / ws)
 
 
 def _backend_has_avg():

@@ -496,9 +496,8 @@ class _StepGraph:
         for name in ("optG", "optD", "optE"):
             if not isinstance(getattr(sg, name), Adam):
                 return f"{name} is not srgan_amd.optim.Adam (call opt_sche_initialization(), or pass that class)"
-        if dp.is_distributed() and not _dp_graph_allowed():
-            return ("data-parallel steps replay eagerly unless SRGAN_DP_GRAPH=1 (RCCL collectives inside a captured graph have "
-                    "not been validated on this pool)")
+        if dp.is_distributed() and os.environ.get("SRGAN_DP_GRAPH") == "0":
+            return "SRGAN_DP_GRAPH=0: data-parallel steps run eagerly (hook-driven all-reduce under the backward)"
         return None
 
     @staticmethod
@@ -580,12 +579,12 @@ class _StepGraph:
         for opt in (sg.optG, sg.optD, sg.optE):
             opt._keep_alive = None
         gc.collect()
-        g = torch.cuda.CUDAGraph()
+        g = _Recording(self.x.device)
         sg._g_active = True
         self._noise_i, self._onehot = 0, {}
         sg.source_image = self.x
         try:
-            with torch.cuda.graph(g):
+            with g:
                 with ops.pack_cache(refresh_on_entry=False):
                     err = sg.UnrolledUpdate()
                 self.out = torch.stack([e.detach().reshape(()) for e in err])
@@ -617,8 +616,68 @@ class _StepGraph:
         return [out[0], out[1], out[2]]
 
 
-def _dp_graph_allowed():
-    return os.environ.get("SRGAN_DP_GRAPH") == "1"
+class _Recording:
+    """One train step as a chain of hipGraph segments with host callables between them.
+
+    Single process: one segment -- the whole step is one graph launch.  Data parallel: ``srgan_amd.dp`` ends the segment being
+    recorded wherever the step exchanges data (the mu all-gather, the bucket all-reduces after each backward) and hands over
+    the collective as a callable; ``replay()`` launches segment, collective, segment, ... on the caller's stream.  The
+    collectives therefore stay ordinary eager RCCL calls on static buffers -- nothing of RCCL is captured, no communication
+    stream is forked into a capture -- and everything between two of them (8 exchange points per step: k discriminator
+    all-reduces, the all-gather, two generator / encoder all-reduces) is one launch.  All segments allocate from one private
+    pool and are replayed in recording order, so a tensor made in one segment is valid in the following ones."""
+
+    def __init__(self, device):
+        self.device = device
+        self.segments = []         # [(CUDAGraph, callable or None)]
+        self.pending = []          # flat gradient buckets laid out since the last cut (dp.GradReducer)
+        self._cur = None
+        self._pool = None
+        self._stream = None
+        self._stream_ctx = None
+        # other threads of a data-parallel process (the process group's watchdog) may touch HIP while this one records
+        self._mode = "thread_local" if dp.is_distributed() else "global"
+
+    def _begin(self):
+        self._cur = torch.cuda.CUDAGraph()
+        self._cur.capture_begin(pool=self._pool, capture_error_mode=self._mode)
+
+    def cut(self, comm):
+        self._cur.capture_end()
+        self.segments.append((self._cur, comm))
+        self._begin()
+
+    def __enter__(self):
+        torch.cuda.synchronize(self.device)
+        gc.collect()
+        torch.cuda.empty_cache()
+        self._pool = torch.cuda.graph_pool_handle()
+        self._stream = torch.cuda.Stream(self.device)
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._stream_ctx = torch.cuda.stream(self._stream)
+        self._stream_ctx.__enter__()
+        dp.set_recorder(self if dp.is_distributed() else None)
+        self._begin()
+        return self
+
+    def __exit__(self, *exc):
+        dp.set_recorder(None)
+        try:
+            self._cur.capture_end()
+            self.segments.append((self._cur, None))
+        finally:
+            self._cur = None
+            self._stream_ctx.__exit__(*exc)
+        if exc[0] is None and self.pending:
+            raise RuntimeError("recorded step left gradient buckets without their all-reduce (GradReducer.finish() not called)")
+        return False
+
+    def replay(self):
+        with torch.no_grad():          # the collectives write buffers (views made inside autograd functions) in place
+            for graph, comm in self.segments:
+                graph.replay()
+                if comm is not None:
+                    comm()
 
 
 def lib_prof_off():

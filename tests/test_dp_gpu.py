@@ -34,7 +34,7 @@ def _run(rank, world, out_q=None, kl=0.0, graph=False, recipe=None):
     from oracle import trainer as otrainer
     from tests.common import build_hip_nets
     from srgan_amd.trainer import SRGAN_training
-    from srgan_amd import optim as hoptim, ops
+    from srgan_amd import optim as hoptim, ops, dp
     G, D, E = build_hip_nets("T")
     if recipe == "config3":          # BASELINE configs[3]: 4 domains, global batch 64, bf16 convolutions, 4 ranks
         ops.set_compute_dtype("bf16")
@@ -63,6 +63,10 @@ def _run(rank, world, out_q=None, kl=0.0, graph=False, recipe=None):
         sl = slice(rank * per, (rank + 1) * per)
         lab = {"source": label["source"][sl].cuda(), "target": label["target"][sl]}
         losses.append([float(v) for v in sg.train(x[sl].cuda(), lab)])
+    if graph:
+        # data parallel: the recording is cut at each of the K + 3 exchange points (K discriminator all-reduces, the mu
+        # all-gather, the G+E and the G all-reduces) -- K + 4 graph segments with eager collectives between them
+        assert sg.graph_active and len(sg._graph.graph.segments) == (K + 4 if dp.is_distributed() else 1)
     state = {f"{n}.{k}": v.detach().cpu().numpy().copy() for n, net in (("G", sg.G), ("D", sg.D), ("E", sg.E)) for k, v in net.state_dict().items()}
     terms = {k: float(v) for k, v in sg.loss_terms.items()}
     if out_q is not None:
@@ -75,8 +79,6 @@ def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False, graph
                       LOCAL_RANK=str(rank), SRGAN_DP_DEVICE="0", SRGAN_DP_BACKEND=backend)
     if force:
         os.environ["SRGAN_DP_FORCE"] = "1"
-    if graph:
-        os.environ["SRGAN_DP_GRAPH"] = "1"
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "style-restricted_gan_amd")):
@@ -91,15 +93,17 @@ def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False, graph
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kl", [0.0, 0.1])
-def test_two_ranks_equal_one_process(kl):
+@pytest.mark.parametrize("kl,graph", [(0.0, False), (0.1, False), (0.0, True)])
+def test_two_ranks_equal_one_process(kl, graph):
     """kl=0.1: the conventional-KL term (a SUM over rows, 01/02/03/05 notebooks' 0.1 option) must be pre-scaled by the world
-    size like the batch-statistics losses, or E receives 1/ws of its gradient."""
+    size like the batch-statistics losses, or E receives 1/ws of its gradient.
+    graph=True: both ranks record the step as hipGraph segments and replay them with the collectives issued eagerly between
+    the segments (step 0 eager, step 1 records + replays, step 2 replays); same bounds as the eager ranks."""
     ref_losses, ref_state, ref_terms = _run(0, 1, kl=kl)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kl)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kl, "gloo", False, graph)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
@@ -130,8 +134,8 @@ def test_rccl_path_one_rank_equals_plain_step(graph):
     on the communication stream (asynchronous: only the ready / done events order it against the compute stream), the mu
     all-gather inside autograd, gradients bound to bucket slices, parameters without gradient left at None -- and must
     reproduce the plain single-process step.  (Two ranks cannot share a device under RCCL; the 2-rank arithmetic is the gloo
-    test above.)  graph=True: the same with the step captured into a hipGraph (SRGAN_DP_GRAPH=1): the RCCL all-reduces and the
-    all-gather are recorded on their forked communication stream and replayed."""
+    test above.)  graph=True: the same with the step recorded as hipGraph segments, the RCCL all-reduces and the all-gather
+    issued eagerly between the segments on every replay."""
     ref_losses, ref_state, ref_terms = _run(0, 1)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
