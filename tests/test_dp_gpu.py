@@ -150,9 +150,11 @@ def test_rccl_path_one_rank_equals_plain_step(graph):
         assert d <= 1e-6, (key, d)
 
 
-def test_config2_recipe_two_ranks_equal_one_process():
+@pytest.mark.parametrize("graph", [False, True])
+def test_config2_recipe_two_ranks_equal_one_process(graph):
     """BASELINE configs[2] in its stated form at tier-T widths: the pretrained-E recipe (encoder trunk outside optE) AND the bf16
-    convolution mode AND two data-parallel ranks, against the single-process step of the same recipe."""
+    convolution mode AND two data-parallel ranks, against the single-process step of the same recipe.  graph=True: the ranks
+    record and replay graph segments (parameters that receive no gradient must stay without one in the recorded step too)."""
     from srgan_amd import ops
     try:
         ref_losses, ref_state, ref_terms = _run(0, 1, recipe="config2")
@@ -161,7 +163,7 @@ def test_config2_recipe_two_ranks_equal_one_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 0.0, "gloo", False, False, "config2")) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 0.0, "gloo", False, graph, "config2")) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
