@@ -123,6 +123,13 @@ bool wino_wgrad_applicable(const srgan_conv_desc* d);
 void wino_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad);
 int wino_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, hipStream_t st);
 
+// conv_halo16.hip: bf16-mode 3x3 stride-1 trunk convolution with the activation patch resident in LDS (dispatch: variant 4 of
+// conv_wino.hip's slot -- not a Winograd transform, it shares the packed-filter plumbing)
+bool halo16_applicable(const srgan_conv_desc* d, int kind);
+size_t halo16_packed_bytes(const srgan_conv_desc* d);
+int halo16_run(const srgan_conv_desc* d, int kind, const float* src, const void* packed, const float* bias, const float* res,
+               float* dst, int act, float slope, double flops, hipStream_t st);
+
 // conv_rgbin.hip: 3-channel-input 7x7 stride-1 layers on the MFMA (LDS-staged halo)
 bool rgbin_applicable(const srgan_conv_desc* d);
 size_t rgbin_packed_elems(const srgan_conv_desc* d);

@@ -1,0 +1,276 @@
+// bf16 compute mode (BASELINE configs [2]-[4]): the 3x3 / stride-1 / zero-pad-1 convolutions of the generator's residual trunk
+// (reference pyfiles/model.py:188-201) -- forward and input gradient -- as a direct GEMM on v_mfma_f32_32x32x16_bf16 whose
+// activation operand lives in LDS for the whole kernel.
+//
+// The bf16 matrix pipe retires a 32x32x16 product in 32 cycles, 16x the fp32 rate: an implicit GEMM that re-stages an
+// activation tile per (tap, channel chunk) moves 9x the activation through L2 -> registers -> convert -> LDS and spends 4x more
+// time on that than on the products (igemm_kernel<256,128,4,2,BF>: 0.16 of the bf16 peak).  Here a workgroup owns a 4 x 32 pixel
+// patch of one image and ALL reduce channels:
+//   * the 6 x 34 pixel halo of the patch (zero outside the image) is read ONCE as fp32 (buffer loads, range-checked), rounded
+//     to bf16 (nearest even, as every bf16-mode conv) and parked in LDS as [halo pixel][C + 8 pad] -- 105 KB at C = 256; the
+//     16-byte pad puts 8 consecutive pixels on 8 different bank groups, so a fragment read (32 pixels x 16 bytes) is
+//     conflict-free.  Only the first 64-channel quarter is loaded in the prologue: the K order is (quarter, tap, 32-chunk) and
+//     quarter q + 1 streams in under the products of quarter q (one 32-pixel pass per tap);
+//   * loop over C/64 quarters x 9 taps x 2 chunks: the A fragment of (tap, chunk) is ONE ds_read_b128 at
+//     halo[(row + ty) * 34 + col + tx][chunk * 32 ...] -- no staging, no conversion, no masks in the loop; only the weight tile
+//     [256 output channels][32 k] (16 KB of bf16, pre-packed in exactly that order, XOR-swizzled 16-byte pieces instead of
+//     padding: ds_read_b128 serves lanes in groups made of aligned 4-lane blocks, so the swizzle key is the row's 4-block)
+//     streams global -> registers (two tiles in flight) -> LDS through THREE buffers, so tile kt + 1 is readable while tile
+//     kt is multiplied: the fragments of every 16-deep K step are requested one step ahead, one barrier per tile.  Every
+//     workgroup streams the whole 9 C N filter image from L2 (16 KB per 16 MFMAs per wave): that stream, not LDS or the
+//     matrix pipe, bounds the loop (measured: 172 us at batch 128 without the epilogue, 134 with the stream removed, 117 with
+//     the fragment reads removed as well);
+//   * 4 waves, one per SIMD, each 64 pixels (two image rows) x BN/2 output channels: 16 MFMAs per wave and K tile (BN = 256)
+//     against 4 + 8 fragment reads;
+//   * epilogue: a lane of the accumulator is an output channel, so every store instruction writes whole 128-byte lines of the
+//     NHWC result; bias / activation / the residual-gradient add (`res`, input gradient of a block's first conv) ride here.
+// HBM tensors stay fp32 (the same contract as the other bf16-mode kernels); the packed filter image is bf16
+// [n tile][quarter][tap][chunk of the quarter][BN][32], kind 1 = taps rotated by 180 degrees with O and I swapped (conv_wino.hip: variant 4).
+#include <cstdlib>
+#include "common.h"
+#include "pack_device.h"
+
+namespace srgan {
+
+namespace {
+
+constexpr int HK = 32;                 // reduce channels per K tile
+constexpr int HPX = 6 * 34;            // halo pixels of a 4 x 32 patch
+
+struct Halo16Params {
+  const float* src;            // [NB][H][W][C] fp32
+  const unsigned short* wp;    // packed bf16 filters
+  const float* bias;           // [N] or null
+  const float* res;            // [NB][H][W][N] or null
+  float* dst;                  // [NB][H][W][N]
+  int NB, H, W, N, tiles_y, tiles_x, n_tiles, act;
+  float slope;
+};
+
+__device__ __forceinline__ auto uniform_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <int C, int BN, bool RES>
+__global__ __launch_bounds__(256) void halo16_kernel(Halo16Params p) {
+  constexpr int PS = C * 2 + 16;               // bytes per halo pixel
+  constexpr int NQ = C / 64;                   // 64-channel quarters of the reduce dimension (K order: quarter, tap, 32-chunk)
+  constexpr int NK = 9 * NQ * 2;               // K tiles
+  constexpr int TN = BN / 64;                  // 32-wide output-channel blocks per wave (2 waves across N)
+  constexpr int WTILE = BN * 64;               // bytes of one weight tile in LDS: [BN rows][4 swizzled 16-byte pieces]
+  constexpr int WLD = BN * 4 / 256;            // 16-byte pieces of a weight tile per thread
+  constexpr int HP = 7;                        // passes of 32 pixels over the 204 halo pixels of one quarter
+  static_assert(BN == 64 || BN == 128 || BN == 256, "BN");
+  __shared__ __attribute__((aligned(16))) unsigned char halo[HPX * PS];
+  __shared__ __attribute__((aligned(16))) unsigned char wt[3 * WTILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);      // neighbouring patches (shared halo rows) on one XCD
+  const int nt = bid % p.n_tiles;
+  int r = bid / p.n_tiles;
+  const int tx = r % p.tiles_x; r /= p.tiles_x;
+  const int ty = r % p.tiles_y;
+  const int nb = r / p.tiles_y;
+  const int Y0 = ty * 4, X0 = tx * 32;
+
+  const auto rs_x = uniform_rsrc(p.src, (unsigned)((size_t)p.NB * p.H * p.W * C * 4));
+  const auto rs_w = uniform_rsrc(p.wp + (size_t)nt * NK * (BN * HK), (unsigned)(NK * BN * HK * 2));
+
+  // ---- weight tiles: global -> registers -> LDS, three buffers (tile kt + 1 is readable while tile kt is multiplied) ----
+  f32x4 wreg[WLD], wreg2[WLD];
+  auto load_w = [&](f32x4* dst, int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WLD; ++i)
+      dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, tid * 16 + i * 4096, kt * (BN * HK * 2), 0));
+  };
+  auto store_w = [&](const f32x4* src, int boff) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) {
+      const int q = tid + 256 * i;               // piece q: row q / 4, 16-byte piece q % 4 (swizzled by the row's 4-block)
+      const int n = q >> 2;
+      *reinterpret_cast<f32x4*>(&wt[boff + n * 64 + (((q & 3) ^ ((n >> 2) & 3)) << 4)]) = src[i];
+    }
+  };
+  load_w(wreg, 0);
+  load_w(wreg2, 1);
+
+  // ---- halo: one 64-channel quarter at a time; thread = (pixel of the pass, 8 channels), 32 pixels per pass ----
+  const int hcg = tid & 7, hpl = tid >> 3;
+  constexpr unsigned kOutside = 0x80000000u;
+  auto halo_off = [&](int quarter, int pass) __attribute__((always_inline)) -> unsigned {
+    const int hp = pass * 32 + hpl;
+    const int hr = hp / 34, hc = hp - hr * 34;
+    const int y = Y0 - 1 + hr, x = X0 - 1 + hc;
+    const bool ok = hp < HPX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    return ok ? (unsigned)((((nb * p.H + y) * p.W + x) * C + quarter * 64 + hcg * 8) * 4) : kOutside;
+  };
+  auto halo_put = [&](int quarter, int pass, f32x4 lo, f32x4 hi) __attribute__((always_inline)) {
+    const int hp = pass * 32 + hpl;
+    if (hp < HPX) {
+      const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+      bf16x8 v;
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+      *reinterpret_cast<bf16x8*>(&halo[hp * PS + quarter * 128 + hcg * 16]) = v;
+    }
+  };
+  {
+    f32x4 lo[HP], hi[HP];
+#pragma unroll
+    for (int g = 0; g < HP; ++g) {
+      const unsigned off = halo_off(0, g);
+      lo[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+      hi[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+    }
+    store_w(wreg, 0);
+    store_w(wreg2, WTILE);
+    load_w(wreg, 2);             // NK >= 18
+    load_w(wreg2, 3);
+#pragma unroll
+    for (int g = 0; g < HP; ++g) halo_put(0, g, lo[g], hi[g]);
+  }
+  __syncthreads();
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // lane's A address: pixel (row 2 wm, column lr) of the patch at tap (0,0) = halo pixel (2 wm) * 34 + lr, k half lh
+  const unsigned char* a_lane = halo + ((2 * wm) * 34 + lr) * PS + lh * 16;
+  // lane's B offsets inside a weight tile for the two K steps of 16: row wn * BN/2 + lr (+ 32 j), piece (2 s + lh) ^ swizzle
+  const int b_row = (wn * (BN / 2) + lr) * 64, b_sw = (lr >> 2) & 3;
+  const int b_lane0 = b_row + (((0 + lh) ^ b_sw) << 4), b_lane1 = b_row + (((2 + lh) ^ b_sw) << 4);
+
+  int kt = 0;
+  bf16x8 fa[2][2], fb[2][TN];
+  auto read_frags = [&](int slot, const unsigned char* a, int woff, int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[slot][i] = *reinterpret_cast<const bf16x8*>(a + i * 34 * PS + s * 32);
+    const unsigned char* B = wt + woff + (s ? b_lane1 : b_lane0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const bf16x8*>(B + j * 32 * 64);
+  };
+  auto mma = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i], fb[slot][j], acc[i][j], 0, 0, 0);
+  };
+
+  int w_cur = 0, w_nxt = WTILE, w_nn = 2 * WTILE;       // LDS offsets of the tiles kt, kt + 1, kt + 2
+  read_frags(0, a_lane, w_cur, 0);
+  f32x4 hlo = {0.f, 0.f, 0.f, 0.f}, hhi = {0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < NQ; ++q) {
+    for (int tap = 0; tap < 9; ++tap) {
+      const int t3 = tap / 3;
+      const unsigned char* a_tap = a_lane + (t3 * 34 + (tap - 3 * t3)) * PS + q * 128;
+      // A address of the tile after this tap's two: next tap of the quarter, or tap 0 of the next quarter
+      const int ntap = tap == 8 ? 0 : tap + 1, nq = tap == 8 ? q + 1 : q, n3 = ntap / 3;
+      const unsigned char* a_next = a_lane + (n3 * 34 + (ntap - 3 * n3)) * PS + nq * 128;
+      // the next quarter of the halo streams in under this quarter's products: pass `tap` is requested here and parked in
+      // LDS one tap later (two barriers before its first reader)
+      if (q + 1 < NQ) {
+        if (tap >= 1 && tap <= HP) halo_put(q + 1, tap - 1, hlo, hhi);
+        if (tap < HP) {
+          const unsigned off = halo_off(q + 1, tap);
+          hlo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+          hhi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+        }
+      }
+#pragma unroll
+      for (int kc2 = 0; kc2 < 2; ++kc2, ++kt) {
+        const unsigned char* a_cur = a_tap + kc2 * 64;
+        // K step 0 of tile kt: its fragments are in slot 0; request step 1 first
+        read_frags(1, a_cur, w_cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // K step 1: request step 0 of tile kt + 1 (already visible: stored an iteration ago)
+        if (kt + 1 < NK) read_frags(0, kc2 == 0 ? a_tap + 64 : a_next, w_nxt, 0);
+        // tile kt + 2 (requested two tiles ago into this parity's registers) -> LDS; request tile kt + 4
+        if (kt + 2 < NK) store_w(kc2 == 0 ? wreg : wreg2, w_nn);
+        if (kt + 4 < NK) load_w(kc2 == 0 ? wreg : wreg2, kt + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1);
+        __syncthreads();
+        const int t = w_cur; w_cur = w_nxt; w_nxt = w_nn; w_nn = t;
+      }
+    }
+  }
+
+  // ---- epilogue: lane = output channel; register e of acc[i][j] = pixel column (e % 4) + 8 (e / 4) + 4 lh of image row
+  // Y0 + 2 wm + i; the 32 lanes of a half-wave store one whole 128-byte line ----
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const size_t row = ((size_t)(nb * p.H + Y0 + 2 * wm + i) * p.W + X0) * p.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nt * BN + wn * (BN / 2) + j * 32 + lr;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+      float rv[16];
+      if constexpr (RES) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = p.res[row + (size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * p.N + n];
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = apply_act(acc[i][j][e] + bv, p.act, p.slope);
+        if constexpr (RES) v += rv[e];
+        p.dst[row + (size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * p.N + n] = v;
+      }
+    }
+  }
+}
+
+template <int C>
+int launch_c(const Halo16Params& p, long long grid, hipStream_t st) {
+  if (p.res) hipLaunchKernelGGL((halo16_kernel<C, C, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((halo16_kernel<C, C, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  return 0;
+}
+
+}  // namespace
+
+// the layer shapes the kernel is instantiated for: square channel counts 64 / 128 / 256, maps of whole 4 x 32 patches
+bool halo16_applicable(const srgan_conv_desc* d, int kind) {
+  static const bool off = std::getenv("SRGAN_NO_HALO16") != nullptr;
+  if (off || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != SRGAN_PAD_ZERO) return false;
+  if (d->I != d->O || !(d->I == 64 || d->I == 128 || d->I == 256)) return false;
+  if (d->Hi % 4 != 0 || d->Wi % 32 != 0 || d->Ho != d->Hi || d->Wo != d->Wi) return false;
+  (void)kind;
+  return (long long)d->N * d->Hi * d->Wi * d->I < (1LL << 29);      // 32-bit byte offsets into the source
+}
+
+size_t halo16_packed_bytes(const srgan_conv_desc* d) { return (size_t)9 * d->I * d->O * 2; }
+
+// src: x (kind 0) or dy (kind 1), both [N][H][W][C]; dst likewise with the other channel count (equal here)
+int halo16_run(const srgan_conv_desc* d, int kind, const float* src, const void* packed, const float* bias, const float* res,
+               float* dst, int act, float slope, double flops, hipStream_t st) {
+  SRGAN_REQUIRE(halo16_applicable(d, kind), "halo16: layer not applicable");
+  Halo16Params p{};
+  p.src = src; p.wp = reinterpret_cast<const unsigned short*>(packed); p.bias = bias; p.res = res; p.dst = dst;
+  p.NB = d->N; p.H = d->Hi; p.W = d->Wi; p.N = d->I;
+  p.tiles_y = d->Hi / 4; p.tiles_x = d->Wi / 32; p.n_tiles = 1; p.act = act; p.slope = slope;
+  const long long grid = (long long)p.NB * p.tiles_y * p.tiles_x * p.n_tiles;
+  SRGAN_REQUIRE(grid > 0 && grid < (1LL << 31), "halo16: grid");
+  ProfToken tok = prof_begin(24, flops, st);
+  if (d->I == 256) launch_c<256>(p, grid, st);
+  else if (d->I == 128) launch_c<128>(p, grid, st);
+  else launch_c<64>(p, grid, st);
+  prof_end(tok, st);
+  return check_launch("halo16_kernel");
+}
+
+}  // namespace srgan

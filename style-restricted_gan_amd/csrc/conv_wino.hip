@@ -741,8 +741,11 @@ static bool wino_s2_disabled() {
 
 // 0: none, 1: F(2x2,3x3) on a 3x3 stride-1 pad-1 layer, 2: F(3x3,2x2) on a 4x4 stride-2 pad-1 layer,
 // 3: F(4x4,3x3) (conv_wino43.hip) on a 3x3 stride-1 zero-pad-1 layer whose map is a multiple of 4 in both directions
+// 4: bf16 mode only -- NOT a Winograd form: the direct bf16 GEMM of conv_halo16.hip (residual-trunk shapes), which shares this
+//    slot's packed-filter / residual-add plumbing
 static int wino_variant(const srgan_conv_desc* d, int kind) {
-  if (wino_disabled() || compute_bf16()) return 0;       // bf16 mode: the transforms would eat the 8-bit mantissa
+  if (compute_bf16()) return halo16_applicable(d, kind) ? 4 : 0;   // bf16 mode: the transforms would eat the 8-bit mantissa
+  if (wino_disabled()) return 0;
 
   const int C = kind == 0 ? d->I : d->O, N = kind == 0 ? d->O : d->I;
   if (C % (2 * WC) != 0 || C < 32 || N < 32 || N % 4 != 0) return 0;   // an even number of 8-channel chunks; 16-byte stores
@@ -783,14 +786,15 @@ static void wino_dims(const srgan_conv_desc* d, int kind, int* C, int* N, int* n
   const int v = wino_variant(d, kind);
   *C = kind == 0 ? d->I : d->O;
   *N = kind == 0 ? d->O : d->I;
-  *n_tiles = v == 3 ? *N / 32 : (int)ceil_div(*N, WNB);
-  *nchunk = (v == 2 && kind == 0 ? 4 : 1) * (*C / WC);      // MODE 1 reduces over (input phase, channel)
+  *n_tiles = v == 4 ? 1 : v == 3 ? *N / 32 : (int)ceil_div(*N, WNB);
+  *nchunk = v == 4 ? *C / 32 : (v == 2 && kind == 0 ? 4 : 1) * (*C / WC);      // MODE 1 reduces over (input phase, channel)
   *phases = (v == 2 && kind == 1) ? 4 : 1;                  // MODE 2: one filter image per output phase
 }
 
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind) {
   int C, N, n_tiles, nchunk, phases;
   wino_dims(d, kind, &C, &N, &n_tiles, &nchunk, &phases);
+  if (wino_variant(d, kind) == 4) return halo16_packed_bytes(d);
   if (wino_variant(d, kind) == 3) return (size_t)n_tiles * nchunk * (36 * 256) * sizeof(float);
   return (size_t)phases * n_tiles * nchunk * 8192 * sizeof(float);
 }
@@ -856,6 +860,11 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
   wino_dims(d, kind, &C, &N, &p.n_tiles, &p.nchunk, &phases);
   const int variant = wino_variant(d, kind);
   SRGAN_REQUIRE(variant != 0, "winograd: layer not applicable");
+  if (variant == 4) {
+    SRGAN_REQUIRE(!v_ready, "halo16: no transformed-input image on this path");
+    if (res_done) *res_done = res != nullptr;
+    return halo16_run(d, kind, src, packed, bias, res, dst, act, slope, conv_flops_of(d), st);
+  }
   const bool reflect = d->pad_mode == SRGAN_PAD_REFLECT;
   p.src = src; p.u = packed; p.bias = bias; p.dst = dst;
   p.NB = d->N; p.C = C; p.Cd = N; p.cpp = C / WC;

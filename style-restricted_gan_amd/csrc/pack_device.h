@@ -48,6 +48,7 @@ struct WinoPackParams {
 
 constexpr int WP_WNB = 64, WP_WC = 8;
 __device__ __host__ __forceinline__ long long wino_pack_total(const WinoPackParams& p) {
+  if (p.variant == 4) return (long long)9 * p.nchunk * p.N * 4;                  // one item = 8 reduce channels of one cout
   if (p.variant == 3) return (long long)p.n_tiles * 32 * p.nchunk * 2;          // one item = 4 channels of one cout
   return (long long)p.n_tiles * WP_WNB * p.nchunk * WP_WC * p.phases;
 }
@@ -106,8 +107,35 @@ __device__ __forceinline__ void wino43_pack_item(const WinoPackParams& p, long l
   for (int k = 0; k < 36; ++k) *reinterpret_cast<f32x4*>(out + k * 256) = u[k];
 }
 
+// variant 4 (conv_halo16.hip, bf16 mode -- no transform): bf16 [64-channel quarter][tap][32-chunk of the quarter][N][32], rounded
+// to nearest even (K tile kt = (quarter * 9 + tap) * 2 + chunk & 1).
+// kind 0: B[n][k] = w[n][k][ky][kx];  kind 1: B[n][k] = w[k][n][2-ky][2-kx].
+__device__ __forceinline__ void halo16_pack_item(const WinoPackParams& p, long long idx) {
+  long long r = idx;
+  const int part = (int)(r % 4); r /= 4;
+  const int n = (int)(r % p.N); r /= p.N;
+  const int kt = (int)r;                               // 0 .. 9 * nchunk - 1
+  const int quarter = kt / 18, rem = kt - quarter * 18;
+  const int tap = rem >> 1, chunk = quarter * 2 + (rem & 1);
+  const int ky = tap / 3, kx = tap - 3 * ky;
+  f32x4 lo, hi;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = chunk * 32 + part * 8 + j;
+    const float v = p.kind == 0 ? p.w[n * p.sO + k * p.sI + ky * p.sH + kx * p.sW]
+                                : p.w[k * p.sO + n * p.sI + (2 - ky) * p.sH + (2 - kx) * p.sW];
+    if (j < 4) lo[j] = v; else hi[j - 4] = v;
+  }
+  const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+  bf16x8 o;
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  unsigned short* dst = reinterpret_cast<unsigned short*>(p.dst);
+  *reinterpret_cast<bf16x8*>(dst + ((size_t)kt * p.N + n) * 32 + part * 8) = o;
+}
+
 __device__ __forceinline__ void wino_pack_item(const WinoPackParams& p, long long idx) {
   constexpr int WNB = WP_WNB, WC = WP_WC;
+  if (p.variant == 4) { halo16_pack_item(p, idx); return; }
   if (p.variant == 3) { wino43_pack_item(p, idx); return; }
     // lanes run over (channel & 3, cout, channel half): the 16 stores of a wave-instruction are 256 contiguous bytes each
     const int c4 = (int)(idx % 4);

@@ -79,6 +79,9 @@ CONV_CASES = [
     (3, 3, 33, 31, 32, 7, 2, 1, False, False),    # same, odd sizes (phase images of different heights / widths)
     (2, 4, 18, 22, 48, 6, 2, 2, False, False),    # same route: 4 input channels, 6x6 taps, pad 2
     (2, 3, 16, 16, 16, 5, 2, 0, False, False),    # same route: odd kernel, no padding
+    (2, 256, 32, 32, 256, 3, 1, 1, False, False), # residual-trunk layer at full width (bf16 mode: LDS-resident patch kernel, C = 256)
+    (1, 128, 8, 64, 128, 3, 1, 1, False, True),   # same kernel family: C = 128, two patches per row, bias
+    (1, 256, 64, 64, 256, 3, 1, 1, False, False), # the 256x256 configuration's trunk map (64 x 64): 32 patches of one image
 ]
 
 
@@ -392,6 +395,32 @@ def test_conv2d_bf16_compute_mode(ops, case):
         close(wd.grad, dw_ref)
     finally:
         ops.set_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("case", [(3, 64, 8, 32, 64), (2, 256, 32, 32, 256), (1, 128, 12, 64, 128)])
+def test_conv2d_skip_bf16_mode(ops, case):
+    """bf16 mode on the residual-trunk shapes: the skip path's gradient is added in the epilogue of the LDS-resident-patch kernel
+    (conv_halo16.hip) -- same bf16-rounded-operand references as test_conv2d_bf16_compute_mode, plus the fp32 skip gradient."""
+    n, i, h, w, o = case
+    torch.set_num_threads(16)
+    x = rnd(n, i, h, w, seed=41)
+    wt = rnd(o, i, 3, 3, seed=42) / np.sqrt(i * 9)
+    gy, gs = rnd(n, o, h, w, seed=43), rnd(n, i, h, w, seed=44)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(_bf16_round(x), _bf16_round(wt), None, 1, 1)
+    (F.conv2d(xr, _bf16_round(wt), None, 1, 1) * _bf16_round(gy)).sum().backward()
+    dx_ref = xr.grad + gs
+    ops.set_compute_dtype("bf16")
+    try:
+        xd, wd = x.cuda().requires_grad_(True), wt.cuda().requires_grad_(True)
+        with ops.pack_cache():
+            y, skip = ops.conv2d_skip(xd, wd, None, 1, 1, ops.PAD_ZERO)
+            ((y * gy.cuda()).sum() + (skip * gs.cuda()).sum()).backward()
+        close(y, yr)
+        close(xd.grad, dx_ref)
+    finally:
+        ops.set_compute_dtype("fp32")
+        ops.invalidate_packed()
 
 
 def test_conv2d_fused_leaky_relu(ops, dispatch):
