@@ -26,6 +26,7 @@
 //     NHWC result; bias / activation / the residual-gradient add (`res`, input gradient of a block's first conv) ride here.
 // HBM tensors stay fp32 (the same contract as the other bf16-mode kernels); the packed filter image is bf16
 // [n tile][quarter][tap][chunk of the quarter][BN][32], kind 1 = taps rotated by 180 degrees with O and I swapped (conv_wino.hip: variant 4).
+#include <algorithm>
 #include <cstdlib>
 #include "common.h"
 #include "pack_device.h"
@@ -234,6 +235,146 @@ __global__ __launch_bounds__(256) void halo16_kernel(Halo16Params p) {
   }
 }
 
+// ---- weight gradient of the same layers:  dW[o][c][ty][tx] = sum_pixels dy[pixel][o] * x[pixel + (ty-1, tx-1)][c]  ----
+// A workgroup owns a 64 (o) x 64 (c) block of ALL NINE taps (9 x 16 accumulator registers per lane: wave (wo, wc) holds the
+// 32 x 32 sub-block of every tap) over a range of 4 x 32 pixel patches.  Per patch the 64-channel slices of dy (128 pixels)
+// and of the x halo (6 x 34 pixels, zero outside the image) are read once as fp32, rounded to bf16 and parked in LDS as
+// [pixel][64 channels + 32 pad] (192-byte rows: the four pixel rows of a transposing read lie 16 banks apart); the reduce
+// index of the MFMA is the PIXEL, so both operands come from ds_read_b64_tr_b16 (a 16-lane group reads 4 pixels x 16 channels
+// and gets them channel-major): the dy fragments of the 8 K steps (16 pixels each) are read once per patch and reused by the
+// nine taps, the x fragment of (tap, K step) is the same read shifted by (ty * 34 + tx) halo pixels -- no staging per tap.
+// 72 MFMAs per wave and patch against 84 KB of fp32 input per workgroup; the next patch's 22 loads per thread are in flight
+// during the products (double-buffered LDS, one barrier per patch).  Split-K over patch ranges into [split][O][9 C] slabs, summed
+// by wgrad_reduce_kernel (conv_igemm.hip) like every other weight-gradient kernel.
+struct Halo16WgradParams {
+  const float* x;     // [NB][H][W][C]
+  const float* dy;    // [NB][H][W][O]
+  float* slab;        // [splits][O][9 C]
+  int NB, H, W, C, O, tiles_y, tiles_x, patches, per_split, splits, o_tiles, c_tiles;
+};
+
+constexpr int GPS = 192;               // bytes per pixel row of a 64-channel bf16 slice in LDS
+constexpr int GX = HPX * GPS, GD = 128 * GPS;
+
+__global__ __launch_bounds__(256) void halo16_wgrad_kernel(Halo16WgradParams p) {
+  typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4;
+  __shared__ __attribute__((aligned(16))) unsigned char xs[2 * GX];
+  __shared__ __attribute__((aligned(16))) unsigned char ds[2 * GD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wo = wave >> 1, wc = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int li = lane & 15, q4 = li >> 2, pq = li & 3, g1 = (lane >> 4) & 1;
+
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);      // the 16 blocks of one patch range share an XCD's L2
+  const int tiles = p.o_tiles * p.c_tiles;
+  const int split = bid / tiles, tile = bid - split * tiles;
+  const int ot = tile / p.c_tiles, ct = tile - ot * p.c_tiles;
+  const int p_begin = split * p.per_split, p_end = min(p_begin + p.per_split, p.patches);
+
+  const auto rs_x = uniform_rsrc(p.x, (unsigned)((size_t)p.NB * p.H * p.W * p.C * 4));
+  const auto rs_d = uniform_rsrc(p.dy, (unsigned)((size_t)p.NB * p.H * p.W * p.O * 4));
+  constexpr unsigned kOutside = 0x80000000u;
+  const int hcg = tid & 7, hpl = tid >> 3;           // 8 channels of one of the 32 pixels of a pass
+
+  f32x4 xl[7], xh[7], dl[4], dh[4];
+  auto issue = [&](int patch) __attribute__((always_inline)) {
+    int r = patch;
+    const int tx = r % p.tiles_x; r /= p.tiles_x;
+    const int ty = r % p.tiles_y;
+    const int nb = r / p.tiles_y;
+    const int Y0 = ty * 4, X0 = tx * 32;
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+      const int hp = g * 32 + hpl;
+      const int hr = hp / 34, hc = hp - hr * 34;
+      const int y = Y0 - 1 + hr, x = X0 - 1 + hc;
+      const bool ok = hp < HPX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      const unsigned off = ok ? (unsigned)((((nb * p.H + y) * p.W + x) * p.C + ct * 64 + hcg * 8) * 4) : kOutside;
+      xl[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+      xh[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int px = g * 32 + hpl;                   // pixel (px / 32, px % 32) of the patch
+      const unsigned off = (unsigned)((((nb * p.H + Y0 + (px >> 5)) * p.W + X0 + (px & 31)) * p.O + ot * 64 + hcg * 8) * 4);
+      dl[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 0, 0));
+      dh[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 16, 0));
+    }
+  };
+  auto pack8 = [](f32x4 lo, f32x4 hi) __attribute__((always_inline)) {
+    const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+    bf16x8 v;
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    return v;
+  };
+  auto park = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+      const int hp = g * 32 + hpl;
+      if (hp < HPX) *reinterpret_cast<bf16x8*>(&xs[buf * GX + hp * GPS + hcg * 16]) = pack8(xl[g], xh[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<bf16x8*>(&ds[buf * GD + (g * 32 + hpl) * GPS + hcg * 16]) = pack8(dl[g], dh[g]);
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  // lane part of a transposing fragment read: pixel 8 lh + q4 of the K step, channels 16 g1 + 4 pq .. + 3 of the wave's 32
+  const int d_lane = (8 * lh + q4) * GPS + (wo * 32 + 16 * g1 + 4 * pq) * 2;
+  const int x_lane = (8 * lh + q4) * GPS + (wc * 32 + 16 * g1 + 4 * pq) * 2;
+  auto frag = [&](const unsigned char* base) __attribute__((always_inline)) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(base));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(base + 4 * GPS));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  if (p_begin < p_end) {
+    issue(p_begin);
+    park(0);
+    __syncthreads();
+  }
+  for (int pt = p_begin; pt < p_end; ++pt) {
+    const int buf = (pt - p_begin) & 1;
+    if (pt + 1 < p_end) issue(pt + 1);
+    const unsigned char* D = ds + buf * GD + d_lane;
+    const unsigned char* X = xs + buf * GX + x_lane;
+    bf16x8 df[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) df[ks] = frag(D + ((ks >> 1) * 32 + (ks & 1) * 16) * GPS);
+    bf16x8 xf[2];
+    xf[0] = frag(X);                                  // tap (0,0), K step 0
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int g = t * 8 + ks;
+        if (g + 1 < 72) {
+          const int t2 = (g + 1) >> 3, k2 = (g + 1) & 7;
+          xf[(g + 1) & 1] = frag(X + (((k2 >> 1) + t2 / 3) * 34 + (k2 & 1) * 16 + t2 % 3) * GPS);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[ks], xf[g & 1], acc[t], 0, 0, 0);
+      }
+    }
+    if (pt + 1 < p_end) park(buf ^ 1);
+    __syncthreads();
+  }
+
+  // slab[split][o][tap * C + c]: lane = c (128-byte lines), register e = o row (e % 4) + 8 (e / 4) + 4 lh
+  float* out = p.slab + ((size_t)split * p.O + ot * 64 + wo * 32) * (9 * p.C) + ct * 64 + wc * 32 + lr;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[(size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * (9 * p.C) + t * p.C] = acc[t][e];
+}
+
 template <int C>
 int launch_c(const Halo16Params& p, long long grid, hipStream_t st) {
   if (p.res) hipLaunchKernelGGL((halo16_kernel<C, C, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
@@ -271,6 +412,40 @@ int halo16_run(const srgan_conv_desc* d, int kind, const float* src, const void*
   else launch_c<64>(p, grid, st);
   prof_end(tok, st);
   return check_launch("halo16_kernel");
+}
+
+// ---- weight gradient host side (hooked into conv_wino.hip's weight-gradient slot in bf16 mode) ----
+static void halo16_wgrad_plan(const srgan_conv_desc* d, Halo16WgradParams* p) {
+  p->NB = d->N; p->H = d->Hi; p->W = d->Wi; p->C = d->I; p->O = d->O;
+  p->tiles_y = d->Hi / 4; p->tiles_x = d->Wi / 32;
+  p->patches = d->N * p->tiles_y * p->tiles_x;
+  p->o_tiles = d->O / 64; p->c_tiles = d->I / 64;
+  const int tiles = p->o_tiles * p->c_tiles;
+  int splits = std::max(1, std::min(p->patches, 256 / tiles));      // one workgroup per CU (127 KB of LDS)
+  p->per_split = (p->patches + splits - 1) / splits;
+  p->splits = (p->patches + p->per_split - 1) / p->per_split;
+}
+
+bool halo16_wgrad_applicable(const srgan_conv_desc* d) {
+  static const bool off = std::getenv("SRGAN_NO_HALO16_WGRAD") != nullptr;
+  return !off && halo16_applicable(d, 0);
+}
+
+void halo16_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad) {
+  Halo16WgradParams p{};
+  halo16_wgrad_plan(d, &p);
+  *splits = p.splits; *Cdpad = d->O; *NNpad = 9 * d->I;
+}
+
+int halo16_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, double flops, hipStream_t st) {
+  SRGAN_REQUIRE(halo16_wgrad_applicable(d), "halo16 wgrad: layer not applicable");
+  Halo16WgradParams p{};
+  halo16_wgrad_plan(d, &p);
+  p.x = x; p.dy = dy; p.slab = slab;
+  ProfToken tok = prof_begin(25, flops, st);
+  hipLaunchKernelGGL(halo16_wgrad_kernel, dim3((unsigned)(p.o_tiles * p.c_tiles * p.splits)), dim3(256), 0, st, p);
+  prof_end(tok, st);
+  return check_launch("halo16_wgrad_kernel");
 }
 
 }  // namespace srgan

@@ -977,19 +977,23 @@ static int wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
   return variant;
 }
 
+// bf16 mode: the slot serves the residual-trunk shapes through conv_halo16.hip's weight-gradient kernel (not a Winograd form)
 bool wino_wgrad_applicable(const srgan_conv_desc* d) {
+  if (compute_bf16()) return halo16_wgrad_applicable(d);
   WinoWgradParams p{};
   return wino_wgrad_geometry(d, &p) != 0;
 }
 
 // slab geometry for wgrad_reduce_kernel: [splits][Cdpad = O][NNpad = kh * kw * I]
 void wino_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad) {
+  if (compute_bf16()) { halo16_wgrad_slab(d, splits, Cdpad, NNpad); return; }
   WinoWgradParams p{};
   wino_wgrad_geometry(d, &p);
   *splits = p.splits; *Cdpad = p.Opad; *NNpad = d->kh * d->kw * d->I;
 }
 
 int wino_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, hipStream_t st) {
+  if (compute_bf16()) return halo16_wgrad_run(d, x, dy, slab, conv_flops_of(d), st);
   WinoWgradParams p{};
   const int variant = wino_wgrad_geometry(d, &p);
   SRGAN_REQUIRE(variant != 0, "winograd wgrad: layer not applicable");
