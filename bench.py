@@ -475,7 +475,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": name, "achieved": round(executed, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(executed / peak, 4),
                          "traffic": traffic,
-                         "traffic_note": f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC) REPLAYED from {traffic_src}: "
+                         "traffic_note": "no PMC entry for this kernel under profiles/" if traffic is None else
+                                         f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC) REPLAYED from {traffic_src}: "
                                          "collected over this same command in separate --pmc passes, not measured in this run",
                          "achieved_note": "achieved / frac = MFMA FLOPs this kernel actually ISSUES (algorithmic conv FLOPs / "
                                           f"{div:g}) / HIP-event duration, against the dense matrix peak: the utilisation of the matrix pipe",
