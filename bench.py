@@ -134,11 +134,13 @@ def cpu_baseline(size, k):
                       f"after a k=1 batch-2 warm-up; {dt:.1f} s on {cores} threads"}
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` REPLAYED from the committed PMC summary (profiles/r*_pmc_traffic.json, collected
-    with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same bench command) -- not measured in this run."""
+def pmc_traffic(kernel_name, dtype="f32"):
+    """HBM bytes per launch of `kernel_name` REPLAYED from the committed PMC summary (profiles/r*_pmc_traffic.json, or
+    r*_bf16_pmc_traffic.json for --dtype bf16; collected with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+    same bench command) -- not measured in this run."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
+                   if ("_bf16_" in os.path.basename(f)) == (dtype == "bf16"))
     if not files:
         return None, None
     try:
@@ -450,7 +452,7 @@ def main():
         step_ms_mean = 1e3 * elapsed / args.steps
         for kk in kernels.values():
             kk.pop("_ms"), kk.pop("_fl")
-        traffic, traffic_src = pmc_traffic(name)
+        traffic, traffic_src = pmc_traffic(name, args.dtype)
         gflop_img = (GFLOP_PER_IMAGE_FROZEN_E if args.pretrained_e else GFLOP_PER_IMAGE).get(args.size)
         out = {
             "metric": "images/sec G+D+E train step, CelebA 128x128 bs=32/GPU" if (args.size == 128 and B == 32) else
@@ -462,8 +464,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SRGAN-{'full, pretrained-E recipe (05-train)' if args.pretrained_e else 'nopretrain (03-train)'} "
                                    f"G+D+E train step, {args.size}x{args.size}, "
-                                   f"bs={B}/GPU, k={args.k}, " + ("fp32" if args.dtype == "f32" else "bf16 MFMA conv forward / input gradient, "
-                                   "fp32 storage, weight gradients, norms, losses, Adam") +
+                                   f"bs={B}/GPU, k={args.k}, " + ("fp32" if args.dtype == "f32" else "bf16 MFMA convolutions (forward, input and weight gradient; "
+                                   "fp32 accumulation), fp32 tensors in HBM, fp32 norms, losses, Adam") +
                                    (", E trunk frozen (BASELINE configs[2])" if args.pretrained_e else ", E trainable (BASELINE configs[1])"),
                        "global_batch": B * world, "unrolled_k": args.k, "parallelism": f"dp{world}",
                        "execution": ("eager launches" if not graphed else "hipGraph replay of the captured step" if world == 1 else

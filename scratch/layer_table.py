@@ -5,6 +5,9 @@ import torch
 import bench
 from srgan_amd import _lib
 lib = _lib.load()
+if os.environ.get("SRGAN_DTYPE") == "bf16":
+    from srgan_amd import ops
+    ops.set_compute_dtype("bf16")
 B = 32
 sg = bench.build_trainer(128, B, 5, torch.device("cuda"))
 batches = []

@@ -6,6 +6,7 @@ import csv, glob, json, os, re, shutil, sys, collections
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ev = os.path.join(root, "gpurun_out", "ev")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
+pmc_tag = tag[:-6] if tag.endswith("_final") else tag      # r02_final -> r02_pmc_*.json; r02_bf16 -> r02_bf16_pmc_*.json
 
 
 def prof_name(n):
@@ -34,6 +35,10 @@ def prof_name(n):
         return "wino43_input_kernel"
     if n.startswith("wino43_kernel"):
         return "wino43_kernel"
+    if "halo16_wgrad_kernel" in n:
+        return "halo16_wgrad_kernel"
+    if "halo16_kernel" in n:
+        return "halo16_kernel"
     return None
 
 
@@ -64,7 +69,7 @@ for k in sorted(fetch):
     f, w = sum(fetch[k]) / len(fetch[k]), sum(write[k]) / max(len(write[k]), 1)
     out["kernels"][k] = {"launches": len(fetch[k]), "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
                          "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
-json.dump(out, open(os.path.join(root, "profiles", tag.split("_")[0] + "_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(root, "profiles", pmc_tag + "_pmc_traffic.json"), "w"), indent=1)
 
 # matrix-pipe utilisation per GEMM kernel: SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs (= 64 x #MFMA for the fp32
 # 32x32x2 instruction); GRBM_GUI_ACTIVE is summed over the 8 XCDs, so GUI/8 is the kernel's length in shader cycles
@@ -78,7 +83,7 @@ if glob.glob(os.path.join(ev, "mfma", "*", "*counter_collection.csv")):
         b, g = sum(busy[k]), sum(gui[k])
         util["kernels"][k] = {"launches": len(busy[k]), "mfma_busy_cycles": int(b), "gui_active": int(g),
                               "mfma_utilisation": round(b / (1024.0 * g / 8.0), 4) if g else None}
-    json.dump(util, open(os.path.join(root, "profiles", tag.split("_")[0] + "_pmc_mfma.json"), "w"), indent=1)
+    json.dump(util, open(os.path.join(root, "profiles", pmc_tag + "_pmc_mfma.json"), "w"), indent=1)
 stats = newest(os.path.join(ev, "stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(root, "profiles", tag + "_bench_steps5_kernel_stats.csv"))
 for src, dst in (("bench_plain.json", tag + "_bench_steps20.json"), ("bench_eager.json", tag + "_bench_steps20_eager.json"),
