@@ -195,6 +195,29 @@ int srgan_linear_fwd(const float* x, const float* W, const float* b, float* y, i
 int srgan_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db,
                      int M, int N, int K, void* stream);
 
+/* bf16 compute mode, residual-trunk layers (3x3 / stride 1 / zero pad 1, Cin = Cout in {64, 128, 256}, maps of whole 4 x 32
+ * patches; reference pyfiles/model.py:188-201) with bf16 TENSORS in HBM on either side: the kernels of the fused residual block
+ * whose intermediates -- conv outputs, the normalised activation, the gradients between the norm and conv backward kernels --
+ * are stored as bf16 (fp32 accumulation, fp32 statistics, fp32 master weights and residual stream).  `*_bf16` flags say which
+ * side is bf16 ([N][H][W][C] dense NHWC either way).  `packed`: the ordinary packed operand of (d, kind) made in bf16 mode.
+ * srgan_halo16_conv: kind 0 forward, kind 1 input gradient (+ `res`, fp32, added to an fp32 result).  srgan_halo16_wgrad: dw
+ * (fp32, through the descriptor's weight strides); bf16 x requires bf16 dy.  ws: srgan_conv2d_workspace(d) bytes. */
+int srgan_halo16_applicable(const srgan_conv_desc* d);
+int srgan_halo16_conv(const srgan_conv_desc* d, int kind, const void* src, int src_bf16, const void* packed, const float* res,
+                      void* dst, int dst_bf16, void* stream);
+int srgan_halo16_wgrad(const srgan_conv_desc* d, const void* x, int x_bf16, const void* dy, int dy_bf16, float* dw, void* ws,
+                       size_t ws_bytes, void* stream);
+/* Single-pass instance norm (+ per-sample scale / shift, activation, optional fp32 skip tensor) of maps with <= 1024 pixels with
+ * bf16 tensors on either side; statistics, sums, scale / shift gradients in fp32.  Backward: x = the normalised tensor's INPUT
+ * (bf16), dy fp32 or bf16, dx bf16.  srgan_instnorm_slab_applicable: the shape is served (C % 32 == 0, HW <= 1024, enough slabs). */
+int srgan_instnorm_slab_applicable(int N, int HW, int C);
+int srgan_instnorm_slab_fwd_io(const void* x, int x_bf16, const float* scale, const float* shift, const float* res, void* y,
+                               int y_bf16, float* mean, float* rstd, int N, int HW, int C, float eps, int act, float slope,
+                               void* stream);
+int srgan_instnorm_slab_bwd_io(const void* x, int x_bf16, const void* dy, int dy_bf16, const float* scale, const float* shift,
+                               const float* mean, const float* rstd, void* dx, int dx_bf16, float* dscale, float* dshift, int N,
+                               int HW, int C, int act, float slope, void* stream);
+
 /* NCHW <-> NHWC repack at the module boundary. */
 int srgan_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);
 int srgan_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);

@@ -127,11 +127,12 @@ int wino_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, fl
 // conv_wino.hip's slot -- not a Winograd transform, it shares the packed-filter plumbing)
 bool halo16_applicable(const srgan_conv_desc* d, int kind);
 size_t halo16_packed_bytes(const srgan_conv_desc* d);
-int halo16_run(const srgan_conv_desc* d, int kind, const float* src, const void* packed, const float* bias, const float* res,
-               float* dst, int act, float slope, double flops, hipStream_t st);
+int halo16_run(const srgan_conv_desc* d, int kind, const void* src, const void* packed, const float* bias, const float* res,
+               void* dst, int act, float slope, double flops, hipStream_t st, bool in16 = false, bool out16 = false);
 bool halo16_wgrad_applicable(const srgan_conv_desc* d);
 void halo16_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad);
-int halo16_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, double flops, hipStream_t st);
+int halo16_wgrad_run(const srgan_conv_desc* d, const void* x, const void* dy, float* slab, double flops, hipStream_t st,
+                     bool x16 = false, bool d16 = false);
 
 // conv_rgbin.hip: 3-channel-input 7x7 stride-1 layers on the MFMA (LDS-staged halo)
 bool rgbin_applicable(const srgan_conv_desc* d);

@@ -39,11 +39,11 @@ constexpr int HK = 32;                 // reduce channels per K tile
 constexpr int HPX = 6 * 34;            // halo pixels of a 4 x 32 patch
 
 struct Halo16Params {
-  const float* src;            // [NB][H][W][C] fp32
+  const void* src;             // [NB][H][W][C] fp32, or bf16 (IN16)
   const unsigned short* wp;    // packed bf16 filters
   const float* bias;           // [N] or null
-  const float* res;            // [NB][H][W][N] or null
-  float* dst;                  // [NB][H][W][N]
+  const float* res;            // [NB][H][W][N] fp32 or null
+  void* dst;                   // [NB][H][W][N] fp32, or bf16 (OUT16)
   int NB, H, W, N, tiles_y, tiles_x, n_tiles, act;
   float slope;
 };
@@ -55,8 +55,12 @@ __device__ __forceinline__ auto uniform_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-template <int C, int BN, bool RES>
+// IN16 / OUT16: the source / destination tensor is bf16 in HBM (the intermediates of the fused residual block, ops._ResBlockBf16Fn:
+// conv outputs, the normalised activation, the gradients between the norm and conv backward kernels); fp32 otherwise.
+template <int C, int BN, bool RES, bool IN16, bool OUT16>
 __global__ __launch_bounds__(256) void halo16_kernel(Halo16Params p) {
+  static_assert(!(RES && OUT16), "the skip gradient is added to an fp32 result");
+  constexpr int ISZ = IN16 ? 2 : 4;            // bytes per source element
   constexpr int PS = C * 2 + 16;               // bytes per halo pixel
   constexpr int NQ = C / 64;                   // 64-channel quarters of the reduce dimension (K order: quarter, tap, 32-chunk)
   constexpr int NK = 9 * NQ * 2;               // K tiles
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void halo16_kernel(Halo16Params p) {
   const int nb = r / p.tiles_y;
   const int Y0 = ty * 4, X0 = tx * 32;
 
-  const auto rs_x = uniform_rsrc(p.src, (unsigned)((size_t)p.NB * p.H * p.W * C * 4));
+  const auto rs_x = uniform_rsrc(p.src, (unsigned)((size_t)p.NB * p.H * p.W * C * ISZ));
   const auto rs_w = uniform_rsrc(p.wp + (size_t)nt * NK * (BN * HK), (unsigned)(NK * BN * HK * 2));
 
   // ---- weight tiles: global -> registers -> LDS, three buffers (tile kt + 1 is readable while tile kt is multiplied) ----
@@ -111,15 +115,19 @@ __global__ __launch_bounds__(256) void halo16_kernel(Halo16Params p) {
     const int hr = hp / 34, hc = hp - hr * 34;
     const int y = Y0 - 1 + hr, x = X0 - 1 + hc;
     const bool ok = hp < HPX && y >= 0 && y < p.H && x >= 0 && x < p.W;
-    return ok ? (unsigned)((((nb * p.H + y) * p.W + x) * C + quarter * 64 + hcg * 8) * 4) : kOutside;
+    return ok ? (unsigned)((((nb * p.H + y) * p.W + x) * C + quarter * 64 + hcg * 8) * ISZ) : kOutside;
   };
   auto halo_put = [&](int quarter, int pass, f32x4 lo, f32x4 hi) __attribute__((always_inline)) {
     const int hp = pass * 32 + hpl;
     if (hp < HPX) {
-      const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
-      bf16x8 v;
-      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-      *reinterpret_cast<bf16x8*>(&halo[hp * PS + quarter * 128 + hcg * 16]) = v;
+      if constexpr (IN16) {                      // lo already holds the 8 bf16 channels
+        *reinterpret_cast<f32x4*>(&halo[hp * PS + quarter * 128 + hcg * 16]) = lo;
+      } else {
+        const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+        bf16x8 v;
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        *reinterpret_cast<bf16x8*>(&halo[hp * PS + quarter * 128 + hcg * 16]) = v;
+      }
     }
   };
   {
@@ -128,7 +136,8 @@ __global__ __launch_bounds__(256) void halo16_kernel(Halo16Params p) {
     for (int g = 0; g < HP; ++g) {
       const unsigned off = halo_off(0, g);
       lo[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
-      hi[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+      if constexpr (!IN16) hi[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+      else hi[g] = lo[g];
     }
     store_w(wreg, 0);
     store_w(wreg2, WTILE);
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256) void halo16_kernel(Halo16Params p) {
         if (tap < HP) {
           const unsigned off = halo_off(q + 1, tap);
           hlo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
-          hhi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+          if constexpr (!IN16) hhi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
         }
       }
 #pragma unroll
@@ -229,7 +238,9 @@ __global__ __launch_bounds__(256) void halo16_kernel(Halo16Params p) {
       for (int e = 0; e < 16; ++e) {
         float v = apply_act(acc[i][j][e] + bv, p.act, p.slope);
         if constexpr (RES) v += rv[e];
-        p.dst[row + (size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * p.N + n] = v;
+        const size_t o = row + (size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * p.N + n;
+        if constexpr (OUT16) static_cast<__bf16*>(p.dst)[o] = (__bf16)v;
+        else static_cast<float*>(p.dst)[o] = v;
       }
     }
   }
@@ -247,8 +258,8 @@ __global__ __launch_bounds__(256) void halo16_kernel(Halo16Params p) {
 // during the products (double-buffered LDS, one barrier per patch).  Split-K over patch ranges into [split][O][9 C] slabs, summed
 // by wgrad_reduce_kernel (conv_igemm.hip) like every other weight-gradient kernel.
 struct Halo16WgradParams {
-  const float* x;     // [NB][H][W][C]
-  const float* dy;    // [NB][H][W][O]
+  const void* x;      // [NB][H][W][C] fp32, or bf16 (X16)
+  const void* dy;     // [NB][H][W][O] fp32, or bf16 (D16)
   float* slab;        // [splits][O][9 C]
   int NB, H, W, C, O, tiles_y, tiles_x, patches, per_split, splits, o_tiles, c_tiles;
 };
@@ -256,7 +267,9 @@ struct Halo16WgradParams {
 constexpr int GPS = 192;               // bytes per pixel row of a 64-channel bf16 slice in LDS
 constexpr int GX = HPX * GPS, GD = 128 * GPS;
 
+template <bool X16, bool D16>
 __global__ __launch_bounds__(256) void halo16_wgrad_kernel(Halo16WgradParams p) {
+  constexpr int XSZ = X16 ? 2 : 4, DSZ = D16 ? 2 : 4;
   typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4;
   __shared__ __attribute__((aligned(16))) unsigned char xs[2 * GX];
   __shared__ __attribute__((aligned(16))) unsigned char ds[2 * GD];
@@ -274,8 +287,8 @@ __global__ __launch_bounds__(256) void halo16_wgrad_kernel(Halo16WgradParams p) 
   const int ot = tile / p.c_tiles, ct = tile - ot * p.c_tiles;
   const int p_begin = split * p.per_split, p_end = min(p_begin + p.per_split, p.patches);
 
-  const auto rs_x = uniform_rsrc(p.x, (unsigned)((size_t)p.NB * p.H * p.W * p.C * 4));
-  const auto rs_d = uniform_rsrc(p.dy, (unsigned)((size_t)p.NB * p.H * p.W * p.O * 4));
+  const auto rs_x = uniform_rsrc(p.x, (unsigned)((size_t)p.NB * p.H * p.W * p.C * XSZ));
+  const auto rs_d = uniform_rsrc(p.dy, (unsigned)((size_t)p.NB * p.H * p.W * p.O * DSZ));
   constexpr unsigned kOutside = 0x80000000u;
   const int hcg = tid & 7, hpl = tid >> 3;           // 8 channels of one of the 32 pixels of a pass
 
@@ -292,16 +305,16 @@ __global__ __launch_bounds__(256) void halo16_wgrad_kernel(Halo16WgradParams p) 
       const int hr = hp / 34, hc = hp - hr * 34;
       const int y = Y0 - 1 + hr, x = X0 - 1 + hc;
       const bool ok = hp < HPX && y >= 0 && y < p.H && x >= 0 && x < p.W;
-      const unsigned off = ok ? (unsigned)((((nb * p.H + y) * p.W + x) * p.C + ct * 64 + hcg * 8) * 4) : kOutside;
+      const unsigned off = ok ? (unsigned)((((nb * p.H + y) * p.W + x) * p.C + ct * 64 + hcg * 8) * XSZ) : kOutside;
       xl[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
-      xh[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+      if constexpr (!X16) xh[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int px = g * 32 + hpl;                   // pixel (px / 32, px % 32) of the patch
-      const unsigned off = (unsigned)((((nb * p.H + Y0 + (px >> 5)) * p.W + X0 + (px & 31)) * p.O + ot * 64 + hcg * 8) * 4);
+      const unsigned off = (unsigned)((((nb * p.H + Y0 + (px >> 5)) * p.W + X0 + (px & 31)) * p.O + ot * 64 + hcg * 8) * DSZ);
       dl[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 0, 0));
-      dh[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 16, 0));
+      if constexpr (!D16) dh[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 16, 0));
     }
   };
   auto pack8 = [](f32x4 lo, f32x4 hi) __attribute__((always_inline)) {
@@ -314,11 +327,16 @@ __global__ __launch_bounds__(256) void halo16_wgrad_kernel(Halo16WgradParams p) 
 #pragma unroll
     for (int g = 0; g < 7; ++g) {
       const int hp = g * 32 + hpl;
-      if (hp < HPX) *reinterpret_cast<bf16x8*>(&xs[buf * GX + hp * GPS + hcg * 16]) = pack8(xl[g], xh[g]);
+      if (hp < HPX) {
+        if constexpr (X16) *reinterpret_cast<f32x4*>(&xs[buf * GX + hp * GPS + hcg * 16]) = xl[g];
+        else *reinterpret_cast<bf16x8*>(&xs[buf * GX + hp * GPS + hcg * 16]) = pack8(xl[g], xh[g]);
+      }
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<bf16x8*>(&ds[buf * GD + (g * 32 + hpl) * GPS + hcg * 16]) = pack8(dl[g], dh[g]);
+    for (int g = 0; g < 4; ++g) {
+      if constexpr (D16) *reinterpret_cast<f32x4*>(&ds[buf * GD + (g * 32 + hpl) * GPS + hcg * 16]) = dl[g];
+      else *reinterpret_cast<bf16x8*>(&ds[buf * GD + (g * 32 + hpl) * GPS + hcg * 16]) = pack8(dl[g], dh[g]);
+    }
   };
 
   f32x16 acc[9];
@@ -376,9 +394,19 @@ __global__ __launch_bounds__(256) void halo16_wgrad_kernel(Halo16WgradParams p) 
 }
 
 template <int C>
-int launch_c(const Halo16Params& p, long long grid, hipStream_t st) {
-  if (p.res) hipLaunchKernelGGL((halo16_kernel<C, C, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((halo16_kernel<C, C, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
+int launch_c(const Halo16Params& p, bool in16, bool out16, long long grid, hipStream_t st) {
+  const dim3 g((unsigned)grid), b(256);
+  if (!in16 && !out16) {
+    if (p.res) hipLaunchKernelGGL((halo16_kernel<C, C, true, false, false>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((halo16_kernel<C, C, false, false, false>), g, b, 0, st, p);
+  } else if (!in16 && out16) {
+    hipLaunchKernelGGL((halo16_kernel<C, C, false, false, true>), g, b, 0, st, p);
+  } else if (in16 && out16) {
+    hipLaunchKernelGGL((halo16_kernel<C, C, false, true, true>), g, b, 0, st, p);
+  } else {
+    if (p.res) hipLaunchKernelGGL((halo16_kernel<C, C, true, true, false>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((halo16_kernel<C, C, false, true, false>), g, b, 0, st, p);
+  }
   return 0;
 }
 
@@ -397,9 +425,10 @@ bool halo16_applicable(const srgan_conv_desc* d, int kind) {
 size_t halo16_packed_bytes(const srgan_conv_desc* d) { return (size_t)9 * d->I * d->O * 2; }
 
 // src: x (kind 0) or dy (kind 1), both [N][H][W][C]; dst likewise with the other channel count (equal here)
-int halo16_run(const srgan_conv_desc* d, int kind, const float* src, const void* packed, const float* bias, const float* res,
-               float* dst, int act, float slope, double flops, hipStream_t st) {
+int halo16_run(const srgan_conv_desc* d, int kind, const void* src, const void* packed, const float* bias, const float* res,
+               void* dst, int act, float slope, double flops, hipStream_t st, bool in16, bool out16) {
   SRGAN_REQUIRE(halo16_applicable(d, kind), "halo16: layer not applicable");
+  SRGAN_REQUIRE(!(res && out16), "halo16: the skip gradient is added to an fp32 result only");
   Halo16Params p{};
   p.src = src; p.wp = reinterpret_cast<const unsigned short*>(packed); p.bias = bias; p.res = res; p.dst = dst;
   p.NB = d->N; p.H = d->Hi; p.W = d->Wi; p.N = d->I;
@@ -407,9 +436,9 @@ int halo16_run(const srgan_conv_desc* d, int kind, const float* src, const void*
   const long long grid = (long long)p.NB * p.tiles_y * p.tiles_x * p.n_tiles;
   SRGAN_REQUIRE(grid > 0 && grid < (1LL << 31), "halo16: grid");
   ProfToken tok = prof_begin(24, flops, st);
-  if (d->I == 256) launch_c<256>(p, grid, st);
-  else if (d->I == 128) launch_c<128>(p, grid, st);
-  else launch_c<64>(p, grid, st);
+  if (d->I == 256) launch_c<256>(p, in16, out16, grid, st);
+  else if (d->I == 128) launch_c<128>(p, in16, out16, grid, st);
+  else launch_c<64>(p, in16, out16, grid, st);
   prof_end(tok, st);
   return check_launch("halo16_kernel");
 }
@@ -437,13 +466,18 @@ void halo16_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* N
   *splits = p.splits; *Cdpad = d->O; *NNpad = 9 * d->I;
 }
 
-int halo16_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, double flops, hipStream_t st) {
+int halo16_wgrad_run(const srgan_conv_desc* d, const void* x, const void* dy, float* slab, double flops, hipStream_t st, bool x16,
+                     bool d16) {
   SRGAN_REQUIRE(halo16_wgrad_applicable(d), "halo16 wgrad: layer not applicable");
   Halo16WgradParams p{};
   halo16_wgrad_plan(d, &p);
   p.x = x; p.dy = dy; p.slab = slab;
   ProfToken tok = prof_begin(25, flops, st);
-  hipLaunchKernelGGL(halo16_wgrad_kernel, dim3((unsigned)(p.o_tiles * p.c_tiles * p.splits)), dim3(256), 0, st, p);
+  const dim3 grid((unsigned)(p.o_tiles * p.c_tiles * p.splits));
+  if (!x16 && !d16) hipLaunchKernelGGL((halo16_wgrad_kernel<false, false>), grid, dim3(256), 0, st, p);
+  else if (!x16 && d16) hipLaunchKernelGGL((halo16_wgrad_kernel<false, true>), grid, dim3(256), 0, st, p);
+  else if (x16 && d16) hipLaunchKernelGGL((halo16_wgrad_kernel<true, true>), grid, dim3(256), 0, st, p);
+  else { set_error("halo16 wgrad: bf16 x with fp32 dy is not instantiated"); return -1; }
   prof_end(tok, st);
   return check_launch("halo16_wgrad_kernel");
 }

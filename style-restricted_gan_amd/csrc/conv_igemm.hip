@@ -1878,6 +1878,38 @@ extern "C" int srgan_conv2d_wgrad_vz(const srgan_conv_desc* d, const float* v_im
   return finish_wgrad(d, w, nullptr, dw, nullptr, ws, st);
 }
 
+// ---- bf16 mode, residual-trunk shapes (conv_halo16.hip) with bf16 TENSORS on either side: the convolution kernels of the fused
+// residual block (srgan_amd.ops._ResBlockBf16Fn), whose intermediates (conv outputs, normalised activation, the gradients between
+// the norm and conv backward kernels) live in HBM as bf16.  `packed`: the ordinary packed operand of (d, kind) in bf16 mode
+// (srgan_conv2d_pack / the pack cache).
+extern "C" int srgan_halo16_applicable(const srgan_conv_desc* d) {
+  if (validate(d) != 0) return 0;
+  return compute_bf16() && halo16_applicable(d, 0) && halo16_wgrad_applicable(d) && wino_applicable(d, 0) && wino_applicable(d, 1) ? 1 : 0;
+}
+
+extern "C" int srgan_halo16_conv(const srgan_conv_desc* d, int kind, const void* src, int src_bf16, const void* packed,
+                                 const float* res, void* dst, int dst_bf16, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(src && packed && dst, "halo16_conv: null pointer");
+  SRGAN_REQUIRE(kind == 0 || kind == 1, "halo16_conv: kind must be 0 (forward) or 1 (input gradient)");
+  SRGAN_REQUIRE(srgan_halo16_applicable(d), "halo16_conv: layer / compute mode not applicable (srgan_halo16_applicable)");
+  return halo16_run(d, kind, src, packed, nullptr, res, dst, SRGAN_ACT_NONE, 0.f, conv_flops(d), as_stream(stream), src_bf16 != 0,
+                    dst_bf16 != 0);
+}
+
+extern "C" int srgan_halo16_wgrad(const srgan_conv_desc* d, const void* x, int x_bf16, const void* dy, int dy_bf16, float* dw,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(x && dy && dw && ws, "halo16_wgrad: null pointer");
+  SRGAN_REQUIRE(srgan_halo16_applicable(d), "halo16_wgrad: layer / compute mode not applicable (srgan_halo16_applicable)");
+  SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "halo16_wgrad: workspace too small (srgan_conv2d_workspace)");
+  hipStream_t st = as_stream(stream);
+  WgradPlan w = plan_wgrad(d);
+  halo16_wgrad_slab(d, &w.splits, &w.Cdpad, &w.NNpad);
+  if (int e = halo16_wgrad_run(d, x, dy, (float*)ws, conv_flops(d), st, x_bf16 != 0, dy_bf16 != 0)) return e;
+  return finish_wgrad(d, w, nullptr, dw, nullptr, ws, st);
+}
+
 namespace srgan {
 static int launch_wgrad(const WgradParams& p, const WgradPlan& w, hipStream_t st) {
   WgradVariant k{};

@@ -525,12 +525,24 @@ __device__ __forceinline__ void slab_coords(int nslab, int N, int remap, int& sl
   }
 }
 
+// 4 consecutive channels of an fp32 or bf16 tensor <-> f32x4 (bf16 tensors: the intermediates of ops._ResBlockBf16Fn)
+template <bool B16>
+__device__ __forceinline__ f32x4 ld4(const void* base, size_t idx) {
+  if constexpr (B16) return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(base) + idx), f32x4);
+  else return *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + idx);
+}
+template <bool B16>
+__device__ __forceinline__ void st4(void* base, size_t idx, f32x4 v) {
+  if constexpr (B16) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(base) + idx) = __builtin_convertvector(v, bf16x4);
+  else *reinterpret_cast<f32x4*>(static_cast<float*>(base) + idx) = v;
+}
+
 // forward: 512 threads over HW x 32 channels (8 lanes per pixel: whole 128-byte lines; 16-channel slabs with 256 threads were
 // measured slower here, 45.6 vs 34.7 us on the 32x32x256 trunk, while they help the backward below)
-template <int R>
-__global__ __launch_bounds__(512) void in_fwd_slab(const float* __restrict__ x, const float* __restrict__ scale,
+template <int R, bool X16 = false, bool Y16 = false>
+__global__ __launch_bounds__(512) void in_fwd_slab(const void* __restrict__ x, const float* __restrict__ scale,
                                                    const float* __restrict__ shift, const float* __restrict__ res,
-                                                   float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                   void* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                    int HW, int C, float eps, int act, float slope, int remap) {
   __shared__ f32x4 sh[8][8];
   const int q = threadIdx.x & 7, ty = threadIdx.x >> 3, wave = threadIdx.x >> 6;
@@ -543,7 +555,7 @@ __global__ __launch_bounds__(512) void in_fwd_slab(const float* __restrict__ x, 
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int r = ty + 64 * j;
-    v[j] = r < HW ? *reinterpret_cast<const f32x4*>(x + base + (size_t)r * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+    v[j] = r < HW ? ld4<X16>(x, base + (size_t)r * C) : f32x4{0.f, 0.f, 0.f, 0.f};
     s += v[j];
   }
   const float inv = 1.f / (float)HW;
@@ -577,7 +589,7 @@ __global__ __launch_bounds__(512) void in_fwd_slab(const float* __restrict__ x, 
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = apply_act(o[e], act, slope);
       if (res) o += *reinterpret_cast<const f32x4*>(res + base + (size_t)r * C);
-      *reinterpret_cast<f32x4*>(y + base + (size_t)r * C) = o;
+      st4<Y16>(y, base + (size_t)r * C, o);
     }
   }
 }
@@ -585,11 +597,11 @@ __global__ __launch_bounds__(512) void in_fwd_slab(const float* __restrict__ x, 
 // backward: x-hat and the masked dy both stay in registers (2 x R float4 per thread); 256-thread workgroups over HW x 16
 // channels (4 lanes per pixel), two resident per CU so one's reduction / store phase overlaps the other's loads (38 us
 // against 43 us with one 1024-thread workgroup per CU).
-template <int R>
-__global__ __launch_bounds__(256) void in_bwd_slab(const float* __restrict__ x, const float* __restrict__ dy,
+template <int R, bool X16 = false, bool G16 = false, bool D16 = false>
+__global__ __launch_bounds__(256) void in_bwd_slab(const void* __restrict__ x, const void* __restrict__ dy,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                    float* __restrict__ dx, float* __restrict__ dscale,
+                                                    void* __restrict__ dx, float* __restrict__ dscale,
                                                     float* __restrict__ dshift, int HW, int C, int act, float slope, int remap) {
   __shared__ f32x4 sh[4][8];
   const int q = threadIdx.x & 3, ty = threadIdx.x >> 2, wave = threadIdx.x >> 6;
@@ -610,8 +622,8 @@ __global__ __launch_bounds__(256) void in_bwd_slab(const float* __restrict__ x, 
   for (int j = 0; j < R; ++j) {
     const int r = ty + 64 * j;
     if (r < HW) {
-      xh[j] = (*reinterpret_cast<const f32x4*>(x + base + (size_t)r * C) - mu) * rs;
-      g[j] = *reinterpret_cast<const f32x4*>(dy + base + (size_t)r * C);
+      xh[j] = (ld4<X16>(x, base + (size_t)r * C) - mu) * rs;
+      g[j] = ld4<G16>(dy, base + (size_t)r * C);
       const f32x4 z = xh[j] * sc + sf;
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[j][e] *= act_grad(z[e], act, slope);
@@ -633,7 +645,7 @@ __global__ __launch_bounds__(256) void in_bwd_slab(const float* __restrict__ x, 
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int r = ty + 64 * j;
-    if (r < HW) *reinterpret_cast<f32x4*>(dx + base + (size_t)r * C) = k * (g[j] - mg - xh[j] * mgx);
+    if (r < HW) st4<D16>(dx, base + (size_t)r * C, k * (g[j] - mg - xh[j] * mgx));
   }
 }
 
@@ -757,6 +769,63 @@ extern "C" int srgan_instnorm_bwd(const float* x, const float* dy, const float* 
     hipLaunchKernelGGL(in_bwd_apply<false>, dim3(blocks), dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, total, HW * C, C, inv_hw, act, slope);
   }
   return check_launch("instnorm_bwd");
+}
+
+// ---- single-pass slab kernels with bf16 tensors on either side (statistics, scale / shift, sums in fp32) ----
+extern "C" int srgan_instnorm_slab_applicable(int N, int HW, int C) { return slab_fast(N, HW, C) ? 1 : 0; }
+
+extern "C" int srgan_instnorm_slab_fwd_io(const void* x, int x_bf16, const float* scale, const float* shift, const float* res,
+                                          void* y, int y_bf16, float* mean, float* rstd, int N, int HW, int C, float eps, int act,
+                                          float slope, void* stream) {
+  SRGAN_REQUIRE(x && y && mean && rstd, "instnorm_slab_fwd_io: null pointer");
+  SRGAN_REQUIRE((scale == nullptr) == (shift == nullptr), "instnorm_slab_fwd_io: scale and shift go together");
+  SRGAN_REQUIRE(slab_fast(N, HW, C), "instnorm_slab_fwd_io: shape not served by the slab kernels (srgan_instnorm_slab_applicable)");
+  SRGAN_REQUIRE(!(res && y_bf16), "instnorm_slab_fwd_io: the skip tensor is added to an fp32 result only");
+  hipStream_t st = as_stream(stream);
+  const dim3 gs((unsigned)(C / 32), (unsigned)N);
+  const int rows = (HW + 63) / 64;
+#define SRGAN_FWD_IO(R, A, B) hipLaunchKernelGGL((in_fwd_slab<R, A, B>), gs, dim3(512), 0, st, x, scale, shift, res, y, mean, rstd, HW, C, eps, act, slope, slab_remap())
+#define SRGAN_FWD_IO_R(A, B)                  \
+  do {                                        \
+    if (rows <= 1) SRGAN_FWD_IO(1, A, B);     \
+    else if (rows <= 2) SRGAN_FWD_IO(2, A, B);\
+    else if (rows <= 4) SRGAN_FWD_IO(4, A, B);\
+    else if (rows <= 8) SRGAN_FWD_IO(8, A, B);\
+    else SRGAN_FWD_IO(16, A, B);              \
+  } while (0)
+  if (x_bf16 && y_bf16) SRGAN_FWD_IO_R(true, true);
+  else if (x_bf16) SRGAN_FWD_IO_R(true, false);
+  else if (y_bf16) SRGAN_FWD_IO_R(false, true);
+  else SRGAN_FWD_IO_R(false, false);
+#undef SRGAN_FWD_IO_R
+#undef SRGAN_FWD_IO
+  return check_launch("instnorm_slab_fwd_io");
+}
+
+extern "C" int srgan_instnorm_slab_bwd_io(const void* x, int x_bf16, const void* dy, int dy_bf16, const float* scale,
+                                          const float* shift, const float* mean, const float* rstd, void* dx, int dx_bf16,
+                                          float* dscale, float* dshift, int N, int HW, int C, int act, float slope, void* stream) {
+  SRGAN_REQUIRE(x && dy && mean && rstd && dx && dscale && dshift, "instnorm_slab_bwd_io: null pointer");
+  SRGAN_REQUIRE((scale == nullptr) == (shift == nullptr), "instnorm_slab_bwd_io: scale and shift go together");
+  SRGAN_REQUIRE(slab_fast(N, HW, C), "instnorm_slab_bwd_io: shape not served by the slab kernels (srgan_instnorm_slab_applicable)");
+  SRGAN_REQUIRE(x_bf16 && dx_bf16, "instnorm_slab_bwd_io: instantiated for a bf16 conv output and a bf16 result (dy fp32 or bf16)");
+  hipStream_t st = as_stream(stream);
+  const dim3 gs((unsigned)(C / 16), (unsigned)N);
+  const int rows = (HW + 63) / 64;
+#define SRGAN_BWD_IO(R, G) hipLaunchKernelGGL((in_bwd_slab<R, true, G, true>), gs, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dx, dscale, dshift, HW, C, act, slope, slab_remap())
+#define SRGAN_BWD_IO_R(G)                  \
+  do {                                     \
+    if (rows <= 1) SRGAN_BWD_IO(1, G);     \
+    else if (rows <= 2) SRGAN_BWD_IO(2, G);\
+    else if (rows <= 4) SRGAN_BWD_IO(4, G);\
+    else if (rows <= 8) SRGAN_BWD_IO(8, G);\
+    else SRGAN_BWD_IO(16, G);              \
+  } while (0)
+  if (dy_bf16) SRGAN_BWD_IO_R(true);
+  else SRGAN_BWD_IO_R(false);
+#undef SRGAN_BWD_IO_R
+#undef SRGAN_BWD_IO
+  return check_launch("instnorm_slab_bwd_io");
 }
 
 extern "C" int srgan_cbin_affine_fwd(const float* c, const float* W, const float* b, const float* gamma,

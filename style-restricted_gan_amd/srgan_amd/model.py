@@ -186,6 +186,10 @@ class SingleResidualBlock(nn.Module):
                 # conv outputs are ever written (ops._ResBlockFn)
                 self.cn1._check_input_dim(data)
                 return ops.residual_block(data, s1, h1, s2, h2, self.c1.weight, self.c2.weight, self.cn1.eps), con
+            if ops.res_block_bf16_fusable(data, self.c1.weight, self.c2.weight, s1, s2):
+                # bf16 mode: one node, its intermediates stored as bf16 (ops._ResBlockBf16Fn)
+                self.cn1._check_input_dim(data)
+                return ops.residual_block_bf16(data, s1, h1, s2, h2, self.c1.weight, self.c2.weight, self.cn1.eps), con
         # the block input feeds c1 and the skip connection: conv2d_skip routes the skip path's gradient into c1's
         # input-gradient kernel (added in its epilogue) instead of a separate accumulation pass
         y1, skip = ops.conv2d_skip(data, self.c1.weight, None, self.c1.stride[0], self.c1.padding[0], PAD_ZERO)

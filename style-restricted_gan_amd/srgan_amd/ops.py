@@ -738,6 +738,118 @@ class _ResBlockFn(Function):
         return dx, ds1, dh1, ds2, dh2, dw1, dw2, None
 
 
+class _ResBlockBf16Fn(Function):
+    """SingleResidualBlock (pyfiles/model.py:196-201) in the bf16 compute mode as ONE autograd node whose INTERMEDIATES live in
+    HBM as bf16:
+
+        y1 = c1(x) [bf16];  h = relu(cbin1(y1)) [bf16];  y2 = c2(h) [bf16];  out = cbin2(y2) + x [fp32]
+
+    and in the backward  dy2 = cbin2'(y2, g) [bf16];  dh = c2^T(dy2) [bf16];  dy1 = (relu . cbin1)'(y1, dh) [bf16];
+    dx = c1^T(dy1) + g [fp32].  The residual stream (x, out, g, dx), the statistics, the scale / shift gradients, the weight
+    gradients and the master weights stay fp32; every product is bf16 x bf16 with fp32 accumulation on the LDS-resident-patch
+    kernels of csrc/conv_halo16.hip (which read a bf16 tensor without the fp32 -> bf16 conversion and at half the bytes), the
+    norms are the single-pass slab kernels with bf16 I/O.  Against the unfused bf16-mode chain the conv outputs are rounded to
+    bf16 before their statistics are taken (as under autocast), the normalised activation and the conv-output gradients are
+    rounded once instead of on every read.  Weights are held by reference and read at backward time (stale-graph semantics,
+    SURVEY.md Appendix C-1)."""
+
+    @staticmethod
+    def forward(ctx, x, s1, h1, s2, h2, w1, w2, eps):
+        lib = _lib.load()
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        dev = x.device
+        st = _stream()
+        d = _conv_desc(n, h, w, c, h, w, c, 3, 3, 1, 1, PAD_ZERO, w1)
+        d2 = _conv_desc(n, h, w, c, h, w, c, 3, 3, 1, 1, PAD_ZERO, w2)
+        hit1, _ = _packed(d, w1, 0, ACT_NONE)
+        hit2, _ = _packed(d2, w2, 0, ACT_NONE)
+
+        def b16():
+            return torch.empty((n, h, w, c), dtype=torch.bfloat16, device=dev)
+
+        y1, hh, y2 = b16(), b16(), b16()
+        _lib.check(lib.srgan_halo16_conv(ctypes.byref(d), 0, _ptr(x), 0, _ptr(hit1.buf), None, _ptr(y1), 1, st), "halo16_conv")
+        mean1 = torch.empty(n * c, dtype=torch.float32, device=dev)
+        rstd1, mean2, rstd2 = torch.empty_like(mean1), torch.empty_like(mean1), torch.empty_like(mean1)
+        _lib.check(lib.srgan_instnorm_slab_fwd_io(_ptr(y1), 1, _ptr(s1), _ptr(h1), None, _ptr(hh), 1, _ptr(mean1), _ptr(rstd1),
+                                                  n, h * w, c, float(eps), ACT_RELU, 0.0, st), "instnorm_slab_fwd_io")
+        _lib.check(lib.srgan_halo16_conv(ctypes.byref(d2), 0, _ptr(hh), 1, _ptr(hit2.buf), None, _ptr(y2), 1, st), "halo16_conv")
+        out = torch.empty_like(x)
+        _lib.check(lib.srgan_instnorm_slab_fwd_io(_ptr(y2), 1, _ptr(s2), _ptr(h2), _ptr(x), _ptr(out), 0, _ptr(mean2), _ptr(rstd2),
+                                                  n, h * w, c, float(eps), ACT_NONE, 0.0, st), "instnorm_slab_fwd_io")
+        ctx.d1, ctx.d2, ctx.w1, ctx.w2 = d, d2, w1, w2
+        ctx.save_for_backward(x, y1, hh, y2, s1, h1, s2, h2, mean1, rstd1, mean2, rstd2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, y1, hh, y2, s1, h1, s2, h2, mean1, rstd1, mean2, rstd2 = ctx.saved_tensors
+        g = to_nhwc(g)
+        n, c, h, w = x.shape
+        dev = g.device
+        st = _stream()
+        d1, d2, w1, w2 = ctx.d1, ctx.d2, ctx.w1, ctx.w2
+
+        def b16():
+            return torch.empty((n, h, w, c), dtype=torch.bfloat16, device=dev)
+
+        def norm_bwd(y, gup, gup16, sc, sh, mean, rstd, act):
+            dy = b16()
+            dsc = torch.empty(n, c, dtype=torch.float32, device=dev)
+            dsh = torch.empty_like(dsc)
+            _lib.check(lib.srgan_instnorm_slab_bwd_io(_ptr(y), 1, _ptr(gup), gup16, _ptr(sc), _ptr(sh), _ptr(mean), _ptr(rstd),
+                                                      _ptr(dy), 1, _ptr(dsc), _ptr(dsh), n, h * w, c, act, 0.0, st),
+                       "instnorm_slab_bwd_io")
+            return dy, dsc, dsh
+
+        def wgrad(desc, weight, xin, xin16, dy):
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+            dd = ConvDesc.from_buffer_copy(desc)
+            dd.sO, dd.sI, dd.sH, dd.sW = dw.stride()
+            ws, nb = _conv_ws(dd, dev)
+            _lib.check(lib.srgan_halo16_wgrad(ctypes.byref(dd), _ptr(xin), xin16, _ptr(dy), 1, _ptr(dw), _ptr(ws), nb, st),
+                       "halo16_wgrad")
+            return dw
+
+        dy2, ds2, dh2 = norm_bwd(y2, g, 0, s2, h2, mean2, rstd2, ACT_NONE)
+        dw2 = wgrad(d2, w2, hh, 1, dy2) if ctx.needs_input_grad[6] else None
+        hit2, _ = _packed(d2, w2, 1, ACT_NONE)
+        dh = b16()
+        _lib.check(lib.srgan_halo16_conv(ctypes.byref(d2), 1, _ptr(dy2), 1, _ptr(hit2.buf), None, _ptr(dh), 1, st), "halo16_conv")
+        dy1, ds1, dh1 = norm_bwd(y1, dh, 1, s1, h1, mean1, rstd1, ACT_RELU)
+        dw1 = wgrad(d1, w1, x, 0, dy1) if ctx.needs_input_grad[5] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            hit1, _ = _packed(d1, w1, 1, ACT_NONE)
+            dx = torch.empty_like(g)
+            _lib.check(lib.srgan_halo16_conv(ctypes.byref(d1), 1, _ptr(dy1), 1, _ptr(hit1.buf), _ptr(g), _ptr(dx), 0, st), "halo16_conv")
+        return dx, ds1, dh1, ds2, dh2, dw1, dw2, None
+
+
+def res_block_bf16_fusable(x, w1, w2, s1, s2):
+    """True when ``residual_block_bf16`` applies: bf16 compute mode, packed-weight scope, affine (scale, shift) pairs, both
+    convolutions 3x3 square-channel layers on the LDS-resident-patch kernels, a map the slab norm kernels hold."""
+    if not (_pack_cache_on and get_compute_dtype() == "bf16" and x.is_cuda and x.dim() == 4 and s1 is not None and s2 is not None):
+        return False
+    if _os.environ.get("SRGAN_NO_RESBLOCK_BF16"):
+        return False
+    n, c, h, w = x.shape
+    if tuple(w1.shape) != (c, c, 3, 3) or tuple(w2.shape) != (c, c, 3, 3):
+        return False
+    lib = _lib.load()
+    if not lib.srgan_instnorm_slab_applicable(n, h * w, c):
+        return False
+    desc = _conv_desc(n, h, w, c, h, w, c, 3, 3, 1, 1, PAD_ZERO, w1)
+    return bool(lib.srgan_halo16_applicable(ctypes.byref(desc)))
+
+
+def residual_block_bf16(x, s1, h1, s2, h2, w1, w2, eps=1e-5):
+    """cbin2(c2(relu(cbin1(c1(x))))) + x in the bf16 mode with bf16 intermediates -- see _ResBlockBf16Fn."""
+    return _ResBlockBf16Fn.apply(x, s1, h1, s2, h2, w1, w2, eps)
+
+
 def res_block_fusable(x, w1, w2, s1, s2):
     """True when ``residual_block`` applies: packed-weight scope, 32x32 map, affine (scale, shift) pairs present, both
     convolutions 3x3 square-channel layers whose forward, input gradient and weight gradient all dispatch to F(4x4,3x3)."""
