@@ -48,7 +48,7 @@ struct WinoPackParams {
 
 constexpr int WP_WNB = 64, WP_WC = 8;
 __device__ __host__ __forceinline__ long long wino_pack_total(const WinoPackParams& p) {
-  if (p.variant == 4) return (long long)9 * p.nchunk * p.N * 4;                  // one item = 8 reduce channels of one cout
+  if (p.variant == 4) return (long long)p.nchunk * p.N * 4;                      // one item = 8 reduce channels of one cout, 9 taps
   if (p.variant == 3) return (long long)p.n_tiles * 32 * p.nchunk * 2;          // one item = 4 channels of one cout
   return (long long)p.n_tiles * WP_WNB * p.nchunk * WP_WC * p.phases;
 }
@@ -110,27 +110,34 @@ __device__ __forceinline__ void wino43_pack_item(const WinoPackParams& p, long l
 // variant 4 (conv_halo16.hip, bf16 mode -- no transform): bf16 [64-channel quarter][tap][32-chunk of the quarter][N][32], rounded
 // to nearest even (K tile kt = (quarter * 9 + tap) * 2 + chunk & 1).
 // kind 0: B[n][k] = w[n][k][ky][kx];  kind 1: B[n][k] = w[k][n][2-ky][2-kx].
+// One item = (output channel n, 8 reduce channels) for ALL NINE taps: with dense OIHW weights its 72 source values are 288
+// contiguous bytes (kind 0) or eight 36-byte runs (kind 1); an item per tap would walk the whole weight tensor nine times with
+// a 36-byte stride (measured: 145 us per repack of the generator, 12 layers x 2 kinds).
 __device__ __forceinline__ void halo16_pack_item(const WinoPackParams& p, long long idx) {
   long long r = idx;
   const int part = (int)(r % 4); r /= 4;
-  const int n = (int)(r % p.N); r /= p.N;
-  const int kt = (int)r;                               // 0 .. 9 * nchunk - 1
-  const int quarter = kt / 18, rem = kt - quarter * 18;
-  const int tap = rem >> 1, chunk = quarter * 2 + (rem & 1);
-  const int ky = tap / 3, kx = tap - 3 * ky;
-  f32x4 lo, hi;
+  const int n = (int)(r % p.N);
+  const int chunk = (int)(r / p.N);                     // 0 .. nchunk - 1 (32 reduce channels each)
+  const int quarter = chunk >> 1;
+  float v[8][9];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int k = chunk * 32 + part * 8 + j;
-    const float v = p.kind == 0 ? p.w[n * p.sO + k * p.sI + ky * p.sH + kx * p.sW]
-                                : p.w[k * p.sO + n * p.sI + (2 - ky) * p.sH + (2 - kx) * p.sW];
-    if (j < 4) lo[j] = v; else hi[j - 4] = v;
+    const float* src = p.kind == 0 ? p.w + n * p.sO + k * p.sI : p.w + k * p.sO + n * p.sI;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[j][t] = src[(t / 3) * p.sH + (t % 3) * p.sW];
   }
-  const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
-  bf16x8 o;
-  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
   unsigned short* dst = reinterpret_cast<unsigned short*>(p.dst);
-  *reinterpret_cast<bf16x8*>(dst + ((size_t)kt * p.N + n) * 32 + part * 8) = o;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int t = p.kind == 0 ? tap : 8 - tap;          // kind 1: taps rotated by 180 degrees
+    const f32x4 lo = {v[0][t], v[1][t], v[2][t], v[3][t]}, hi = {v[4][t], v[5][t], v[6][t], v[7][t]};
+    const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+    bf16x8 o;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+    const int kt = (quarter * 9 + tap) * 2 + (chunk & 1);
+    *reinterpret_cast<bf16x8*>(dst + ((size_t)kt * p.N + n) * 32 + part * 8) = o;
+  }
 }
 
 __device__ __forceinline__ void wino_pack_item(const WinoPackParams& p, long long idx) {
