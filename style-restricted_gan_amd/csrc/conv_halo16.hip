@@ -393,6 +393,193 @@ __global__ __launch_bounds__(256) void halo16_wgrad_kernel(Halo16WgradParams p) 
     for (int e = 0; e < 16; ++e) out[(size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * (9 * p.C) + t * p.C] = acc[t][e];
 }
 
+// ---- transposed form of the 4x4 / stride-2 / pad-1 layers (input gradient of the generator's down convolutions and of the
+// discriminator trunk, forward of the generator's ConvTranspose2d layers; reference pyfiles/model.py:212-215,227-230,302-309) ----
+// Output pixel (2u + r, 2v + s) of phase (r, s) is a 2x2 stride-1 correlation of the SOURCE map:
+//   out[2u+r][2v+s][n] = sum_{a,b in {0,1}} sum_k src[u + a + r - 1][v + b + s - 1][k] * w[k][n][3 - 2a - r][3 - 2b - s]
+// -- in halo coordinates the shifts (a + r, b + s) are four of the nine shifts of the 3x3 kernel above, so the same 6 x 34 halo
+// of a 4 x 32 source patch serves all four phases: one GEMM per phase (K = 4 taps x C), run back to back as ONE tile stream
+// (phase, tap, chunk) so that the filter tiles keep flowing and the 8 x 64-pixel result of a phase is stored under the
+// products of the next.  N = C / 2 output channels: a filter tile is always 16 KB = [BN][HK] with HK = 8192 / BN reduce
+// channels (64 at BN = 128, 128 at BN = 64), i.e. 16 MFMAs per wave and tile as above; swizzle key of a row = its index
+// shifted so that the 16 rows of a ds_read_b128 lane group hit 16 different 16-byte columns.
+struct Halo16TParams {
+  const float* src;            // [NB][Hs][Ws][C]
+  const unsigned short* wp;    // packed bf16 filters [phase][tap][chunk][BN][HK]
+  float* dst;                  // [NB][2 Hs][2 Ws][N]
+  int NB, Hs, Ws, tiles_y, tiles_x;
+};
+
+template <int C, int BN>
+__global__ __launch_bounds__(256) void halo16t_kernel(Halo16TParams p) {
+  constexpr int PS = C * 2 + 16;               // bytes per halo pixel
+  constexpr int HKT = 8192 / BN;               // reduce channels per tile
+  constexpr int NCH = C / HKT;                 // chunks per tap
+  constexpr int NKP = 4 * NCH;                 // tiles per phase
+  constexpr int NK = 4 * NKP;                  // tiles in all
+  constexpr int KS = HKT / 16;                 // 16-deep K steps per tile
+  constexpr int TN = BN / 64;                  // 32-wide output-channel blocks per wave
+  constexpr int WTILE = 16384;
+  constexpr int PCS = HKT / 8;                 // 16-byte pieces per tile row
+  constexpr int SWS = PCS == 8 ? 1 : 0;        // swizzle key = (row >> SWS) & (PCS - 1)
+  static_assert((BN == 128 && C == 256) || (BN == 64 && C == 128), "instantiated for (C, N) = (256, 128) and (128, 64)");
+  static_assert(NKP % 2 == 0, "two tiles per loop body");
+  __shared__ __attribute__((aligned(16))) unsigned char halo[HPX * PS];
+  __shared__ __attribute__((aligned(16))) unsigned char wt[3 * WTILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  int r0 = bid;
+  const int tx = r0 % p.tiles_x; r0 /= p.tiles_x;
+  const int ty = r0 % p.tiles_y;
+  const int nb = r0 / p.tiles_y;
+  const int Y0 = ty * 4, X0 = tx * 32;
+
+  const auto rs_x = uniform_rsrc(p.src, (unsigned)((size_t)p.NB * p.Hs * p.Ws * C * 4));
+  const auto rs_w = uniform_rsrc(p.wp, (unsigned)(NK * WTILE));
+
+  f32x4 wreg[4], wreg2[4];
+  auto load_w = [&](f32x4* dst, int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, tid * 16 + i * 4096, kt * WTILE, 0));
+  };
+  auto store_w = [&](const f32x4* src, int boff) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i;               // piece q: row q / PCS, piece q % PCS
+      const int n = q / PCS, pc = q % PCS;
+      *reinterpret_cast<f32x4*>(&wt[boff + n * (HKT * 2) + ((pc ^ ((n >> SWS) & (PCS - 1))) << 4)]) = src[i];
+    }
+  };
+  load_w(wreg, 0);
+  load_w(wreg2, 1);
+
+  // ---- the whole halo, one 64-channel quarter at a time (7 passes of 32 pixels x 8 channels per thread) ----
+  {
+    const int hcg = tid & 7, hpl = tid >> 3;
+    constexpr unsigned kOutside = 0x80000000u;
+#pragma unroll
+    for (int quarter = 0; quarter < C / 64; ++quarter) {
+      f32x4 lo[7], hi[7];
+#pragma unroll
+      for (int g = 0; g < 7; ++g) {
+        const int hp = g * 32 + hpl;
+        const int hr = hp / 34, hc = hp - hr * 34;
+        const int y = Y0 - 1 + hr, x = X0 - 1 + hc;
+        const bool ok = hp < HPX && y >= 0 && y < p.Hs && x >= 0 && x < p.Ws;
+        const unsigned off = ok ? (unsigned)((((nb * p.Hs + y) * p.Ws + x) * C + quarter * 64 + hcg * 8) * 4) : kOutside;
+        lo[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+        hi[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+      }
+#pragma unroll
+      for (int g = 0; g < 7; ++g) {
+        const int hp = g * 32 + hpl;
+        if (hp < HPX) {
+          const bf16x4 a = __builtin_convertvector(lo[g], bf16x4), b = __builtin_convertvector(hi[g], bf16x4);
+          bf16x8 v;
+          v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+          *reinterpret_cast<bf16x8*>(&halo[hp * PS + quarter * 128 + hcg * 16]) = v;
+        }
+      }
+    }
+  }
+  store_w(wreg, 0);
+  store_w(wreg2, WTILE);
+  load_w(wreg, 2);
+  load_w(wreg2, 3);
+  __syncthreads();
+
+  f32x16 acc[2][TN];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  };
+  zero_acc();
+
+  const unsigned char* a_lane = halo + ((2 * wm) * 34 + lr) * PS + lh * 16;
+  const int b_row = (wn * (BN / 2) + lr) * (HKT * 2), b_key = (lr >> SWS) & (PCS - 1);
+  auto b_off = [&](int s) __attribute__((always_inline)) { return b_row + (((2 * s + lh) ^ b_key) << 4); };
+
+  bf16x8 fa[2][2], fb[2][TN];
+  auto read_frags = [&](int slot, const unsigned char* a, int woff, int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[slot][i] = *reinterpret_cast<const bf16x8*>(a + i * 34 * PS + s * 32);
+    const unsigned char* B = wt + woff + b_off(s);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const bf16x8*>(B + j * 32 * (HKT * 2));
+  };
+  auto mma = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i], fb[slot][j], acc[i][j], 0, 0, 0);
+  };
+  // A address of tile (phase, tap, chunk): shift (a + r, b + s) halo pixels, chunk * HKT channels
+  auto a_of = [&](int ph, int tap, int ch) __attribute__((always_inline)) {
+    return a_lane + (((tap >> 1) + (ph >> 1)) * 34 + (tap & 1) + (ph & 1)) * PS + ch * (HKT * 2);
+  };
+  auto flush = [&](int ph) __attribute__((always_inline)) {
+    const int r = ph >> 1, sx = ph & 1;
+    const int Wd = 2 * p.Ws;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const size_t row = ((size_t)(nb * 2 * p.Hs + 2 * (Y0 + 2 * wm + i) + r) * Wd + 2 * X0 + sx) * BN;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = wn * (BN / 2) + j * 32 + lr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) p.dst[row + (size_t)(2 * ((e & 3) + 8 * (e >> 2) + 4 * lh)) * BN + n] = acc[i][j][e];
+      }
+    }
+  };
+
+  int w_cur = 0, w_nxt = WTILE, w_nn = 2 * WTILE;
+  int ph = 0, tap = 0, ch = 0;                 // coordinates of tile kt
+  read_frags(0, a_of(0, 0, 0), w_cur, 0);
+  for (int kt = 0; kt < NK; kt += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = kt + u;
+      const unsigned char* a_cur = a_of(ph, tap, ch);
+      // coordinates of the next tile
+      int nch = ch + 1, ntap = tap, nph = ph;
+      if (nch == NCH) { nch = 0; ntap = tap + 1; if (ntap == 4) { ntap = 0; nph = ph + 1; } }
+      const unsigned char* a_nx = a_of(nph, ntap, nch);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        // request the fragments of the next K step (of this tile, or step 0 of the next tile: stored an iteration ago)
+        if (s + 1 < KS) read_frags((s + 1) & 1, a_cur, w_cur, s + 1);
+        else {
+          if (t + 1 < NK) read_frags((s + 1) & 1, a_nx, w_nxt, 0);
+          if (t + 2 < NK) store_w(u == 0 ? wreg : wreg2, w_nn);
+          if (t + 4 < NK) load_w(u == 0 ? wreg : wreg2, t + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(s & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (nph != ph) {                         // last tile of a phase: its 8 x 64-pixel result goes out under the next phase
+        flush(ph);
+        zero_acc();
+      }
+      __syncthreads();
+      const int tw = w_cur; w_cur = w_nxt; w_nxt = w_nn; w_nn = tw;
+      ph = nph; tap = ntap; ch = nch;
+    }
+  }
+}
+
 template <int C>
 int launch_c(const Halo16Params& p, bool in16, bool out16, long long grid, hipStream_t st) {
   const dim3 g((unsigned)grid), b(256);
@@ -441,6 +628,31 @@ int halo16_run(const srgan_conv_desc* d, int kind, const void* src, const void* 
   else launch_c<64>(p, in16, out16, grid, st);
   prof_end(tok, st);
   return check_launch("halo16_kernel");
+}
+
+// ---- transposed 4x4 / stride-2 form: kind 1 of a strided layer d (its input gradient = a ConvTranspose2d forward) ----
+bool halo16t_applicable(const srgan_conv_desc* d) {
+  static const bool off = std::getenv("SRGAN_NO_HALO16T") != nullptr;
+  if (off || d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 1 || d->pad_mode != SRGAN_PAD_ZERO) return false;
+  if (!((d->O == 256 && d->I == 128) || (d->O == 128 && d->I == 64))) return false;
+  if (d->Hi != 2 * d->Ho || d->Wi != 2 * d->Wo || d->Ho % 4 != 0 || d->Wo % 32 != 0) return false;
+  return (long long)d->N * d->Ho * d->Wo * d->O < (1LL << 29) && (long long)d->N * d->Hi * d->Wi * d->I < (1LL << 30);
+}
+
+size_t halo16t_packed_bytes(const srgan_conv_desc* d) { return (size_t)16 * d->I * d->O * 2; }
+
+int halo16t_run(const srgan_conv_desc* d, const float* dy, const void* packed, float* dx, double flops, hipStream_t st) {
+  SRGAN_REQUIRE(halo16t_applicable(d), "halo16t: layer not applicable");
+  Halo16TParams p{};
+  p.src = dy; p.wp = reinterpret_cast<const unsigned short*>(packed); p.dst = dx;
+  p.NB = d->N; p.Hs = d->Ho; p.Ws = d->Wo; p.tiles_y = d->Ho / 4; p.tiles_x = d->Wo / 32;
+  const long long grid = (long long)p.NB * p.tiles_y * p.tiles_x;
+  SRGAN_REQUIRE(grid > 0 && grid < (1LL << 31), "halo16t: grid");
+  ProfToken tok = prof_begin(27, flops, st);
+  if (d->O == 256) hipLaunchKernelGGL((halo16t_kernel<256, 128>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((halo16t_kernel<128, 64>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  prof_end(tok, st);
+  return check_launch("halo16t_kernel");
 }
 
 // ---- weight gradient host side (hooked into conv_wino.hip's weight-gradient slot in bf16 mode) ----

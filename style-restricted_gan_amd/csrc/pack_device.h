@@ -48,6 +48,7 @@ struct WinoPackParams {
 
 constexpr int WP_WNB = 64, WP_WC = 8;
 __device__ __host__ __forceinline__ long long wino_pack_total(const WinoPackParams& p) {
+  if (p.variant == 5) return (long long)p.N * (p.C / 8);                           // one item = 8 reduce channels of one output channel, 16 taps
   if (p.variant == 4) return (long long)p.nchunk * p.N * 4;                      // one item = 8 reduce channels of one cout, 9 taps
   if (p.variant == 3) return (long long)p.n_tiles * 32 * p.nchunk * 2;          // one item = 4 channels of one cout
   return (long long)p.n_tiles * WP_WNB * p.nchunk * WP_WC * p.phases;
@@ -140,8 +141,41 @@ __device__ __forceinline__ void halo16_pack_item(const WinoPackParams& p, long l
   }
 }
 
+// variant 5 (conv_halo16.hip, transposed 4x4 / stride-2 form, kind 1 of a strided layer w[O][I][4][4]): bf16
+// [phase (r,s)][tap (a,b)][chunk][N = I][HK = 8192 / N reduce channels o],  B[n][k] = w[k][n][3 - 2a - r][3 - 2b - s].
+// One item = (n, 8 reduce channels) for all 16 (phase, tap) pairs = all 16 filter taps: eight 64-byte source runs.
+__device__ __forceinline__ void halo16t_pack_item(const WinoPackParams& p, long long idx) {
+  const int hk = 8192 / p.N, pcs = hk / 8, nch = p.C / hk;
+  long long r = idx;
+  const int part = (int)(r % pcs); r /= pcs;
+  const int n = (int)(r % p.N);
+  const int chunk = (int)(r / p.N);
+  float v[8][16];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = chunk * hk + part * 8 + j;
+    const float* src = p.w + k * p.sO + n * p.sI;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[j][t] = src[(t >> 2) * p.sH + (t & 3) * p.sW];
+  }
+  unsigned short* dst = reinterpret_cast<unsigned short*>(p.dst);
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+      const int ky = 3 - 2 * (tap >> 1) - (ph >> 1), kx = 3 - 2 * (tap & 1) - (ph & 1), t = ky * 4 + kx;
+      const f32x4 lo = {v[0][t], v[1][t], v[2][t], v[3][t]}, hi = {v[4][t], v[5][t], v[6][t], v[7][t]};
+      const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+      bf16x8 o;
+      o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+      const int kt = (ph * 4 + tap) * nch + chunk;
+      *reinterpret_cast<bf16x8*>(dst + ((size_t)kt * p.N + n) * hk + part * 8) = o;
+    }
+}
+
 __device__ __forceinline__ void wino_pack_item(const WinoPackParams& p, long long idx) {
   constexpr int WNB = WP_WNB, WC = WP_WC;
+  if (p.variant == 5) { halo16t_pack_item(p, idx); return; }
   if (p.variant == 4) { halo16_pack_item(p, idx); return; }
   if (p.variant == 3) { wino43_pack_item(p, idx); return; }
     // lanes run over (channel & 3, cout, channel half): the 16 stores of a wave-instruction are 256 contiguous bytes each

@@ -82,6 +82,9 @@ CONV_CASES = [
     (2, 256, 32, 32, 256, 3, 1, 1, False, False), # residual-trunk layer at full width (bf16 mode: LDS-resident patch kernel, C = 256)
     (1, 128, 8, 64, 128, 3, 1, 1, False, True),   # same kernel family: C = 128, two patches per row, bias
     (1, 256, 64, 64, 256, 3, 1, 1, False, False), # the 256x256 configuration's trunk map (64 x 64): 32 patches of one image
+    (2, 64, 16, 64, 128, 4, 2, 1, False, False),  # 64 -> 128 down conv on an 8 x 32 output map (bf16 mode: input gradient on the transposed patch kernel)
+    (1, 128, 8, 64, 256, 4, 2, 1, False, False),  # 128 -> 256 down conv, one output patch (same kernel, C = 256 reduce channels)
+    (3, 64, 64, 128, 128, 4, 2, 1, False, True),  # same layer class on a wider map: 8 x 2 patches per image, bias
 ]
 
 
