@@ -35,6 +35,8 @@ def prof_name(n):
         return "wino43_input_kernel"
     if n.startswith("wino43_kernel"):
         return "wino43_kernel"
+    if "halo16t_kernel" in n:
+        return "halo16t_kernel"
     if "halo16_wgrad_kernel" in n:
         return "halo16_wgrad_kernel"
     if "halo16_kernel" in n:
