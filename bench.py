@@ -469,7 +469,8 @@ def main():
                                    (", E trunk frozen (BASELINE configs[2])" if args.pretrained_e else ", E trainable (BASELINE configs[1])"),
                        "global_batch": B * world, "unrolled_k": args.k, "parallelism": f"dp{world}",
                        "execution": ("eager launches" if not graphed else "hipGraph replay of the captured step" if world == 1 else
-                                     "hipGraph segments replayed with the RCCL collectives issued eagerly between them"),
+                                     f"hipGraph segments replayed with the {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} "
+                                     "collectives issued eagerly between them"),
                        "gflop_per_image_algorithmic": gflop_img,
                        "step_tflops_algorithmic": round(value * (gflop_img or 0) / 1e3, 2),
                        "losses_first_step_vs_oracle": check,
