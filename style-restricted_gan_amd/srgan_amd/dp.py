@@ -314,6 +314,17 @@ def _all_reduce_avg(flats):
             flat.mul_(1.0 / ws)
 
 
+def all_agree(ok):
+    """True iff ``ok`` is true on EVERY rank (one eager MIN all-reduce; the plain value without a process group).  Every rank
+    must call it at the same point of its program."""
+    if not is_distributed():
+        return bool(ok)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def _backend_has_avg():
     """RCCL reduces with ncclAvg in the collective itself; gloo has no AVG (sum, then one scaling launch per bucket)."""
     try:

@@ -106,6 +106,21 @@ class Adam(torch.optim.Optimizer):
     def graph_keepalive(self):
         return [t for co in self._cohorts.values() for t in (co.state, co.table)]
 
+    def host_counters(self):
+        """Snapshot of the host-side step counters (per-parameter ``state[p]["step"]`` and the cohorts')."""
+        return ({id(p): self.state[p]["step"] for g in self.param_groups for p in g["params"] if p in self.state and len(self.state[p])},
+                {key: co.steps for key, co in self._cohorts.items()})
+
+    def restore_host_counters(self, snap):
+        per_param, per_cohort = snap
+        for g in self.param_groups:
+            for p in g["params"]:
+                if id(p) in per_param:
+                    self.state[p]["step"] = per_param[id(p)]
+        for key, co in self._cohorts.items():
+            if key in per_cohort:
+                co.steps = per_cohort[key]
+
     def advance_host(self, n):
         """A replayed graph ran ``n`` optimiser steps on the device: move the host-side counters with it."""
         ids = {pid for key in self._cohorts for pid in key[1:]}

@@ -579,6 +579,11 @@ class _StepGraph:
         for opt in (sg.optG, sg.optD, sg.optE):
             opt._keep_alive = None
         gc.collect()
+        # fault injection for the tests of the agreed fall-back: "<rank>:before" / "<rank>:inside"
+        inject = os.environ.get("SRGAN_TEST_FAIL_CAPTURE", "")
+        inject = inject.split(":") if inject and int(inject.split(":")[0]) == dp.rank() else None
+        if inject and inject[1] == "before":
+            raise RuntimeError("injected failure before the recording (SRGAN_TEST_FAIL_CAPTURE)")
         g = _Recording(self.x.device)
         sg._g_active = True
         self._noise_i, self._onehot = 0, {}
@@ -587,6 +592,8 @@ class _StepGraph:
             with g:
                 with ops.pack_cache(refresh_on_entry=False):
                     err = sg.UnrolledUpdate()
+                if inject and inject[1] == "inside":
+                    raise RuntimeError("injected failure inside the recording (SRGAN_TEST_FAIL_CAPTURE)")
                 self.out = torch.stack([e.detach().reshape(()) for e in err])
         finally:
             sg._g_active = False
@@ -597,6 +604,34 @@ class _StepGraph:
         self._epoch = ops.structure_epoch()
         self._keep = ops.graph_keepalive() + [t for opt in (sg.optG, sg.optD, sg.optE) for t in opt.graph_keepalive()]
 
+    def _abandon(self, err, snap):
+        """Some rank could not record the step: every rank drops graph mode together.  THIS step still runs -- eagerly, from the
+        inputs already staged for the recording (same image batch, labels and pre-drawn noise, so the CPU generator is where an
+        eager run would have left it) -- and later steps take the ordinary eager path."""
+        import warnings
+        sg = self.sg
+        for opt, c in zip((sg.optG, sg.optD, sg.optE), snap):
+            opt.restore_host_counters(c)          # the recording advanced them without running anything
+        warnings.warn("SRGAN_training: the step could not be recorded as hipGraph segments on every rank"
+                      + (f" (this rank: {type(err).__name__}: {err})" if err is not None else "") + "; running eagerly from here on")
+        self.graph = self._keep = None
+        self._noise_i, self._onehot = 0, {}
+        sg.target_image = sg.recon_image = sg.c_rand = None
+        sg.loss_terms = {}
+        sg.__dict__.get("_label_cache", {}).clear()
+        # host-side caches may describe device buffers whose filling launch was only RECORDED (a packed operand or a repack table
+        # first made while recording): forget them all, the eager step re-packs from the weights
+        ops.invalidate_packed()
+        sg.source_image = self.x
+        sg._g_active = True
+        try:
+            with ops.pack_cache():
+                out = sg.UnrolledUpdate()
+        finally:
+            sg._g_active = False
+            sg._graph = None
+        return out
+
     def run(self, source_image, label):
         sg = self.sg
         self._stage(source_image, label)
@@ -604,7 +639,18 @@ class _StepGraph:
         for opt in (sg.optG, sg.optD, sg.optE):
             opt.sync_device()
         if self.graph is None:
-            self._capture()          # records; the host-side optimiser counters advanced while recording
+            err = None
+            snap = [opt.host_counters() for opt in (sg.optG, sg.optD, sg.optE)]
+            try:
+                self._capture()      # records; the host-side optimiser counters advanced while recording
+            except Exception as e:   # noqa: BLE001 -- under a process group the ranks first agree on what happened
+                if not dp.is_distributed():
+                    raise
+                err = e
+            if dp.is_distributed() and not dp.all_agree(err is None):
+                # some rank could not record the step: EVERY rank gives the recording up together (a rank replaying segments
+                # beside a rank running eagerly would issue the same collectives in another order) and runs eagerly
+                return self._abandon(err, snap)
         else:
             sg.optD.advance_host(sg.k)
             sg.optG.advance_host(2)

@@ -63,7 +63,9 @@ def _run(rank, world, out_q=None, kl=0.0, graph=False, recipe=None):
         sl = slice(rank * per, (rank + 1) * per)
         lab = {"source": label["source"][sl].cuda(), "target": label["target"][sl]}
         losses.append([float(v) for v in sg.train(x[sl].cuda(), lab)])
-    if graph:
+    if graph and os.environ.get("SRGAN_TEST_FAIL_CAPTURE"):
+        assert sg._graph is None and not sg.graph_active          # every rank gave the recording up together
+    elif graph:
         # data parallel: the recording is cut at each of the K + 3 exchange points (K discriminator all-reduces, the mu
         # all-gather, the G+E and the G all-reduces) -- K + 4 graph segments with eager collectives between them
         assert sg.graph_active and len(sg._graph.graph.segments) == (K + 4 if dp.is_distributed() else 1)
@@ -74,7 +76,9 @@ def _run(rank, world, out_q=None, kl=0.0, graph=False, recipe=None):
     return losses, state, terms
 
 
-def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False, graph=False, recipe=None):
+def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False, graph=False, recipe=None, inject=None):
+    if inject:
+        os.environ["SRGAN_TEST_FAIL_CAPTURE"] = inject
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SRGAN_DP_DEVICE="0", SRGAN_DP_BACKEND=backend)
     if force:
@@ -125,6 +129,29 @@ def test_two_ranks_equal_one_process(kl, graph):
     for key, v in res[0][2].items():
         d = float(np.abs(v - ref_state[key]).max())
         assert d <= 1e-5, (key, d)        # 4 optimiser steps of at most lr=1e-4 each; observed ~2e-6
+
+
+@pytest.mark.parametrize("inject", ["1:before", "1:inside"])
+def test_failed_recording_on_one_rank_makes_every_rank_fall_back(inject):
+    """Rank 1 cannot record the step (fault injected before / inside the recording): the ranks agree on it with one MIN
+    all-reduce, BOTH drop graph mode, run that very step eagerly from the inputs staged for the recording and continue eagerly --
+    same results as the eager two-rank run (bounds of the test above)."""
+    ref_losses, ref_state, ref_terms = _run(0, 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 0.0, "gloo", False, True, None, inject)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    dp_losses = (np.array(res[0][1]) + np.array(res[1][1])) / 2
+    np.testing.assert_allclose(dp_losses, np.array(ref_losses), rtol=1e-3)
+    for key, v in res[0][2].items():
+        d = float(np.abs(v - ref_state[key]).max())
+        assert d <= 1e-5, (key, d)
 
 
 @pytest.mark.parametrize("graph", [False, True])
