@@ -457,7 +457,10 @@ class SRGAN_training():
         shape still runs eagerly (it creates the optimiser state, packed operands and workspaces a capture must not
         re-create), the second captures and replays, later ones only stage the step's inputs (image batch, labels, the
         CPU-generator noise drawn in the reference's order) into static device buffers and launch the graph.  Inputs of
-        another shape (an epoch's last partial batch) run eagerly.  Results are bit-identical to eager execution."""
+        another shape (an epoch's last partial batch) run eagerly.  Results are bit-identical to eager execution.
+        Under a process group the recording is cut at every collective (k + 4 graph segments, the collectives issued eagerly
+        between them: ``_Recording``); if any rank fails to record, all ranks drop graph mode together and continue eagerly
+        (``SRGAN_DP_GRAPH=0`` refuses graph mode under a process group altogether)."""
         self._graph = _StepGraph(self)
         return self
 
