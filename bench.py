@@ -83,12 +83,21 @@ def build_trainer(size, global_batch, k, device, pretrained_e=False):
 
 
 def host_cores():
-    """Threads we may really use: the affinity mask, capped at the GPU box's CPU share for one GPU (16)."""
+    """Threads we may really use: the affinity mask, bounded by the cgroup CPU quota when the box sets one
+    (``SRGAN_BENCH_CPU_THREADS`` overrides)."""
+    if os.environ.get("SRGAN_BENCH_CPU_THREADS"):
+        return max(1, int(os.environ["SRGAN_BENCH_CPU_THREADS"]))
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, int(os.environ.get("SRGAN_BENCH_CPU_THREADS", "16"))))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def cpu_model():
@@ -105,33 +114,34 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(size, k):
-    """The CPU oracle (oracle/, a port of the reference's PyTorch-CPU path) on a bounded sample."""
+def cpu_baseline(size, k, batch):
+    """The CPU oracle (oracle/, a port of the reference's PyTorch-CPU path) on a bounded sample of the SAME workload: full-width
+    networks, the metric's batch size, k D-updates -- 1 warm-up + 2 timed steps."""
     from oracle import params as op, trainer as ot
     cores = host_cores()
     torch.set_num_threads(cores)
-    spec = (op.generator_spec(3, 64, 2, 2, 6, 12), op.discriminator_spec(3, 64, 2, 4, 4), op.encoder_spec(3, 8, 64, 4, 4))
+    spec = (op.generator_spec(3, 64, 2, 2, 6, 12), op.discriminator_spec(3, 64, 2, 4 if size == 128 else 5, 4),
+            op.encoder_spec(3, 8, 64, 4, 4))
     PG, PD, PE = (op.fill(s, i) for i, s in enumerate(spec))
     torch.manual_seed(0)
-    batch = 8
     orc = ot.SRGANOracle(PG, PD, PE, LBD, k, np.eye(4), batch, "mu", 8)
-    orc_w = ot.SRGANOracle(PG, PD, PE, LBD, 1, np.eye(4), 2, "mu", 8)
-    x2, l2 = ot.synthetic_batch(2, size, 4, seed=2)
+    orc_w = ot.SRGANOracle(PG, PD, PE, LBD, 1, np.eye(4), 4, "mu", 8)
+    x2, l2 = ot.synthetic_batch(4, size, 4, seed=2)
     log(f"cpu baseline: warm-up on {cores} threads")
-    orc_w.train(x2, l2)                                   # warm-up (thread pool, allocator), k=1, 2 images
-    log("cpu baseline: timed steps")
+    orc_w.train(x2, l2)                                   # warm-up (thread pool, allocator, oneDNN primitives): k=1, 4 images
+    log(f"cpu baseline: timed steps at batch {batch}")
     steps, dt = 0, 0.0
-    while dt < 12.0 and steps < 6:                        # bounded sample: ~10-30 s of CPU work
+    while steps < 2 and (steps == 0 or dt < 40.0):        # bounded sample: ~10-30 s of CPU work on the GPU box's host cores
         x, label = ot.synthetic_batch(batch, size, 4, seed=3 + steps)
         t0 = time.perf_counter()
         orc.train(x, label)
         dt += time.perf_counter() - t0
         steps += 1
+        log(f"cpu baseline: step {steps} done, {dt:.1f} s so far")
     return {"value": round(batch * steps / dt, 4), "unit": "images/sec", "cores": cores, "cpu_model": cpu_model(),
             "kind": "port",
-            "sample": f"{steps} full train steps (k={k}, fp32, same networks/losses) of the CPU oracle at batch {batch} "
-                      f"({size}x{size}; a batch-32 step is ~9 s per step on these cores and would not fit the time bound) "
-                      f"after a k=1 batch-2 warm-up; {dt:.1f} s on {cores} threads"}
+            "sample": f"{steps} full train steps (k={k}, fp32, same networks / losses / batch size: {batch} images of "
+                      f"{size}x{size}) of the CPU oracle after a k=1 batch-4 warm-up; {dt:.1f} s on {cores} threads"}
 
 
 def pmc_traffic(kernel_name, dtype="f32"):
@@ -194,6 +204,24 @@ def micro_gd_run(size, batch, dtype, steps, warmup, device):
     value = B / dt
     peak = PEAK_TFLOPS["f32" if dtype == "f32" else "bf16"]
     tf = value * gf / 1e3 if gf else None
+    # MFMA FLOPs the GEMM-class launches of one micro step actually ISSUE (algorithmic / Winograd divisor), from two more steps
+    # under the library's HIP-event brackets: against the UN-instrumented step time above
+    from srgan_amd import _lib
+    lib = _lib.load()
+    lib.srgan_prof_enable(1)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    lib.srgan_prof_enable(0)
+    issued, counted, gemm_ms = 0.0, 0.0, 0.0
+    for kid in range(lib.srgan_prof_num_kernels()):
+        ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+        _lib.check(lib.srgan_prof_collect(kid, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_collect")
+        if n.value:
+            issued += fl.value / executed_divisor(lib.srgan_prof_kernel_name(kid).decode()) / 2
+            counted += fl.value / 2
+            gemm_ms += ms.value / 2
+    issued_tf = issued / dt / 1e12
     return {
         "metric": f"images/sec G+D forward-backward, {S}x{S} bs={B} (micro-benchmark, SURVEY 8d)", "value": round(value, 2),
         "unit": "images/sec", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt, 3),
@@ -202,6 +230,14 @@ def micro_gd_run(size, batch, dtype, steps, warmup, device):
                                "init, first-layer input gradients skipped", "gflop_per_image_algorithmic": gf},
         "roofline": {"bound": "mfma", "algorithmic_tflops": round(tf, 2) if tf else None, "peak": peak, "unit": "TFLOP/s",
                      "algorithmic_frac": round(tf / peak, 4) if tf else None,
+                     "issued_tflops": round(issued_tf, 2), "issued_frac": round(issued_tf / peak, 4),
+                     "issued_frac_over_gemm_kernel_time": round(issued / (gemm_ms * 1e-3) / 1e12 / peak, 4) if gemm_ms else None,
+                     "gemm_kernel_ms_per_step": round(gemm_ms, 3),
+                     "gflop_per_image_in_gemm_launches": round(counted / B / 1e9, 2),
+                     "issued_note": "MFMA FLOPs the conv launches of one micro step ISSUE (algorithmic / 4 on F(4x4,3x3), / 2.25 on "
+                                    "F(2x2,3x3) and F(3x3,2x2), / 1 on the direct forms; the VALU head kernels are not counted) / "
+                                    "the micro step's wall time / peak: the utilisation of the matrix pipe over the whole "
+                                    "forward-backward, always <= 1",
                      "note": "whole micro-benchmark: algorithmic FLOPs (SURVEY 8d) x images/s against the dense MFMA peak of the "
                              "dtype; includes norm / pointwise / reduction kernels; the Winograd layers issue 2.25-4x fewer MFMA "
                              "FLOPs than counted, so this ALGORITHMIC fraction can exceed 1 (north_star's >= 0.70 target is "
@@ -374,6 +410,14 @@ def main():
         torch.cuda.synchronize()
         log(f"warm-up step {s} done")
     graphed = bool(use_graph and getattr(sg, "graph_active", False))
+    graph_fallback = bool(use_graph and not graphed)
+    if graph_fallback and (world == 1 or args.graph == "on"):
+        # enable_graph() was accepted but the step is not replaying a recording after the warm-up: the line would silently
+        # describe another execution mode -- refuse instead of warning.  (Under a process group with --graph auto the ranks'
+        # agreed fall-back to eager launches is kept -- a first multi-rank RCCL run should still produce its number -- and the
+        # line says so in "graph_fallback" / "execution".)
+        raise SystemExit("bench: hipGraph mode was requested and available, but the warm-up did not leave a recorded step behind "
+                         "(the trainer fell back to eager launches); run with --graph off to measure that")
     barrier()
     prof_live = not graphed                   # HIP events cannot bracket kernels inside a graph replay
     if prof_live:
@@ -468,7 +512,9 @@ def main():
                                    "fp32 accumulation), fp32 tensors in HBM, fp32 norms, losses, Adam") +
                                    (", E trunk frozen (BASELINE configs[2])" if args.pretrained_e else ", E trainable (BASELINE configs[1])"),
                        "global_batch": B * world, "unrolled_k": args.k, "parallelism": f"dp{world}",
-                       "execution": ("eager launches" if not graphed else "hipGraph replay of the captured step" if world == 1 else
+                       "graph_fallback": graph_fallback,
+                       "execution": ("eager launches (hipGraph recording FAILED on some rank: all ranks fell back)" if graph_fallback else
+                                     "eager launches" if not graphed else "hipGraph replay of the captured step" if world == 1 else
                                      f"hipGraph segments replayed with the {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} "
                                      "collectives issued eagerly between them"),
                        "gflop_per_image_algorithmic": gflop_img,
@@ -505,7 +551,7 @@ def main():
             torch.cuda.empty_cache()
             out["micro_gd"] = micro_gd_run(args.size, B, args.dtype, 10, 3, device)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.size, args.k)
+            out["cpu_baseline"] = cpu_baseline(args.size, args.k, B)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

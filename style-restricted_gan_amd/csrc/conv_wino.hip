@@ -153,6 +153,9 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   // sixteen back-to-back loads per wave would hold all eight waves at the load with the matrix pipe idle)
   auto load_x_part = [&](auto part_c) __attribute__((always_inline)) {
     constexpr int PART = decltype(part_c)::value;
+#if WINO_EXP == 5 || WINO_EXP == 6
+    if (lc8 + lphase > 0) return;      // ablation: only the first chunk is gathered
+#endif
 #pragma unroll
     for (int i = 4 * PART; i < 4 * PART + 4; ++i)
       d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off[i], lc8 * (WC * 4), 0));
@@ -173,6 +176,9 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   };
   auto load_u1 = [&](int kc, auto par, int a, int j) __attribute__((always_inline)) {
     constexpr int P = decltype(par)::value;
+#if WINO_EXP == 7
+    if (kc > 1) return;                // ablation: filter fragments of the first two chunks only
+#endif
     bfr[P][a][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ubase + a * 2048 + j * 512, kc * 32768, 0));
   };
   auto load_u = [&](int kc, auto par) __attribute__((always_inline)) {
@@ -186,11 +192,14 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
   float tv[16];
   auto store_piece = [&](int buf, auto piece_c) __attribute__((always_inline)) {
     constexpr int PIECE = decltype(piece_c)::value;
-#if WINO_EXP == 4
+#if WINO_EXP == 4 || WINO_EXP == 6
     return;
 #endif
     float* V = lds + buf * VSZ + (ch >> 2) * VH + tl * 4 + (ch & 3);
     if constexpr (PIECE == 0) {
+#if WINO_EXP == 9
+      return;
+#endif
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         tv[0 * 4 + c] = d[0 * 4 + c] - d[2 * 4 + c];
@@ -199,6 +208,22 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
         tv[3 * 4 + c] = d[1 * 4 + c] - d[3 * 4 + c];
       }
     } else {
+#if WINO_EXP == 8        // ablation: the transform arithmetic without the LDS stores
+#pragma unroll
+      for (int r = 2 * (PIECE - 1); r < 2 * PIECE; ++r) {
+        asm volatile("" ::"v"(tv[r * 4 + 0] - tv[r * 4 + 2]), "v"(tv[r * 4 + 1] + tv[r * 4 + 2]), "v"(tv[r * 4 + 2] - tv[r * 4 + 1]),
+                     "v"(tv[r * 4 + 1] - tv[r * 4 + 3]));
+      }
+      (void)V;
+#elif WINO_EXP == 9      // ablation: the LDS stores without the transform arithmetic
+#pragma unroll
+      for (int r = 2 * (PIECE - 1); r < 2 * PIECE; ++r) {
+        V[(r * 4 + 0) * VP] = d[r * 4 + 0];
+        V[(r * 4 + 1) * VP] = d[r * 4 + 1];
+        V[(r * 4 + 2) * VP] = d[r * 4 + 2];
+        V[(r * 4 + 3) * VP] = d[r * 4 + 3];
+      }
+#else
 #pragma unroll
       for (int r = 2 * (PIECE - 1); r < 2 * PIECE; ++r) {
         V[(r * 4 + 0) * VP] = tv[r * 4 + 0] - tv[r * 4 + 2];
@@ -206,6 +231,7 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
         V[(r * 4 + 2) * VP] = tv[r * 4 + 2] - tv[r * 4 + 1];
         V[(r * 4 + 3) * VP] = tv[r * 4 + 1] - tv[r * 4 + 3];
       }
+#endif
     }
   };
   auto store_v = [&](int buf) __attribute__((always_inline)) {

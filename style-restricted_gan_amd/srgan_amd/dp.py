@@ -56,6 +56,9 @@ def init_from_env(backend=None):
             warm = torch.zeros(1, device=device)
             dist.all_reduce(warm)
             torch.cuda.synchronize(device)
+        global _control
+        _control = None
+        control_group()
     return rk, ws, device
 
 
@@ -314,15 +317,33 @@ def _all_reduce_avg(flats):
             flat.mul_(1.0 / ws)
 
 
-def all_agree(ok):
-    """True iff ``ok`` is true on EVERY rank (one eager MIN all-reduce; the plain value without a process group).  Every rank
-    must call it at the same point of its program."""
+_control = None
+
+
+def control_group():
+    """Host-side agreement between ranks (which execution mode a step takes, whether a recording succeeded) travels over a
+    gloo group on CPU tensors: no RCCL kernel in the compute stream and no device synchronisation to read the answer.
+    Created collectively: ``init_from_env`` makes it right after the process group; otherwise at the first agreement, which
+    every rank reaches at the same point of its program."""
+    global _control
+    if _control is None:
+        _control = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    return _control
+
+
+def all_min(value):
+    """min of an int over the ranks (the plain value without a process group).  Every rank must call it at the same point."""
     if not is_distributed():
-        return bool(ok)
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return bool(int(t.item()))
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=control_group())
+    return int(t.item())
+
+
+def all_agree(ok):
+    """True iff ``ok`` is true on EVERY rank (one MIN all-reduce on the control group).  Every rank must call it at the same
+    point of its program."""
+    return all_min(1 if ok else 0) == 1
 
 
 def _backend_has_avg():

@@ -155,7 +155,12 @@ def _dev_f32(a, device):
 
 
 def compute_prdc(real_features, fake_features, nearest_k, device="cuda"):
-    """prdc.compute_prdc(real_features, fake_features, nearest_k) -> dict(precision, recall, density, coverage)."""
+    """prdc.compute_prdc(real_features, fake_features, nearest_k) -> dict(precision, recall, density, coverage).
+    ``nearest_k`` <= 15 (the reference's notebooks use 5, evaluation.py:85-110): the k-th-neighbour kernel keeps its candidates
+    in registers (``KTH_MAX`` = 16 slots per lane, csrc/evaluation.hip); a larger k raises ``ValueError`` here instead of a C-ABI
+    error from inside the launch sequence."""
+    if not 1 <= int(nearest_k) <= 15:
+        raise ValueError(f"compute_prdc: nearest_k = {nearest_k} outside 1..15 (register-resident k-th-neighbour kernel)")
     lib = _lib.load()
     x, y = _dev_f32(real_features, device), _dev_f32(fake_features, device)
     n, d = x.shape

@@ -602,7 +602,7 @@ class _NormActConvFn(Function):
         _lib.check(lib.srgan_conv2d_fwd_from_v(ctypes.byref(desc), _ptr(v), _ptr(hit.buf), None, _ptr(y), ACT_NONE, 0.0, _stream()),
                    "conv2d_fwd_from_v")
         ctx.desc, ctx.weight, ctx.v_image = desc, weight, keep
-        ctx.act, ctx.slope = act, slope
+        ctx.act, ctx.slope, ctx.eps = act, slope, eps
         ctx.save_for_backward(x, scale, shift, mean, rstd)
         return y
 
@@ -621,7 +621,7 @@ class _NormActConvFn(Function):
             if ctx.v_image is not None:
                 _run_conv_wgrad(desc, None, gy, dw, None, ctx.v_image)
             else:       # no V kept (layer outside the F(4x4,3x3) weight-gradient geometry): recompute the normalised input
-                hx = _InstNormFn.apply(x.detach(), scale, shift, None, ctx.act, ctx.slope, 1e-5)
+                hx = _InstNormFn.apply(x.detach(), scale, shift, None, ctx.act, ctx.slope, ctx.eps)
                 _run_conv_wgrad(desc, hx, gy, dw, None)
         dx = dscale = dshift = None
         if ctx.needs_input_grad[0] or (scale is not None and ctx.needs_input_grad[1]):

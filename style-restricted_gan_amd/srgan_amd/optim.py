@@ -121,12 +121,22 @@ class Adam(torch.optim.Optimizer):
             if key in per_cohort:
                 co.steps = per_cohort[key]
 
-    def advance_host(self, n):
-        """A replayed graph ran ``n`` optimiser steps on the device: move the host-side counters with it."""
-        ids = {pid for key in self._cohorts for pid in key[1:]}
+    def counters_since(self, snap):
+        """What moved between ``snap`` (``host_counters()``) and now -- i.e. what ONE run of the step recorded in between does to
+        the host-side counters: per parameter and per cohort (a cohort or parameter that did not take part stays out)."""
+        per_param, per_cohort = snap
+        now_p, now_c = self.host_counters()
+        return ({pid: n - per_param.get(pid, 0) for pid, n in now_p.items() if n != per_param.get(pid, 0)},
+                {key: n - per_cohort[key] for key, n in now_c.items() if key in per_cohort and n != per_cohort[key]})
+
+    def advance_host(self, delta):
+        """A replayed graph ran its optimiser steps on the device: move the host-side counters by what the recording moved
+        (``counters_since``) -- exactly the parameters and cohorts that stepped while it was recorded."""
+        per_param, per_cohort = delta
         for group in self.param_groups:
             for p in group["params"]:
-                if id(p) in ids and p in self.state and len(self.state[p]):
-                    self.state[p]["step"] += n
-        for co in self._cohorts.values():
-            co.steps += n
+                d = per_param.get(id(p))
+                if d:
+                    self.state[p]["step"] += d
+        for key, d in per_cohort.items():
+            self._cohorts[key].steps += d

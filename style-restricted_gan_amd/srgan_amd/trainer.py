@@ -441,6 +441,8 @@ class SRGAN_training():
         g = self._graph
         if g is not None and g.accepts(source_image, label):
             return g.run(source_image, label)
+        if g is not None:
+            g.before_eager_step()
         self._g_active = False
         self.source_image = ops.to_nhwc(source_image)
         with ops.pack_cache():        # weights only change at self._step() inside this scope
@@ -465,6 +467,8 @@ class SRGAN_training():
         return self
 
     def disable_graph(self):
+        if self._graph is not None:
+            self._graph.before_eager_step()
         self._graph = None
         self._g_active = False
 
@@ -491,6 +495,11 @@ class _StepGraph:
         self.table = None
         self._epoch = -1
         self._keep = None
+        self._baked = None       # fingerprint of everything the recording holds by value or by pointer (see _fingerprint)
+        self._steps = None       # host-side optimiser step counts the device records stand at after the last replay
+        self._graph_ran = False  # the previous step ran on the capture stream (recorded or replayed)
+
+    fault_hook = None            # tests: callable(stage) with stage in {"before", "inside"}; raising makes the recording fail
 
     def unsupported_reason(self):
         sg = self.sg
@@ -509,19 +518,90 @@ class _StepGraph:
             return t.device.type if torch.is_tensor(t) else "host"
         return (tuple(source_image.shape), dev(label["source"]), dev(label["target"]))
 
+    def _fingerprint(self):
+        """Everything a recording bakes in besides the input shape and the buffers ``ops.structure_epoch()`` watches: the
+        optimiser objects, their hyper-parameters and moment tensors (``load_state_dict`` replaces them), which parameters
+        take gradients (``freeze_melt`` / ``requires_grad_``), k, the loss weights, the criteria, the style-code source, the
+        label table.  A replay with any of these changed would silently keep training the OLD configuration."""
+        sg = self.sg
+        fp = [sg.k, sg.n_batch, sg.ndim, sg.encoded_feature, tuple(sorted((k, float(v)) for k, v in sg.lbd.items())),
+              type(sg.criterion), type(sg.criterion_class), np.asarray(sg.ref_label, dtype=np.float64).tobytes()]
+        for opt in (sg.optG, sg.optD, sg.optE):
+            fp.append(id(opt))
+            for g in getattr(opt, "param_groups", ()):
+                fp.append((tuple(g["betas"]), float(g["eps"])))
+                for p in g["params"]:
+                    st = opt.state.get(p) or {}
+                    m, v = st.get("exp_avg"), st.get("exp_avg_sq")
+                    fp.append((id(p), m.data_ptr() if m is not None else 0, v.data_ptr() if v is not None else 0))
+        fp.append(tuple((id(p), p.data_ptr(), p.requires_grad) for p in self._all_params()))
+        return tuple(fp)
+
+    def _opt_steps(self):
+        sg = self.sg
+        return [[int(opt.state[p]["step"]) if len(opt.state.get(p) or {}) else -1 for g in opt.param_groups for p in g["params"]]
+                for opt in (sg.optG, sg.optD, sg.optE)]
+
+    def _drop(self):
+        self.graph, self.key, self._keep, self._baked, self._steps = None, None, None, None, None
+        self.x = self.noise = self.out = None
+
+    def _local_mode(self, source_image, label):
+        """2: replay the recording, 1: record (the eager warm-up of this input shape has run), 0: eager."""
+        if self.graph is not None:
+            stale = self._epoch != ops.structure_epoch()
+            # a buffer the recording points at was replaced (compute-mode switch, invalidate_packed, optimiser re-seeded), or
+            # something it baked in changed (optimiser state loaded, requires_grad toggled, lbd / k edited), or the host-side
+            # step counts are not where the last replay left them (load_state_dict): forget the graph; this step runs eagerly
+            # with the new state (which also re-seeds the device-side Adam records), the next one records again
+            if not stale and (self._baked != self._fingerprint() or self._steps != self._opt_steps()):
+                stale = True
+                reason = self.unsupported_reason()
+                if reason:
+                    raise NotImplementedError("SRGAN_training graph mode: " + reason)
+            if stale:
+                self._drop()
+        if self.key is None or self._key(source_image, label) != self.key or not source_image.is_cuda:
+            return 0
+        return 2 if self.graph is not None else 1
+
     def accepts(self, source_image, label):
-        if self.graph is not None and self._epoch != ops.structure_epoch():
-            # a buffer the recording points at was replaced (compute-mode switch, invalidate_packed, optimiser re-seeded):
-            # forget the graph; this step runs eagerly with the new buffers, the next one records again
-            self.graph, self.key, self._keep = None, None, None
-            self.x = self.noise = self.out = None
-        return self.key is not None and self._key(source_image, label) == self.key and source_image.is_cuda
+        """Replay / record this step (True) or run it eagerly (False).  Under a process group the decision is COLLECTIVE (one
+        MIN all-reduce of the local answer on the host-side control group): a rank replaying index-ordered flat buckets beside
+        a rank running the hook-ordered eager step -- or recording, with its extra agreement all-reduce -- would issue different
+        collectives.  If any rank has to record, every rank records again; if any rank runs eagerly, all do."""
+        mode = self._local_mode(source_image, label)
+        if dp.is_distributed():
+            agreed = dp.all_min(mode)
+            if agreed < 2 and self.graph is not None:
+                if agreed == 1:
+                    key = self.key
+                    self._drop()           # another rank re-records: record again with it (same segment structure)
+                    self.key = key
+            mode = agreed
+        return mode >= 1
+
+    def before_eager_step(self):
+        """An eager step follows a recorded / replayed one: the autograd graph the step keeps on purpose (``target_image`` is
+        back-propagated twice) pins AccumulateGrad nodes made on the CAPTURE stream; re-used by an eager backward they would
+        synchronise across streams on every gradient (PyTorch warns about the mismatch).  Drop those graphs first."""
+        if not self._graph_ran:
+            return
+        self._graph_ran = False
+        sg = self.sg
+        sg.target_image = sg.recon_image = sg.c_rand = sg.enc_info = sg.target_cenc = None
+        sg.loss_terms = {}
+        for opt in (sg.optG, sg.optD, sg.optE):
+            opt._keep_alive = None
+        gc.collect()
 
     def note_eager_step(self, source_image, label):
         if self.key is None and source_image.is_cuda:
             self.key = self._key(source_image, label)
         # the eager step left every packed operand fresh: writes from here on (load_state_dict, copy_) must be noticed
         self._versions = sum(p._version for p in self._all_params())
+        if self.graph is not None:      # an eager step of this trainer (another batch shape) moved the optimisers legitimately
+            self._steps = self._opt_steps()
 
     # -- what the captured body reads -----------------------------------------------------------------------------
     def onehot(self, which):
@@ -582,11 +662,9 @@ class _StepGraph:
         for opt in (sg.optG, sg.optD, sg.optE):
             opt._keep_alive = None
         gc.collect()
-        # fault injection for the tests of the agreed fall-back: "<rank>:before" / "<rank>:inside"
-        inject = os.environ.get("SRGAN_TEST_FAIL_CAPTURE", "")
-        inject = inject.split(":") if inject and int(inject.split(":")[0]) == dp.rank() else None
-        if inject and inject[1] == "before":
-            raise RuntimeError("injected failure before the recording (SRGAN_TEST_FAIL_CAPTURE)")
+        hook = type(self).fault_hook
+        if hook is not None:
+            hook("before")
         g = _Recording(self.x.device)
         sg._g_active = True
         self._noise_i, self._onehot = 0, {}
@@ -595,8 +673,8 @@ class _StepGraph:
             with g:
                 with ops.pack_cache(refresh_on_entry=False):
                     err = sg.UnrolledUpdate()
-                if inject and inject[1] == "inside":
-                    raise RuntimeError("injected failure inside the recording (SRGAN_TEST_FAIL_CAPTURE)")
+                if hook is not None:
+                    hook("inside")
                 self.out = torch.stack([e.detach().reshape(()) for e in err])
         finally:
             sg._g_active = False
@@ -606,6 +684,7 @@ class _StepGraph:
         self.terms = dict(sg.loss_terms)
         self._epoch = ops.structure_epoch()
         self._keep = ops.graph_keepalive() + [t for opt in (sg.optG, sg.optD, sg.optE) for t in opt.graph_keepalive()]
+        self._baked = self._fingerprint()
 
     def _abandon(self, err, snap):
         """Some rank could not record the step: every rank drops graph mode together.  THIS step still runs -- eagerly, from the
@@ -617,7 +696,7 @@ class _StepGraph:
             opt.restore_host_counters(c)          # the recording advanced them without running anything
         warnings.warn("SRGAN_training: the step could not be recorded as hipGraph segments on every rank"
                       + (f" (this rank: {type(err).__name__}: {err})" if err is not None else "") + "; running eagerly from here on")
-        self.graph = self._keep = None
+        self.graph = self._keep = self._baked = self._steps = None
         self._noise_i, self._onehot = 0, {}
         sg.target_image = sg.recon_image = sg.c_rand = None
         sg.loss_terms = {}
@@ -648,17 +727,28 @@ class _StepGraph:
                 self._capture()      # records; the host-side optimiser counters advanced while recording
             except Exception as e:   # noqa: BLE001 -- under a process group the ranks first agree on what happened
                 if not dp.is_distributed():
+                    # leave nothing half-advanced behind for a caller that catches this: the counters moved without anything
+                    # having run, caches may describe operands whose fill was only recorded, and graph mode stays off
+                    for opt, c in zip((sg.optG, sg.optD, sg.optE), snap):
+                        opt.restore_host_counters(c)
+                    ops.invalidate_packed()
+                    self._drop()
+                    sg._graph = None
+                    sg.target_image = sg.recon_image = sg.c_rand = None
+                    sg.loss_terms = {}
                     raise
                 err = e
             if dp.is_distributed() and not dp.all_agree(err is None):
                 # some rank could not record the step: EVERY rank gives the recording up together (a rank replaying segments
                 # beside a rank running eagerly would issue the same collectives in another order) and runs eagerly
                 return self._abandon(err, snap)
+            self._deltas = [opt.counters_since(c) for opt, c in zip((sg.optG, sg.optD, sg.optE), snap)]
         else:
-            sg.optD.advance_host(sg.k)
-            sg.optG.advance_host(2)
-            sg.optE.advance_host(1)
+            for opt, d in zip((sg.optG, sg.optD, sg.optE), self._deltas):
+                opt.advance_host(d)
         self.graph.replay()
+        self._graph_ran = True
+        self._steps = self._opt_steps()
         sg.source_image = self.x
         sg.loss_terms = dict(self.terms)
         out = self.out.clone()       # the static result vector is overwritten by the next replay

@@ -18,8 +18,12 @@ TIER_F = dict(G=dict(nch_in=3, nch=64, reduce=2, num_cls=2, res_num=6, num_con=1
 TIER_T256 = dict(G=TIER_T["G"], D=dict(nch_in=3, nch=4, reduce=2, num_cls=5, n_class=4), E=TIER_T["E"])
 
 
+# full widths on the 256x256 geometry (BASELINE configs[4]'s real dispatch: 64x64x256 trunk maps, five-conv discriminator)
+TIER_F256 = dict(G=TIER_F["G"], D=dict(nch_in=3, nch=64, reduce=2, num_cls=5, n_class=4), E=TIER_F["E"])
+
+
 def tier(name):
-    return {"T": TIER_T, "T256": TIER_T256}.get(name, TIER_F)
+    return {"T": TIER_T, "T256": TIER_T256, "F256": TIER_F256}.get(name, TIER_F)
 
 
 def oracle_params(name, seed=0):
@@ -88,7 +92,7 @@ def close_grad(a, b, tol=2e-4, l2_tol=1e-2, med_tol=1e-2, what=""):
     assert med <= med_tol, f"{what}: median err / median magnitude {med:.3e} (broad error: not an activation flip)"
 
 
-def close_params(a, b, lr, n_opt_steps, what=""):
+def close_params(a, b, lr, n_opt_steps, what="", walk=False):
     """Parameters after ``n_opt_steps`` Adam steps.  Adam moves every element by about lr*sign(g) in its first
     steps, so an element whose gradient is at rounding-noise level can legitimately end up to 2*lr per step away;
     the bulk of the tensor must agree far more tightly."""
@@ -101,4 +105,8 @@ def close_params(a, b, lr, n_opt_steps, what=""):
     # observed 4.094e-4 = 2 * lr * 2.047 on one element of G.down_convs.1.weight after 2 steps at bs=32, k=5
     assert float(err.max()) <= 2.2 * lr * n_opt_steps + 1e-6, f"{what}: max err {float(err.max()):.3e}"
     if a.numel() >= 32:      # tiny tensors (a 4-element bias) have no meaningful "bulk"
-        assert float(err.median()) <= 0.2 * lr, f"{what}: median err {float(err.median()):.3e}"
+        # ``walk``: over a long trajectory the elements whose gradient sits at rounding-noise level take independent +-lr
+        # steps on the two sides, a random walk of ~lr * sqrt(steps) (measured after 40 steps: median 4.8e-5 = 0.48 lr on the
+        # generator's RGB input layer, whose gradients are the noisiest; 0.2 * lr * sqrt(40) = 1.26 lr bounds it)
+        bound = 0.2 * lr * (max(n_opt_steps, 1) ** 0.5 if walk else 1.0)
+        assert float(err.median()) <= bound, f"{what}: median err {float(err.median()):.3e}"

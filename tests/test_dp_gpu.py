@@ -63,7 +63,8 @@ def _run(rank, world, out_q=None, kl=0.0, graph=False, recipe=None):
         sl = slice(rank * per, (rank + 1) * per)
         lab = {"source": label["source"][sl].cuda(), "target": label["target"][sl]}
         losses.append([float(v) for v in sg.train(x[sl].cuda(), lab)])
-    if graph and os.environ.get("SRGAN_TEST_FAIL_CAPTURE"):
+    from srgan_amd import trainer as htrainer
+    if graph and htrainer._StepGraph.fault_hook is not None:
         assert sg._graph is None and not sg.graph_active          # every rank gave the recording up together
     elif graph:
         # data parallel: the recording is cut at each of the K + 3 exchange points (K discriminator all-reduces, the mu
@@ -77,8 +78,6 @@ def _run(rank, world, out_q=None, kl=0.0, graph=False, recipe=None):
 
 
 def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False, graph=False, recipe=None, inject=None):
-    if inject:
-        os.environ["SRGAN_TEST_FAIL_CAPTURE"] = inject
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SRGAN_DP_DEVICE="0", SRGAN_DP_BACKEND=backend)
     if force:
@@ -92,9 +91,42 @@ def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False, graph
     from srgan_amd import dp
     dp.init_from_env()
     assert dp.world_size() == world and dp.is_distributed()
+    if inject:           # "<rank>:<stage>": that rank's recording fails before / inside the capture
+        from srgan_amd import trainer as htrainer
+        bad_rank, bad_stage = inject.split(":")
+
+        def hook(stage):
+            if rank == int(bad_rank) and stage == bad_stage:
+                raise RuntimeError(f"injected failure {stage} the recording")
+        htrainer._StepGraph.fault_hook = staticmethod(hook)
     _run(rank, world, out_q, kl, graph, recipe)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _spawn(world, make_args, timeout=240):
+    """Start ``world`` rank processes, collect one result per rank and ALWAYS reap them: a rank that dies leaves the others blocked
+    in a collective holding the GPU until the process-group timeout, which would wedge the rest of the GPU session."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=make_args(r, port, q)) for r in range(world)]
+    try:
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=timeout) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=120)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+                if p.is_alive():
+                    p.kill()
+                    p.join(timeout=10)
+    assert [p.exitcode for p in procs] == [0] * world, [p.exitcode for p in procs]
+    return res
 
 
 @pytest.mark.parametrize("kl,graph", [(0.0, False), (0.1, False), (0.0, True)])
@@ -104,16 +136,7 @@ def test_two_ranks_equal_one_process(kl, graph):
     graph=True: both ranks record the step as hipGraph segments and replay them with the collectives issued eagerly between
     the segments (step 0 eager, step 1 records + replays, step 2 replays); same bounds as the eager ranks."""
     ref_losses, ref_state, ref_terms = _run(0, 1, kl=kl)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kl, "gloo", False, graph)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    res = _spawn(2, lambda r, port, q: (r, 2, port, q, kl, "gloo", False, graph), timeout=240)
     dp_losses = (np.array(res[0][1]) + np.array(res[1][1])) / 2
     ref = np.array(ref_losses)
     # errG / errD are per-sample means -> rank average == full batch; errE's latent part is global on every rank
@@ -137,16 +160,7 @@ def test_failed_recording_on_one_rank_makes_every_rank_fall_back(inject):
     all-reduce, BOTH drop graph mode, run that very step eagerly from the inputs staged for the recording and continue eagerly --
     same results as the eager two-rank run (bounds of the test above)."""
     ref_losses, ref_state, ref_terms = _run(0, 1)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 0.0, "gloo", False, True, None, inject)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    res = _spawn(2, lambda r, port, q: (r, 2, port, q, 0.0, "gloo", False, True, None, inject), timeout=240)
     dp_losses = (np.array(res[0][1]) + np.array(res[1][1])) / 2
     np.testing.assert_allclose(dp_losses, np.array(ref_losses), rtol=1e-3)
     for key, v in res[0][2].items():
@@ -164,13 +178,7 @@ def test_rccl_path_one_rank_equals_plain_step(graph):
     test above.)  graph=True: the same with the step recorded as hipGraph segments, the RCCL all-reduces and the all-gather
     issued eagerly between the segments on every replay."""
     ref_losses, ref_state, ref_terms = _run(0, 1)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), q, 0.0, "nccl", True, graph))
-    p.start()
-    rank, losses, state, terms = q.get(timeout=240)
-    p.join(timeout=120)
-    assert p.exitcode == 0
+    (rank, losses, state, terms), = _spawn(1, lambda r, port, q: (0, 1, port, q, 0.0, "nccl", True, graph))
     np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=1e-4)
     for key, v in state.items():
         d = float(np.abs(v - ref_state[key]).max())
@@ -187,16 +195,7 @@ def test_config2_recipe_two_ranks_equal_one_process(graph):
         ref_losses, ref_state, ref_terms = _run(0, 1, recipe="config2")
     finally:
         ops.set_compute_dtype("fp32")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 0.0, "gloo", False, graph, "config2")) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    res = _spawn(2, lambda r, port, q: (r, 2, port, q, 0.0, "gloo", False, graph, "config2"), timeout=240)
     dp_losses = (np.array(res[0][1]) + np.array(res[1][1])) / 2
     np.testing.assert_allclose(dp_losses, np.array(ref_losses), rtol=1e-3)
     for key, v in res[0][2].items():
@@ -214,16 +213,7 @@ def test_config3_recipe_four_ranks_equal_one_process():
         ref_losses, ref_state, ref_terms = _run(0, 1, recipe="config3")
     finally:
         ops.set_compute_dtype("fp32")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 4, port, q, 0.0, "gloo", False, False, "config3")) for r in range(4)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    res = _spawn(4, lambda r, port, q: (r, 4, port, q, 0.0, "gloo", False, False, "config3"), timeout=300)
     dp_losses = sum(np.array(r[1]) for r in res) / 4
     np.testing.assert_allclose(dp_losses, np.array(ref_losses), rtol=1e-3)
     for key in ("errE_bKL", "errE_corr", "errE_hist"):          # global-batch statistics: identical on every rank

@@ -105,6 +105,7 @@ def step_vs_oracle(tier, batch, k, seed, batch_seed, size=128, rtol=1e-3, norm_r
     orc = otrainer.SRGANOracle(PG, PD, PE, otrainer.DEFAULT_LBD, k, np.eye(4), batch, "mu", 8)
     x, label = otrainer.synthetic_batch(batch, size, 4, seed=batch_seed)
     ref = [float(v) for v in orc.train(x, label)]
+    orc.last_losses = ref
 
     from srgan_amd.trainer import SRGAN_training
     G, D, E = build_hip_nets(tier)
@@ -183,6 +184,76 @@ def test_headline_shape_step_bf16_vs_oracle():
     if os.environ.get("SRGAN_TEST_LOG"):
         print("bf16 headline step: losses", out, "oracle", ref, "worst relative deviation", worst)
     np.testing.assert_allclose(out, ref, rtol=3e-2)
+
+
+def test_config4_full_width_256_step_vs_oracle():
+    """BASELINE configs[4]'s REAL dispatch: full-width networks on 256x256 images (64x64x256 trunk maps on F(4x4,3x3) / the
+    LDS-resident-patch bf16 kernels, the five-conv discriminator at width 64, 128x128x64 and 256x256x64 stride-2 layers),
+    bs 2, k 2, one whole train step against the CPU oracle on the same seeds -- in fp32 (1e-3, north_star) and in the bf16 mode
+    the configuration names (1e-2 on the three losses and every loss term against the fp32 oracle)."""
+    from srgan_amd import ops
+    from srgan_amd.trainer import SRGAN_training
+    batch, k, size = 2, 2, 256
+    sg, orc = step_vs_oracle("F256", batch, k, seed=13, batch_seed=91, size=size, norm_rtol=1e-4)
+    ref = [float(v) for v in orc.last_losses]
+    del sg
+    torch.cuda.empty_cache()
+    x, label = otrainer.synthetic_batch(batch, size, 4, seed=91)
+    ops.set_compute_dtype("bf16")
+    try:
+        G, D, E = build_hip_nets("F256")
+        torch.manual_seed(13)
+        sg = SRGAN_training([G, D, E], [None, None, None], [nn.MSELoss(), nn.MSELoss()], dict(otrainer.DEFAULT_LBD), k,
+                            "cuda", np.eye(4), batch, "mu", 8)
+        sg.opt_sche_initialization()
+        out = [float(v) for v in sg.train(x.cuda(), {"source": label["source"].cuda(), "target": label["target"]})]
+    finally:
+        ops.set_compute_dtype("fp32")
+        ops.invalidate_packed()
+    np.testing.assert_allclose(out, ref, rtol=1e-2)
+    t = {k_: float(v) for k_, v in sg.loss_terms.items()}
+    for a, b in TERM_PAIRS:
+        assert abs(t[a] - orc.trace[b]) <= 1e-2 * max(abs(orc.trace[b]), 1e-3), (a, t[a], orc.trace[b])
+
+
+def test_twenty_step_trajectory_vs_oracle_across_a_scheduler_step():
+    """20 consecutive train steps (tier-T widths, real 128x128 geometry, k=2) against the CPU oracle on the same seeds, with the
+    epoch boundary of the notebooks in the middle: ``ExponentialLR(gamma=0.95).step()`` on all three optimisers after step 10
+    (util_notebook.py:484-508; the oracle's Adam gets the same factor).  Checks that nothing drifts apart over a trajectory --
+    optimiser state, the stale-graph phase, the RNG order -- beyond fp32 reduction-order noise amplified by the GAN dynamics."""
+    from srgan_amd.trainer import SRGAN_training
+    batch, k, steps = 4, 2, 20
+    PG, PD, PE = oracle_params("T")
+    torch.manual_seed(21)
+    orc = otrainer.SRGANOracle(PG, PD, PE, otrainer.DEFAULT_LBD, k, np.eye(4), batch, "mu", 8)
+    ref = []
+    for s in range(steps):
+        if s == 10:
+            for o in (orc.optG, orc.optD, orc.optE):
+                o.lr *= 0.95
+        x, label = otrainer.synthetic_batch(batch, 128, 4, seed=600 + s)
+        ref.append([float(v) for v in orc.train(x, label)])
+    G, D, E = build_hip_nets("T")
+    torch.manual_seed(21)
+    sg = SRGAN_training([G, D, E], [None, None, None], [nn.MSELoss(), nn.MSELoss()], dict(otrainer.DEFAULT_LBD), k,
+                        "cuda", np.eye(4), batch, "mu", 8)
+    sg.opt_sche_initialization()
+    out = []
+    for s in range(steps):
+        if s == 10:
+            sg.scheG.step(), sg.scheD.step(), sg.scheE.step()
+        x, label = otrainer.synthetic_batch(batch, 128, 4, seed=600 + s)
+        out.append([float(v) for v in sg.train(x.cuda(), {"source": label["source"].cuda(), "target": label["target"]})])
+    assert abs(sg.optG.param_groups[0]["lr"] - 0.95e-4) < 1e-12
+    out, ref = np.array(out), np.array(ref)
+    rel = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-6)
+    if os.environ.get("SRGAN_TEST_LOG"):
+        with open(os.environ["SRGAN_TEST_LOG"], "a") as f:
+            f.write("20-step trajectory, max relative deviation per step: " + " ".join(f"{v:.1e}" for v in rel.max(1)) + "\n")
+    np.testing.assert_allclose(out, ref, rtol=1e-3)          # measured on the MI355X: <= 3.8e-5 at every step
+    for net, P, n_opt in ((sg.G, orc.G, 2 * steps), (sg.D, orc.D, k * steps), (sg.E, orc.E, steps)):
+        for key, v in net.state_dict().items():
+            close_params(v, P[key], 1e-4, n_opt, what=key, walk=True)
 
 
 def test_bs64_step_vs_oracle_tier_T():
