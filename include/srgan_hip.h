@@ -116,8 +116,12 @@ size_t srgan_pack_entry_bytes(void);
 int srgan_conv2d_pack_entry(const srgan_conv_desc* d, int kind, int act, const float* w, void* packed, void* entry);
 int srgan_conv2d_pack_multi(const void* entries_dev, int n_entries, void* stream);
 
-/* Gradient w.r.t. the conv weight, written through (sO,sI,sH,sW) (overwrites, no accumulate);
- * dbias[O] (may be NULL) = column sums of dy. */
+/* Gradient w.r.t. the conv weight, written through (sO,sI,sH,sW); dbias[O] (may be NULL) = column sums of dy.
+ * Overwrites dw / dbias, unless srgan_set_wgrad_accumulate(1) is in effect on the calling host thread: then every weight-gradient
+ * entry point (srgan_conv2d_wgrad, _wgrad_v, _wgrad_vz, srgan_halo16_wgrad) ADDS its result in the split-K slab reduce
+ * (dw += ...): the reference's autograd sums the two uses of the generator's weights inside one backward call
+ * (util_notebook.py:664, :689; torch's AccumulateGrad input buffer) -- here without a separate elementwise pass. */
+int srgan_set_wgrad_accumulate(int on);
 int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, const float* dy, float* dw,
                        float* dbias, void* ws, size_t ws_bytes, void* stream);
 
@@ -167,6 +171,9 @@ size_t srgan_cbin_rec_bytes(void);
 int srgan_cbin_rec_fill(void* rec, const float* W, const float* b, const float* gamma, const float* beta, float* t,
                         float* scale, float* shift, const float* dscale, const float* dshift, float* dgamma,
                         float* dbeta, float* dW, float* db, float* da, int C);
+/* on != 0: the backward of this record ADDS to dgamma / dbeta / dW / db (a layer reached twice in one backward pass: the
+ * generator is back-propagated through two graphs inside util_notebook.py:664 and again inside :689). */
+int srgan_cbin_rec_set_accumulate(void* rec, int on);
 int srgan_cbin_affine_multi_fwd(const float* c, const void* table_dev, int n_layers, int N, int max_C, int num_con,
                                 void* stream);
 int srgan_cbin_affine_multi_bwd(const float* c, const void* table_dev, int n_layers, int N, int max_C, int num_con,

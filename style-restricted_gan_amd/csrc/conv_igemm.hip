@@ -891,6 +891,7 @@ struct WgradReduceParams {
   float* dw;
   long long sO, sI, sH, sW;
   int O, I, kh, kw, splits, Cdpad, NNpad;
+  int accumulate;      // 1: dw += the slab sum (a second use of the same weight in one backward pass: srgan_set_wgrad_accumulate)
 };
 
 __global__ void wgrad_reduce_kernel(WgradReduceParams p) {
@@ -906,7 +907,8 @@ __global__ void wgrad_reduce_kernel(WgradReduceParams p) {
     const size_t off = (size_t)o * p.NNpad + (size_t)(ky * p.kw + kx) * p.I + i;
     float v = 0.f;
     for (int s = 0; s < p.splits; ++s) v += p.slab[s * slab_stride + off];
-    p.dw[o * p.sO + i * p.sI + ky * p.sH + kx * p.sW] = v;
+    float* dst = p.dw + (o * p.sO + i * p.sI + ky * p.sH + kx * p.sW);
+    *dst = p.accumulate ? *dst + v : v;
   }
 }
 
@@ -927,7 +929,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(WgradReduceParam
     float v = 0.f;
     for (int s = lane; s < p.splits; s += 64) v += p.slab[s * slab_stride + off];
     v = wave_sum(v);
-    if (lane == 0) p.dw[o * p.sO + i * p.sI + ky * p.sH + kx * p.sW] = v;
+    if (lane == 0) {
+      float* dst = p.dw + (o * p.sO + i * p.sI + ky * p.sH + kx * p.sW);
+      *dst = p.accumulate ? *dst + v : v;
+    }
   }
 }
 
@@ -942,13 +947,13 @@ __global__ void colsum_partial_kernel(const float* a, float* part, int M, int C,
 }
 // one WAVE per column: lane l sums partials l, l + 64, ... (fixed assignment), then a shuffle tree -- deterministic, and the
 // up-to-1024 partials no longer sit in one thread's serial chain (18 us per launch, 25 launches per step)
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, float* out, int C, int nparts) {
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, float* out, int C, int nparts, int accumulate) {
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (c >= C) return;
   float s = 0.f;
   for (int i = lane; i < nparts; i += 64) s += part[(size_t)i * C + c];
   s = wave_sum(s);
-  if (lane == 0) out[c] = s;
+  if (lane == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
 // ---- host side ----------------------------------------------------------------------------
@@ -1922,12 +1927,16 @@ static int launch_wgrad(const WgradParams& p, const WgradPlan& w, hipStream_t st
 }  // namespace srgan
 
 namespace srgan {
+// srgan_set_wgrad_accumulate: while on, the weight-gradient entry points of this host thread ADD to dw / dbias
+static thread_local int g_wgrad_accumulate = 0;
+
 // slab sum -> dW (through the weight strides) and optional bias column sums
 static int finish_wgrad(const srgan_conv_desc* d, const WgradPlan& w, const float* dy, float* dw, float* dbias, void* ws,
                         hipStream_t st) {
   WgradReduceParams r{};
   r.slab = (const float*)ws; r.dw = dw; r.sO = d->sO; r.sI = d->sI; r.sH = d->sH; r.sW = d->sW;
   r.O = d->O; r.I = d->I; r.kh = d->kh; r.kw = d->kw; r.splits = w.splits; r.Cdpad = w.Cdpad; r.NNpad = w.NNpad;
+  r.accumulate = g_wgrad_accumulate;
   long long total = (long long)d->O * d->kh * d->kw * d->I;
   if (w.splits >= 64 && total <= 131072)
     hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 4), 8192)), dim3(256), 0, st, r);
@@ -1943,7 +1952,8 @@ static int finish_wgrad(const srgan_conv_desc* d, const WgradPlan& w, const floa
     dim3 g1((unsigned)ceil_div(d->O, 64), (unsigned)nparts);
     hipLaunchKernelGGL(colsum_partial_kernel, g1, dim3(64), 0, st, dy, part, M, d->O, rpb);
     if (int e3 = check_launch("colsum_partial_kernel")) return e3;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(d->O, 4)), dim3(256), 0, st, (const float*)part, dbias, d->O, nparts);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(d->O, 4)), dim3(256), 0, st, (const float*)part, dbias, d->O, nparts,
+                       g_wgrad_accumulate);
     return check_launch("colsum_final_kernel");
   }
   return 0;
@@ -1983,6 +1993,13 @@ extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, cons
   int e = launch_wgrad(p, w, st);
   if (e) return e;
   return finish_wgrad(d, w, dy, dw, dbias, ws, st);
+}
+
+// A weight used more than once in one backward pass (the generator runs twice inside util_notebook.py:664 and :689) gets its
+// later contributions added by the split-K slab reduce instead of by a separate elementwise pass of the caller.
+extern "C" int srgan_set_wgrad_accumulate(int on) {
+  srgan::g_wgrad_accumulate = on != 0;
+  return 0;
 }
 
 // ---- compute mode (BASELINE configs [2]-[4] are bf16): process-wide, set between steps ----

@@ -400,7 +400,7 @@ struct CbinRec {
   float *t, *scale, *shift;              // forward outputs / backward inputs (t)
   const float *dscale, *dshift;          // backward inputs ([N][C], never null: the host substitutes zeros)
   float *dgamma, *dbeta, *dW, *db, *da;  // backward outputs; da = [N][C] scratch for the dc pass
-  int C, pad;
+  int C, accumulate;                     // accumulate: the backward ADDS to dgamma / dbeta / dW / db (srgan_cbin_rec_set_accumulate)
 };
 
 __global__ void cbin_affine_multi_fwd_kernel(const float* c, const CbinRec* tab, int N, int nc) {
@@ -446,13 +446,13 @@ __global__ __launch_bounds__(256) void cbin_affine_multi_bwd_ch(const float* c, 
   for (int j = 0; j < 16; ++j)
     if (j < nc) dw[j] = wave_sum(dw[j]);
   if (lane == 0) {
-    r.dgamma[ch] = dg;
-    r.dbeta[ch] = dbt;
-    r.db[ch] = dbb;
+    r.dgamma[ch] = r.accumulate ? r.dgamma[ch] + dg : dg;
+    r.dbeta[ch] = r.accumulate ? r.dbeta[ch] + dbt : dbt;
+    r.db[ch] = r.accumulate ? r.db[ch] + dbb : dbb;
   }
 #pragma unroll
   for (int j = 0; j < 16; ++j)
-    if (j < nc && lane == j) r.dW[ch * nc + j] = dw[j];
+    if (j < nc && lane == j) r.dW[ch * nc + j] = r.accumulate ? r.dW[ch * nc + j] + dw[j] : dw[j];
 }
 
 // one WORKGROUP per sample, one wave per layer (<= 16 layers per pass): dc[n][j] = sum over layers and channels of
@@ -846,6 +846,17 @@ extern "C" int srgan_cbin_rec_fill(void* rec, const float* W, const float* b, co
                                    float* dbeta, float* dW, float* db, float* da, int C) {
   SRGAN_REQUIRE(rec && C > 0, "cbin_rec_fill: bad argument");
   CbinRec r{W, b, gamma, beta, t, scale, shift, dscale, dshift, dgamma, dbeta, dW, db, da, C, 0};
+  std::memcpy(rec, &r, sizeof(r));
+  return 0;
+}
+
+// The backward pass of this record ADDS its parameter gradients to dgamma / dbeta / dW / db instead of overwriting them (the
+// same layer reached a second time in one backward pass: the caller points the record at the first visit's results).
+extern "C" int srgan_cbin_rec_set_accumulate(void* rec, int on) {
+  SRGAN_REQUIRE(rec, "cbin_rec_set_accumulate: null record");
+  CbinRec r;
+  std::memcpy(&r, rec, sizeof(r));
+  r.accumulate = on != 0;
   std::memcpy(rec, &r, sizeof(r));
   return 0;
 }

@@ -50,6 +50,7 @@ SIGNATURES = {
     "srgan_instnorm_slab_applicable": (c_int, [c_int, c_int, c_int]),
     "srgan_instnorm_slab_fwd_io": (c_int, [P, c_int, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_float, P]),
     "srgan_instnorm_slab_bwd_io": (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "srgan_set_wgrad_accumulate": (c_int, [c_int]),
     "srgan_conv2d_wgrad": (c_int, [_DESC, P, P, P, P, P, c_size_t, P]),
     "srgan_conv2d_wgrad_v_bytes": (c_size_t, [_DESC]),
     "srgan_conv2d_wgrad_v": (c_int, [_DESC, P, P, P, P, P, c_size_t, P]),
@@ -60,6 +61,7 @@ SIGNATURES = {
     "srgan_cbin_affine_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     "srgan_cbin_rec_bytes": (c_size_t, []),
     "srgan_cbin_rec_fill": (c_int, [P] * 15 + [c_int]),
+    "srgan_cbin_rec_set_accumulate": (c_int, [P, c_int]),
     "srgan_cbin_affine_multi_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "srgan_cbin_affine_multi_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
     "srgan_act_fwd": (c_int, [P, P, c_longlong, c_int, c_float, P]),

@@ -93,6 +93,13 @@ def unwrap(net):
 _recorder = None
 
 
+def hooks_need_live_grads():
+    """True when the gradient hooks must fire WHILE the backward runs: the eager data-parallel step sends a bucket the moment
+    its last gradient is final (``GradReducer._on_grad``), so parameter gradients have to pass through autograd's AccumulateGrad
+    there; everywhere else the trainer lets the weight-gradient kernels accumulate (``ops.fused_param_grads``)."""
+    return is_distributed() and _recorder is None
+
+
 def set_recorder(rec):
     """rec: object with ``cut(comm)`` (end the current graph segment, run ``comm()`` after it on every replay) or None."""
     global _recorder

@@ -409,6 +409,76 @@ def _run_conv_wgrad(desc, x, dy, dw, dbias, v_image=None):
                                               nb, _stream()), "conv2d_wgrad")
 
 
+# ---- parameter-gradient sink ------------------------------------------------------------------------------
+# A parameter reached through several graphs in ONE backward call (the generator inside util_notebook.py:664 and :689: the
+# reconstruction / identity graph and the kept ``target_image`` graph) gets one gradient per use; torch's engine sums them in
+# the AccumulateGrad input buffer -- 156 small elementwise launches per train step.  Inside a ``fused_param_grads`` scope the
+# weight-gradient kernels of this module write a parameter's FIRST contribution of the pass into a fresh buffer and ADD the
+# later ones in their own epilogue (split-K slab reduce with beta = 1, central-biasing records with the accumulate flag); the
+# Functions return no gradient for such a parameter, and when the scope closes ``p.grad`` is bound to the buffer (added to an
+# existing ``p.grad``, as AccumulateGrad would) and the parameter's post-accumulate-grad hooks are called.  Same operands, same
+# single rounding per addition as the engine's ``a += b``: bit-identical results.  Opt-in (the trainer wraps its backward calls):
+# plain ``.backward()`` / ``autograd.grad`` on the modules keeps the ordinary path.
+_grad_sink = None
+
+
+class fused_param_grads:
+    def __init__(self, enabled=True):
+        self._enabled = enabled
+
+    def __enter__(self):
+        global _grad_sink
+        self._prev = _grad_sink
+        _grad_sink = {} if self._enabled else None
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _grad_sink
+        sink, _grad_sink = _grad_sink, self._prev
+        if et is None and sink:
+            with torch.no_grad():
+                for p, buf in sink.values():
+                    if p.grad is None:
+                        p.grad = buf
+                    else:
+                        p.grad.add_(buf)
+                    for hook in (getattr(p, "_post_accumulate_grad_hooks", None) or {}).values():
+                        hook(p)
+        return False
+
+
+def _sink_slots(*params):
+    """-> ([buffer per parameter], accumulate) when every parameter can take its gradient through the sink of the current
+    scope (leaf parameters, all visited before or none), else None: the caller then returns ordinary gradients."""
+    if _grad_sink is None:
+        return None
+    if not all(p.is_leaf and p.requires_grad for p in params):
+        return None
+    seen = [id(p) in _grad_sink for p in params]
+    if any(seen) and not all(seen):
+        return None
+    if not seen[0]:
+        for p in params:
+            _grad_sink[id(p)] = (p, torch.empty(p.shape, dtype=torch.float32, device=p.device))
+    return [_grad_sink[id(p)][1] for p in params], seen[0]
+
+
+class _wgrad_accumulate:
+    """``srgan_set_wgrad_accumulate`` around the weight-gradient calls of one Function.backward (thread-local in the library)."""
+
+    def __init__(self, on):
+        self._on = bool(on)
+
+    def __enter__(self):
+        if self._on:
+            _lib.load().srgan_set_wgrad_accumulate(1)
+
+    def __exit__(self, *exc):
+        if self._on:
+            _lib.load().srgan_set_wgrad_accumulate(0)
+        return False
+
+
 def _act_bwd(y, gy, act, slope):
     g = torch.empty_like(gy)
     _lib.check(_lib.load().srgan_act_bwd(_ptr(y), _ptr(gy), _ptr(g), gy.numel(), act, float(slope), _stream()), "act_bwd")
@@ -443,6 +513,7 @@ class _Conv2dFn(Function):
         ctx.desc, ctx.act, ctx.slope = desc, act, slope
         ctx.weight = weight            # by reference: read at backward time (torch 1.4 semantics)
         ctx.has_bias = bias is not None
+        ctx.bias = bias
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
         if skip:
             return y, x
@@ -465,12 +536,21 @@ class _Conv2dFn(Function):
                 res = res.clone()
             _run_conv_dgrad(ctx.desc, gy, weight, dx, res)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
+            slots = _sink_slots(*((weight, ctx.bias) if ctx.has_bias else (weight,)))
+            acc = False
+            if slots is not None:
+                (dw, *rest), acc = slots
+                db = rest[0] if rest else None
+            else:
+                dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
+                if ctx.has_bias:
+                    db = torch.empty(weight.shape[0], dtype=torch.float32, device=weight.device)
             desc = ConvDesc.from_buffer_copy(ctx.desc)
             desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
-            if ctx.has_bias:
-                db = torch.empty(weight.shape[0], dtype=torch.float32, device=weight.device)
-            _run_conv_wgrad(desc, x, gy, dw, db, ctx.v_image)
+            with _wgrad_accumulate(acc):
+                _run_conv_wgrad(desc, x, gy, dw, db, ctx.v_image)
+            if slots is not None:
+                dw = db = None
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -515,10 +595,14 @@ class _ConvTranspose2dFn(Function):
             dx = torch.empty_like(x)
             _run_conv_fwd(ctx.desc, gy, weight, None, dx, ACT_NONE, 0.0)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
+            slots = _sink_slots(weight)
+            (dw,), acc = slots if slots is not None else ([torch.empty(weight.shape, dtype=torch.float32, device=weight.device)], False)
             desc = ConvDesc.from_buffer_copy(ctx.desc)
             desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
-            _run_conv_wgrad(desc, gy, x, dw, None)
+            with _wgrad_accumulate(acc):
+                _run_conv_wgrad(desc, gy, x, dw, None)
+            if slots is not None:
+                dw = None
         return dx, dw, None, None
 
 
@@ -615,14 +699,18 @@ class _NormActConvFn(Function):
         n, c, h, w = x.shape
         dw = None
         if ctx.needs_input_grad[3]:
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
+            slots = _sink_slots(weight)
+            (dw,), acc = slots if slots is not None else ([torch.empty(weight.shape, dtype=torch.float32, device=weight.device)], False)
             desc = ConvDesc.from_buffer_copy(ctx.desc)
             desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
-            if ctx.v_image is not None:
-                _run_conv_wgrad(desc, None, gy, dw, None, ctx.v_image)
-            else:       # no V kept (layer outside the F(4x4,3x3) weight-gradient geometry): recompute the normalised input
-                hx = _InstNormFn.apply(x.detach(), scale, shift, None, ctx.act, ctx.slope, ctx.eps)
-                _run_conv_wgrad(desc, hx, gy, dw, None)
+            with _wgrad_accumulate(acc):
+                if ctx.v_image is not None:
+                    _run_conv_wgrad(desc, None, gy, dw, None, ctx.v_image)
+                else:   # no V kept (layer outside the F(4x4,3x3) weight-gradient geometry): recompute the normalised input
+                    hx = _InstNormFn.apply(x.detach(), scale, shift, None, ctx.act, ctx.slope, ctx.eps)
+                    _run_conv_wgrad(desc, hx, gy, dw, None)
+            if slots is not None:
+                dw = None
         dx = dscale = dshift = None
         if ctx.needs_input_grad[0] or (scale is not None and ctx.needs_input_grad[1]):
             dh = torch.empty_like(x)
@@ -713,12 +801,15 @@ class _ResBlockFn(Function):
             return vimg, zimg, dsc, dsh
 
         def wgrad_vz(desc, weight, v_fwd, zimg):
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+            slots = _sink_slots(weight)
+            (dw,), acc = slots if slots is not None else ([torch.empty(weight.shape, dtype=torch.float32, device=dev)], False)
             dd = ConvDesc.from_buffer_copy(desc)
             dd.sO, dd.sI, dd.sH, dd.sW = dw.stride()
             ws, nb = _conv_ws(dd, dev)
-            _lib.check(lib.srgan_conv2d_wgrad_vz(ctypes.byref(dd), _ptr(v_fwd), _ptr(zimg), _ptr(dw), _ptr(ws), nb, st), "conv2d_wgrad_vz")
-            return dw
+            with _wgrad_accumulate(acc):
+                _lib.check(lib.srgan_conv2d_wgrad_vz(ctypes.byref(dd), _ptr(v_fwd), _ptr(zimg), _ptr(dw), _ptr(ws), nb, st),
+                           "conv2d_wgrad_vz")
+            return None if slots is not None else dw
 
         def dgrad_from_v(desc, weight, vimg, res, ch):
             hit, _ = _packed(desc, weight, 1, ACT_NONE)
@@ -805,13 +896,15 @@ class _ResBlockBf16Fn(Function):
             return dy, dsc, dsh
 
         def wgrad(desc, weight, xin, xin16, dy):
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+            slots = _sink_slots(weight)
+            (dw,), acc = slots if slots is not None else ([torch.empty(weight.shape, dtype=torch.float32, device=dev)], False)
             dd = ConvDesc.from_buffer_copy(desc)
             dd.sO, dd.sI, dd.sH, dd.sW = dw.stride()
             ws, nb = _conv_ws(dd, dev)
-            _lib.check(lib.srgan_halo16_wgrad(ctypes.byref(dd), _ptr(xin), xin16, _ptr(dy), 1, _ptr(dw), _ptr(ws), nb, st),
-                       "halo16_wgrad")
-            return dw
+            with _wgrad_accumulate(acc):
+                _lib.check(lib.srgan_halo16_wgrad(ctypes.byref(dd), _ptr(xin), xin16, _ptr(dy), 1, _ptr(dw), _ptr(ws), nb, st),
+                           "halo16_wgrad")
+            return None if slots is not None else dw
 
         dy2, ds2, dh2 = norm_bwd(y2, g, 0, s2, h2, mean2, rstd2, ACT_NONE)
         dw2 = wgrad(d2, w2, hh, 1, dy2) if ctx.needs_input_grad[6] else None
@@ -974,6 +1067,7 @@ class _CbinAffineMultiFn(Function):
         table = _cbin_table(recs, dev)
         _lib.check(lib.srgan_cbin_affine_multi_fwd(_ptr(c), _ptr(table), L, n, max(chs), nc, _stream()), "cbin_affine_multi_fwd")
         ctx.Ws = [params[4 * l] for l in range(L)]          # by reference: read at backward time
+        ctx.params = params                                 # the parameter objects (gradient sink: see fused_param_grads)
         ctx.chs = chs
         ctx.save_for_backward(c, *ts, *outs[0::2])
         return tuple(outs)
@@ -1000,17 +1094,24 @@ class _CbinAffineMultiFn(Function):
                 dscale = zeros if dscale is None else dscale
                 dshift = zeros if dshift is None else dshift
             dscale, dshift = _dense2d(dscale), _dense2d(dshift)
-            dgamma = torch.empty(ch, dtype=torch.float32, device=dev)
-            dbeta = torch.empty_like(dgamma)
-            dW = torch.empty(ch, nc, dtype=torch.float32, device=dev)
-            db = torch.empty_like(dgamma)
+            slots = _sink_slots(*ctx.params[4 * l: 4 * l + 4]) if all(ctx.needs_input_grad[1 + 4 * l: 5 + 4 * l]) else None
+            if slots is not None:
+                (dW, db, dgamma, dbeta), acc = slots
+            else:
+                acc = False
+                dgamma = torch.empty(ch, dtype=torch.float32, device=dev)
+                dbeta = torch.empty_like(dgamma)
+                dW = torch.empty(ch, nc, dtype=torch.float32, device=dev)
+                db = torch.empty_like(dgamma)
             rec = (ctypes.c_char * nb)()
             _lib.check(lib.srgan_cbin_rec_fill(ctypes.byref(rec), _ptr(ctx.Ws[l]), None, _ptr(scales[l]), None, _ptr(ts[l]), None,
                                                None, _ptr(dscale), _ptr(dshift), _ptr(dgamma), _ptr(dbeta), _ptr(dW), _ptr(db),
                                                da.data_ptr() + off * 4, ch), "cbin_rec_fill")
+            if acc:
+                _lib.check(lib.srgan_cbin_rec_set_accumulate(ctypes.byref(rec), 1), "cbin_rec_set_accumulate")
             off += n * ch
             recs.append((rec, dscale, dshift))
-            res += [dW, db, dgamma, dbeta]
+            res += [None] * 4 if slots is not None else [dW, db, dgamma, dbeta]
         table = _cbin_table([r[0] for r in recs], dev)
         dc = torch.empty(n, nc, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         _lib.check(lib.srgan_cbin_affine_multi_bwd(_ptr(c), _ptr(table), L, n, max(ctx.chs), nc, _ptr(dc), _stream()),

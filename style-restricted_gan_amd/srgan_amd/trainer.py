@@ -260,7 +260,8 @@ class SRGAN_training():
             errD_fake, _ = self._d_losses(self.target_image.detach(), 0., None, False)
         errD = errD_real + errD_class * self.lbd["class"] + errD_fake
         self._reduce_arm("D", self.optD)
-        errD.backward()
+        with ops.fused_param_grads(not dp.hooks_need_live_grads()):
+            errD.backward()
         red = self._reduce_start("D", self.optD)
         nxt = _next_fake() if _next_fake is not None else None      # optional work to overlap with the all-reduce
         if red is not None:
@@ -342,7 +343,10 @@ class SRGAN_training():
             total_p1 = errG + errE if torch.is_tensor(errE) else errG
             self._reduce_arm("G", self.optG)
             self._reduce_arm("E", self.optE)
-            total_p1.backward(retain_graph=True)         # target_image's graph is needed again in phase 2
+            # the generator's weights are reached twice in this pass (reconstruction / identity graph and the kept target_image
+            # graph): their weight-gradient kernels add the second contribution themselves (ops.fused_param_grads)
+            with ops.fused_param_grads(not dp.hooks_need_live_grads()):
+                total_p1.backward(retain_graph=True)     # target_image's graph is needed again in phase 2
         redG = self._reduce_start("G", self.optG)
         redE = self._reduce_start("E", self.optE)
         if redG is not None:
@@ -385,7 +389,8 @@ class SRGAN_training():
                     errG_ex = errG_ex + errG_idt_reg * (L["idt_reg"] * (L["idt"] / L["cycle"]))
                     terms["errG_idt_reg"] = errG_idt_reg
             self._reduce_arm("G", self.optG)
-            errG_ex.backward()
+            with ops.fused_param_grads(not dp.hooks_need_live_grads()):
+                errG_ex.backward()
         redG = self._reduce_start("G", self.optG)
         if redG is not None:
             redG.finish()

@@ -816,3 +816,45 @@ def test_pack_cache_never_serves_a_stale_operand(ops):
         close(conv(), ref())
         w.data = (w.data * 3.0).clone()      # storage swapped under the parameter
         close(conv(), ref())
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_fused_param_grads_equal_autograd_accumulation(ops, mode):
+    """ops.fused_param_grads: a generator reached through TWO graphs in one backward call (as inside util_notebook.py:664 and
+    :689) -- the weight-gradient kernels add the second contribution in their own epilogue (slab reduce with beta = 1,
+    central-biasing records with the accumulate flag) instead of autograd's AccumulateGrad input buffer doing it with one
+    elementwise launch per parameter.  Same operands, same single addition: every parameter gradient bit-identical; a
+    post-accumulate-grad hook still fires once per parameter; a gradient already in ``p.grad`` is added to, as AccumulateGrad would."""
+    from srgan_amd import model
+    torch.manual_seed(5)
+    G = model.SingleGenerator(3, 64, 2, 2, 2, "instance", num_con=12).cuda()      # full width, two residual blocks
+    x1, x2 = rnd(2, 3, 128, 128, seed=1).cuda(), rnd(3, 3, 128, 128, seed=2).cuda()
+    c1, c2 = rnd(2, 12, seed=3).cuda(), rnd(3, 12, seed=4).cuda()
+    fired = []
+    handles = [p.register_post_accumulate_grad_hook(lambda p_: fired.append(id(p_))) for p in G.parameters()]
+    ops.set_compute_dtype(mode)
+    try:
+        out = {}
+        for fused in (False, True):
+            for p in G.parameters():
+                p.grad = None
+            fired.clear()
+            ops.invalidate_packed()
+            with ops.pack_cache():
+                y1, y2 = G(x1, c1), G(x2, c2)
+                loss = y1.square().mean() + (y2 * 0.5).abs().mean()
+                with ops.fused_param_grads(fused):
+                    loss.backward(retain_graph=True)
+                first = {n: p.grad.clone() for n, p in G.named_parameters()}
+                assert sorted(fired) == sorted(id(p) for p in G.parameters())          # once per parameter
+                with ops.fused_param_grads(fused):
+                    y1.mean().backward()          # a second backward call onto existing .grad tensors
+            out[fused] = (first, {n: p.grad.clone() for n, p in G.named_parameters()})
+    finally:
+        ops.set_compute_dtype("fp32")
+        ops.invalidate_packed()
+        for h in handles:
+            h.remove()
+    for stage in (0, 1):
+        for n in out[False][stage]:
+            assert torch.equal(out[False][stage][n], out[True][stage][n]), (stage, n)
