@@ -516,7 +516,7 @@ def main():
                        "execution": ("eager launches (hipGraph recording FAILED on some rank: all ranks fell back)" if graph_fallback else
                                      "eager launches" if not graphed else "hipGraph replay of the captured step" if world == 1 else
                                      f"hipGraph segments replayed with the {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} "
-                                     "collectives issued eagerly between them"),
+                                     "all-reduces started on the communication stream between them (running under the next segment)"),
                        "gflop_per_image_algorithmic": gflop_img,
                        "step_tflops_algorithmic": round(value * (gflop_img or 0) / 1e3, 2),
                        "losses_first_step_vs_oracle": check,

@@ -251,6 +251,24 @@ int srgan_l1_mean(const float* a, const float* b, long long n, float weight, flo
 int srgan_latent_losses(const float* mu, int B, int d, float n_batch, const float* hist_target, int bins,
                         float range_max, float sigma, float w_bkl, float w_corr, float w_hist,
                         float* vals, float* dmu, float* corr_out /* [d*d] Pearson matrix or NULL */, void* stream);
+/* Every loss of ONE discriminator evaluation in one launch (util.py:457-468 as used by util_notebook.py:582-590 and :622-624):
+ * per scale s an LSGAN map o[s] = [rows][per_row[s]] and class logits z[s] = [rows][n_class] (z / dz may be NULL: no class
+ * head).  Rows [0, rows_first) are compared with the constant t_first and carry the softmax + class-MSE loss against label[];
+ * rows [rows_first, rows) (the translated half of a real | fake batch; may be empty) with t_rest.
+ * vals[4] = {lsgan_first, class, lsgan_rest, total}, each the mean over scales of the per-scale nn.MSELoss,
+ * total = lsgan_first + w_class * class + lsgan_rest; d_o[s] / dz[s] = d total / d o[s], z[s] (zero rows where unused).
+ * o, per_row, z, d_o, dz are HOST arrays of n_scales (<= 4) entries. */
+int srgan_d_losses(const float* const* o, const long long* per_row, const float* const* z, int n_scales, int rows,
+                   int rows_first, int n_class, const long long* label, float t_first, float t_rest, float w_class,
+                   float* vals, float* const* d_o, float* const* dz, void* stream);
+/* out[0] = sum_i w[i] * x[i][0] over n <= 16 device scalars (x, w: host arrays) -- the weighted sum of a phase's loss terms
+ * (util_notebook.py:585, :626-662, :677-687) in one launch; srgan_lincomb_bwd: dx[i] = w[i] * g[0]. */
+int srgan_lincomb(const float* const* x, const float* w, int n, float* out, void* stream);
+int srgan_lincomb_bwd(const float* w, int n, const float* g, float* dx, void* stream);
+/* conventional KL term of the encoder (util_notebook.py:630-634; SingleGAN: :302): weight * -0.5 * sum(1 + logvar - mu^2 -
+ * exp(logvar)) over all n = B*ndim values, with dmu / dlogvar (either may be NULL) in the same launch */
+int srgan_kl_normal(const float* mu, const float* logvar, long long n, float weight, float* loss, float* dmu,
+                    float* dlogvar, void* stream);
 /* generic nn.MSELoss(a, b) * weight with both gradients (get_domainloss_D on probabilities, util.py:464-468) */
 int srgan_mse_pair(const float* a, const float* b, long long n, float weight, float* loss, float* da, float* db,
                    void* stream);

@@ -731,7 +731,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
 // variant 1, F(2x2,3x3):  U = G g G^T;  kind 0 (forward): g = w[n][c][ky][kx];  kind 1 (input gradient): g = w[c][n][2-ky][2-kx]
 // variant 2, F(3x3,2x2):  U = A g A^T;  kind 0 (4x4 stride-2 conv): reduce index k = (input phase pq, c),
 //   g[a][b] = w[n][c][2a+p][2b+q];  kind 1 (its transpose): one image per OUTPUT phase rs, g[a][b] = w[c][n][3-2a-r][3-2b-s]
-__global__ void wino_pack_kernel(WinoPackParams p) {
+__global__ __launch_bounds__(256) void wino_pack_kernel(WinoPackParams p) {
   const long long total = wino_pack_total(p);
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x)

@@ -56,6 +56,96 @@ __global__ __launch_bounds__(256) void softmax_mse_kernel(const float* z, const 
   if (threadIdx.x == 0) loss[0] = weight * s / (float)(B * nc);
 }
 
+// All losses of one discriminator evaluation in ONE launch (K12 of SURVEY.md 2.2: util.py:457-468 applied by
+// util_notebook.py:582-590 and :622-624): per scale s an LSGAN map o_s [rows][per_s] and class logits z_s [rows][nc]; the
+// first `rows_first` rows are compared with the constant t_first and carry the class loss against `label`, the remaining rows
+// (the translated half of a real | fake batch) with t_rest.  vals = {lsgan_first, class, lsgan_rest, total}, each the MEAN over
+// scales of the per-scale nn.MSELoss; total = lsgan_first + w_class * class + lsgan_rest; d_o_s / dz_s = d total / d (.).
+struct DLossParams {
+  const float* o[4];
+  const float* z[4];
+  float* d_o[4];
+  float* dz[4];
+  long long per[4];
+  const long long* label;
+  float* vals;
+  int n_scales, rows, rows_first, nc;
+  float t_first, t_rest, w_class;
+};
+
+__global__ __launch_bounds__(256) void d_losses_kernel(DLossParams p) {
+  __shared__ float red[16];
+  const float ws = 1.f / (float)p.n_scales;
+  float first = 0.f, rest = 0.f, cls = 0.f;
+  for (int s = 0; s < p.n_scales; ++s) {
+    const long long n1 = (long long)p.rows_first * p.per[s], n2 = (long long)(p.rows - p.rows_first) * p.per[s];
+    const float g1 = n1 > 0 ? 2.f * ws / (float)n1 : 0.f, g2 = n2 > 0 ? 2.f * ws / (float)n2 : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (long long i = threadIdx.x; i < n1 + n2; i += blockDim.x) {
+      const bool f = i < n1;
+      const float d = p.o[s][i] - (f ? p.t_first : p.t_rest);
+      if (f) s1 += d * d; else s2 += d * d;
+      p.d_o[s][i] = (f ? g1 : g2) * d;
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (n1 > 0) first += ws * s1 / (float)n1;
+    if (n2 > 0) rest += ws * s2 / (float)n2;
+    if (p.z[s]) {
+      const int nc = p.nc;
+      const float gs = 2.f * ws * p.w_class / (float)(p.rows_first * nc);
+      float sc = 0.f;
+      for (int b = threadIdx.x; b < p.rows; b += blockDim.x) {
+        if (b >= p.rows_first) {
+          for (int j = 0; j < nc; ++j) p.dz[s][b * nc + j] = 0.f;
+          continue;
+        }
+        float qq[16], dq[16];
+        float mx = -INFINITY;
+        for (int j = 0; j < nc; ++j) mx = fmaxf(mx, p.z[s][b * nc + j]);
+        float den = 0.f;
+        for (int j = 0; j < nc; ++j) { qq[j] = expf(p.z[s][b * nc + j] - mx); den += qq[j]; }
+        const int lab = (int)p.label[b];
+        float dot = 0.f;
+        for (int j = 0; j < nc; ++j) {
+          qq[j] /= den;
+          const float d = qq[j] - (j == lab ? 1.f : 0.f);
+          sc += d * d;
+          dq[j] = gs * d;
+          dot += qq[j] * dq[j];
+        }
+        for (int j = 0; j < nc; ++j) p.dz[s][b * nc + j] = qq[j] * (dq[j] - dot);
+      }
+      sc = block_sum(sc, red);
+      cls += ws * sc / (float)(p.rows_first * nc);
+    }
+  }
+  if (threadIdx.x == 0) {
+    p.vals[0] = first;
+    p.vals[1] = cls;
+    p.vals[2] = rest;
+    p.vals[3] = first + cls * p.w_class + rest;
+  }
+}
+
+// out = sum_i w_i * x_i over n <= 16 scalars living anywhere on the device (the loss terms of a phase); dx_i = w_i * g in the
+// backward (one launch each way instead of one per python-level `+` / `*`).
+struct LincombParams {
+  const float* x[16];
+  float w[16];
+  int n;
+};
+__global__ void lincomb_fwd_kernel(LincombParams p, float* out) {
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < p.n; ++i) s += p.w[i] * p.x[i][0];
+    out[0] = s;
+  }
+}
+__global__ void lincomb_bwd_kernel(LincombParams p, const float* g, float* dx /* [n] */) {
+  if ((int)threadIdx.x < p.n) dx[threadIdx.x] = p.w[threadIdx.x] * g[0];
+}
+
 // nn.CrossEntropyLoss (mean): loss = mean_b( logsumexp(z_b) - z_b[label_b] ), dz = (softmax(z) - onehot) * weight / B
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* z, const long long* label, int B, int nc,
                                                            float weight, float* loss, float* dz) {
@@ -112,6 +202,23 @@ __global__ __launch_bounds__(256) void mse_pair_kernel(const float* a, const flo
   }
   s = block_sum(s, red);
   if (threadIdx.x == 0) loss[0] = weight * s / (float)n;
+}
+
+// Conventional KL of N(mu, exp(logvar)) against N(0, I), a SUM over all rows and dimensions (util_notebook.py:630-634, :302):
+//   L = -0.5 * sum(1 + logvar - mu^2 - exp(logvar));  dL/dmu = mu;  dL/dlogvar = 0.5 * (exp(logvar) - 1)   (times weight)
+// value + both gradients in one launch; single block (B x ndim values)
+__global__ __launch_bounds__(256) void kl_normal_kernel(const float* mu, const float* logvar, long long n, float weight,
+                                                        float* loss, float* dmu, float* dlogvar) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float m = mu[i], lv = logvar[i], ev = expf(lv);
+    s += 1.f + lv - m * m - ev;
+    if (dmu) dmu[i] = weight * m;
+    if (dlogvar) dlogvar[i] = weight * 0.5f * (ev - 1.f);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) loss[0] = -0.5f * weight * s;
 }
 
 // GaussianHistogram.forward (util.py:532-537) for a long 1-D sample: part[block][bin], then summed.
@@ -346,6 +453,50 @@ extern "C" int srgan_mse_pair(const float* a, const float* b, long long n, float
   SRGAN_REQUIRE(a && b && loss && n > 0, "mse_pair: bad argument");
   hipLaunchKernelGGL(mse_pair_kernel, dim3(1), dim3(256), 0, as_stream(stream), a, b, n, weight, loss, da, db);
   return check_launch("mse_pair_kernel");
+}
+
+extern "C" int srgan_d_losses(const float* const* o, const long long* per_row, const float* const* z, int n_scales, int rows,
+                              int rows_first, int n_class, const long long* label, float t_first, float t_rest, float w_class,
+                              float* vals, float* const* d_o, float* const* dz, void* stream) {
+  SRGAN_REQUIRE(o && per_row && d_o && vals && n_scales >= 1 && n_scales <= 4, "d_losses: 1..4 scales");
+  SRGAN_REQUIRE(rows > 0 && rows_first >= 0 && rows_first <= rows, "d_losses: bad row split");
+  DLossParams p{};
+  p.n_scales = n_scales; p.rows = rows; p.rows_first = rows_first; p.nc = n_class;
+  p.t_first = t_first; p.t_rest = t_rest; p.w_class = w_class; p.label = label; p.vals = vals;
+  for (int s = 0; s < n_scales; ++s) {
+    SRGAN_REQUIRE(o[s] && d_o[s] && per_row[s] > 0, "d_losses: null scale");
+    p.o[s] = o[s]; p.d_o[s] = d_o[s]; p.per[s] = per_row[s];
+    p.z[s] = z ? z[s] : nullptr;
+    p.dz[s] = dz ? dz[s] : nullptr;
+    SRGAN_REQUIRE(!p.z[s] || (p.dz[s] && label && rows_first > 0 && n_class > 0 && n_class <= 16), "d_losses: class head needs dz, labels, <= 16 classes");
+  }
+  hipLaunchKernelGGL(d_losses_kernel, dim3(1), dim3(256), 0, as_stream(stream), p);
+  return check_launch("d_losses_kernel");
+}
+
+extern "C" int srgan_lincomb(const float* const* x, const float* w, int n, float* out, void* stream) {
+  SRGAN_REQUIRE(x && w && out && n >= 1 && n <= 16, "lincomb: 1..16 terms");
+  LincombParams p{};
+  p.n = n;
+  for (int i = 0; i < n; ++i) { SRGAN_REQUIRE(x[i], "lincomb: null term"); p.x[i] = x[i]; p.w[i] = w[i]; }
+  hipLaunchKernelGGL(lincomb_fwd_kernel, dim3(1), dim3(64), 0, as_stream(stream), p, out);
+  return check_launch("lincomb_fwd_kernel");
+}
+
+extern "C" int srgan_lincomb_bwd(const float* w, int n, const float* g, float* dx, void* stream) {
+  SRGAN_REQUIRE(w && g && dx && n >= 1 && n <= 16, "lincomb_bwd: 1..16 terms");
+  LincombParams p{};
+  p.n = n;
+  for (int i = 0; i < n; ++i) p.w[i] = w[i];
+  hipLaunchKernelGGL(lincomb_bwd_kernel, dim3(1), dim3(64), 0, as_stream(stream), p, g, dx);
+  return check_launch("lincomb_bwd_kernel");
+}
+
+extern "C" int srgan_kl_normal(const float* mu, const float* logvar, long long n, float weight, float* loss, float* dmu,
+                               float* dlogvar, void* stream) {
+  SRGAN_REQUIRE(mu && logvar && loss && n > 0, "kl_normal: bad argument");
+  hipLaunchKernelGGL(kl_normal_kernel, dim3(1), dim3(256), 0, as_stream(stream), mu, logvar, n, weight, loss, dmu, dlogvar);
+  return check_launch("kl_normal_kernel");
 }
 
 extern "C" size_t srgan_soft_histogram_workspace(long long n, int bins) {

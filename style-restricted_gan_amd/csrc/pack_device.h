@@ -108,6 +108,71 @@ __device__ __forceinline__ void wino43_pack_item(const WinoPackParams& p, long l
   for (int k = 0; k < 36; ++k) *reinterpret_cast<f32x4*>(out + k * 256) = u[k];
 }
 
+// The same items for one WORKGROUP of 256 threads = 256 consecutive items = 32 couts x 32 reduce channels of one cout tile (four
+// consecutive chunks): with dense OIHW weights that block's source is 32 rows of 288 contiguous floats (kind 0: row = cout, the
+// 32 channels x 9 taps behind it; kind 1: row = reduce channel (the O index of w), the 32 couts (its I index) x 9 taps), so it is
+// read with nine coalesced 16-byte loads per thread into LDS (row stride 289: the item's reads are conflict-free) instead of 36
+// dword loads per thread that each touch 64 different lines; results leave per filter row (24 registers in flight, no spill).
+// Measured on the generator's repack (24 F(4x4,3x3) images per optimiser step): see DESIGN.md section 4.
+constexpr int WP43_ROW = 289;
+__device__ __host__ __forceinline__ bool wino43_pack_block_ok(const WinoPackParams& p) {
+  return p.variant == 3 && p.sW == 1 && p.sH == 3 && p.sI == 9 && p.sO % 4 == 0 && p.nchunk % 4 == 0 && p.N % 32 == 0 && p.C % 32 == 0 &&
+         (reinterpret_cast<unsigned long long>(p.w) & 15) == 0;
+}
+__device__ __forceinline__ void wino43_pack_block(const WinoPackParams& p, long long base, float* tile /* [32][WP43_ROW] */) {
+  const int t = threadIdx.x;
+  long long r = base / 64;                              // (chunk, ntile) of the block's first item
+  const int chunk0 = (int)(r % p.nchunk);
+  const int ntile = (int)(r / p.nchunk);
+  const int n0 = ntile * 32, c0 = chunk0 * WP_WC;
+  __syncthreads();                                      // the previous block of this workgroup is done with the tile
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int f = t + 256 * i, row = f / 72, q = f - row * 72;
+    const float* src = p.kind == 0 ? p.w + (long long)(n0 + row) * p.sO + c0 * 9 : p.w + (long long)(c0 + row) * p.sO + n0 * 9;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + q * 4);
+    float* dst = tile + row * WP43_ROW + q * 4;
+    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+  }
+  __syncthreads();
+  const int nl = t & 31, lh = (t >> 5) & 1, cl = t >> 6;          // item = (cout nl, channel quad lh, chunk chunk0 + cl)
+  float h[4][6][3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = cl * WP_WC + lh * 4 + j;                         // channel inside the block
+    const float* g = p.kind == 0 ? tile + nl * WP43_ROW + c * 9 : tile + c * WP43_ROW + nl * 9;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      // kind 1: the filter rotated by 180 degrees
+      const float a = p.kind == 0 ? g[0 * 3 + kx] : g[8 - (0 * 3 + kx)], b = p.kind == 0 ? g[1 * 3 + kx] : g[8 - (1 * 3 + kx)],
+                  cc = p.kind == 0 ? g[2 * 3 + kx] : g[8 - (2 * 3 + kx)];
+      h[j][0][kx] = 0.25f * a;
+      h[j][1][kx] = (-1.f / 6.f) * (a + b + cc);
+      h[j][2][kx] = (-1.f / 6.f) * (a - b + cc);
+      h[j][3][kx] = (1.f / 24.f) * a + (1.f / 12.f) * b + (1.f / 6.f) * cc;
+      h[j][4][kx] = (1.f / 24.f) * a - (1.f / 12.f) * b + (1.f / 6.f) * cc;
+      h[j][5][kx] = cc;
+    }
+  }
+  float* out = p.dst + (((size_t)ntile * p.nchunk + chunk0 + cl) * 36) * 256 + lh * 128 + nl * 4;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    f32x4 u[6];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = h[j][a][0], y = h[j][a][1], z = h[j][a][2];
+      u[0][j] = 0.25f * x;
+      u[1][j] = (-1.f / 6.f) * (x + y + z);
+      u[2][j] = (-1.f / 6.f) * (x - y + z);
+      u[3][j] = (1.f / 24.f) * x + (1.f / 12.f) * y + (1.f / 6.f) * z;
+      u[4][j] = (1.f / 24.f) * x - (1.f / 12.f) * y + (1.f / 6.f) * z;
+      u[5][j] = z;
+    }
+#pragma unroll
+    for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x4*>(out + (a * 6 + b) * 256) = u[b];
+  }
+}
+
 // variant 4 (conv_halo16.hip, bf16 mode -- no transform): bf16 [64-channel quarter][tap][32-chunk of the quarter][N][32], rounded
 // to nearest even (K tile kt = (quarter * 9 + tap) * 2 + chunk & 1).
 // kind 0: B[n][k] = w[n][k][ky][kx];  kind 1: B[n][k] = w[k][n][2-ky][2-kx].

@@ -86,6 +86,10 @@ SIGNATURES = {
     "srgan_l1_mean": (c_int, [P, P, c_longlong, c_float, P, P, P, P, c_size_t, P]),
     "srgan_latent_losses": (c_int, [P, c_int, c_int, c_float, P, c_int, c_float, c_float, c_float, c_float, c_float, P, P, P, P]),
     "srgan_mse_pair": (c_int, [P, P, c_longlong, c_float, P, P, P, P]),
+    "srgan_kl_normal": (c_int, [P, P, c_longlong, c_float, P, P, P, P]),
+    "srgan_d_losses": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, c_float, c_float, c_float, P, P, P, P]),
+    "srgan_lincomb": (c_int, [P, P, c_int, P, P]),
+    "srgan_lincomb_bwd": (c_int, [P, c_int, P, P, P]),
     "srgan_soft_histogram_workspace": (c_size_t, [c_longlong, c_int]),
     "srgan_soft_histogram_fwd": (c_int, [P, c_longlong, c_int, c_float, c_float, c_float, P, P, c_size_t, P]),
     "srgan_soft_histogram_bwd": (c_int, [P, P, c_longlong, c_int, c_float, c_float, c_float, P, P]),

@@ -106,6 +106,16 @@ def set_recorder(rec):
     _recorder = rec
 
 
+def _all_gather_into(out, src):
+    """Rank-ordered rows of every rank's ``src`` into ONE preallocated tensor (``all_gather_into_tensor``: RCCL writes the
+    destination directly; a list of per-rank views may be staged through an internal flat buffer and copied out).  Backends
+    without the call get the list form on views of ``out`` -- same result."""
+    try:
+        dist.all_gather_into_tensor(out, src)
+    except (RuntimeError, NotImplementedError):
+        dist.all_gather(list(out.chunk(dist.get_world_size(), 0)), src)
+
+
 class _AllGatherRows(torch.autograd.Function):
     """Concatenate each rank's [B_local, d] rows in rank order; backward hands every rank the rows of the
     incoming gradient that belong to it (the gathered loss is evaluated redundantly on every rank)."""
@@ -114,15 +124,14 @@ class _AllGatherRows(torch.autograd.Function):
     def forward(ctx, x):
         ws = dist.get_world_size()
         ctx.rows, ctx.rank = x.shape[0], dist.get_rank()
+        src = x.contiguous()
+        out = torch.empty((ws * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         if _recorder is not None:
-            src = x.contiguous()
-            out = torch.empty((ws * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-            parts = list(out.chunk(ws, 0))
-            _recorder.cut(lambda: dist.all_gather(parts, src))
+            launch_pending()
+            _recorder.cut(_Comm("all_gather", lambda: _all_gather_into(out, src)))
             return out
-        parts = [torch.empty_like(x) for _ in range(ws)]
-        dist.all_gather(parts, x.contiguous())
-        return torch.cat(parts, 0)
+        _all_gather_into(out, src)
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -191,6 +200,7 @@ class GradReducer:
         self._pending = None
         self._comm_stream = None
         self._armed = False
+        self._waited = False           # recording: the wait for this reducer's buckets already rides in the cut that started them
         self._buckets_cache = [_Bucket(b) for b in self._buckets()]
         self._where = {}
         for b, bucket in enumerate(self._buckets_cache):
@@ -260,11 +270,11 @@ class GradReducer:
                 torch._foreach_zero_(holes)
         avg = _backend_has_avg()
         if _recorder is not None:
-            # recording: the flatten above is part of the graph segment; the all-reduce is issued between segments (finish())
-            _recorder.pending.append((bk.flat, avg))
+            # recording: the flatten above is part of the graph segment; the all-reduce is issued between segments, on the
+            # communication stream (launch_pending), and awaited at another cut (finish())
+            _recorder.pending.append((bk, avg))
         elif on_gpu:
-            if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(device=bk.flat.device)
+            self._comm_stream = comm_stream(bk.flat.device)
             bk.ready.record(torch.cuda.current_stream(bk.flat.device))
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(bk.ready)
@@ -297,11 +307,11 @@ class GradReducer:
         work, armed = self._pending
         self._pending = None
         recording = _recorder is not None
-        if recording and _recorder.pending:
-            # every bucket flattened since the last cut (this reducer's and those of reducers started with it) goes out here,
-            # in the order it was flattened -- the same on every rank
-            flats, _recorder.pending = list(_recorder.pending), []
-            _recorder.cut(lambda: _all_reduce_avg(flats))
+        if recording:
+            launch_pending(then_wait=self)      # (a no-op when the caller already started the collectives to put work under them)
+            if not self._waited:
+                _recorder.cut(_Comm("wait", lambda: _wait_done(work)))
+            self._waited = False
         for bk in work:
             if bk.done is not None and not recording:
                 torch.cuda.current_stream(bk.flat.device).wait_event(bk.done)
@@ -315,13 +325,78 @@ class GradReducer:
         self.finish()
 
 
-def _all_reduce_avg(flats):
-    """Eager in-place average of flat buckets on the CURRENT stream (between two graph segments of a recorded step)."""
+_comm_streams = {}
+
+
+def comm_stream(device):
+    """The ONE communication stream of a device: every reducer's all-reduces are enqueued on it, in program order -- the same
+    order on every rank."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _comm_streams.get(key)
+    if st is None:
+        st = _comm_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+class _Comm:
+    """A host callable between two graph segments of a recorded step (``trainer._Recording``), with a name for the trace."""
+    __slots__ = ("kind", "fn")
+
+    def __init__(self, kind, fn):
+        self.kind, self.fn = kind, fn
+
+    def __call__(self):
+        self.fn()
+
+
+def _all_reduce_async(items):
+    """In-place average of flat buckets, issued on the communication stream behind everything the compute stream has been
+    given so far; returns at once -- the graph segments launched next run UNDER the collectives (``_wait_done`` joins)."""
     ws = dist.get_world_size()
-    for flat, avg in flats:
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
-        if not avg:
-            flat.mul_(1.0 / ws)
+    bk0 = items[0][0]
+    if not bk0.flat.is_cuda:
+        for bk, avg in items:
+            dist.all_reduce(bk.flat, op=dist.ReduceOp.SUM)
+            bk.flat.mul_(1.0 / ws)
+        return
+    dev = bk0.flat.device
+    comm = comm_stream(dev)
+    bk0.ready.record(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(comm):
+        comm.wait_event(bk0.ready)
+        for bk, avg in items:
+            dist.all_reduce(bk.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
+            if not avg:
+                bk.flat.mul_(1.0 / ws)
+            bk.done.record(comm)
+
+
+def _wait_done(buckets):
+    for bk in buckets:
+        if bk.done is not None:
+            torch.cuda.current_stream(bk.flat.device).wait_event(bk.done)
+
+
+def launch_pending(then_wait=None):
+    """Recorded data-parallel step: end the graph segment here and, on every replay, start the all-reduce of every bucket
+    flattened since the last cut on the communication stream.  What the caller records next runs under those collectives until
+    the owning reducer's ``finish()`` (another cut: the compute stream waits for the ``done`` events).  ``then_wait``: a
+    reducer whose result is needed at once -- its wait joins this cut instead of making one of its own (an empty graph
+    segment between the two is avoided); the other reducers' buckets stay in flight.  Eager step: nothing to do (the buckets
+    went out from the gradient hooks / ``start()``)."""
+    rec = _recorder
+    if rec is None or not rec.pending:
+        return
+    items, rec.pending = list(rec.pending), []
+    joined = []
+    if then_wait is not None and then_wait._pending is not None:
+        joined = list(then_wait._pending[0])
+        then_wait._waited = True
+
+    def comm():
+        _all_reduce_async(items)
+        _wait_done(joined)
+    rec.cut(_Comm("all_reduce", comm))
 
 
 _control = None

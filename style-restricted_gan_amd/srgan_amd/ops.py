@@ -416,9 +416,12 @@ def _run_conv_wgrad(desc, x, dy, dw, dbias, v_image=None):
 # weight-gradient kernels of this module write a parameter's FIRST contribution of the pass into a fresh buffer and ADD the
 # later ones in their own epilogue (split-K slab reduce with beta = 1, central-biasing records with the accumulate flag); the
 # Functions return no gradient for such a parameter, and when the scope closes ``p.grad`` is bound to the buffer (added to an
-# existing ``p.grad``, as AccumulateGrad would) and the parameter's post-accumulate-grad hooks are called.  Same operands, same
-# single rounding per addition as the engine's ``a += b``: bit-identical results.  Opt-in (the trainer wraps its backward calls):
-# plain ``.backward()`` / ``autograd.grad`` on the modules keeps the ordinary path.
+# existing ``p.grad``, as AccumulateGrad would).  Same operands, same single rounding per addition as the engine's ``a += b``:
+# bit-identical results.  A parameter's post-accumulate-grad hooks still fire once per backward call -- the engine runs the
+# AccumulateGrad node with an undefined gradient -- but DURING the pass, before ``p.grad`` is bound: fine for hooks that count
+# (``dp.GradReducer`` while a step is recorded), wrong for hooks that read the gradient, which is why the eager data-parallel
+# step (buckets sent from the hooks) keeps the ordinary path.  Opt-in (the trainer wraps its backward calls): plain
+# ``.backward()`` / ``autograd.grad`` on the modules are untouched.
 _grad_sink = None
 
 
@@ -442,8 +445,6 @@ class fused_param_grads:
                         p.grad = buf
                     else:
                         p.grad.add_(buf)
-                    for hook in (getattr(p, "_post_accumulate_grad_hooks", None) or {}).values():
-                        hook(p)
         return False
 
 
@@ -1447,6 +1448,109 @@ class _MsePairFn(Function):
 def mse_pair(a, b, weight=1.0):
     """weight * mean((a - b)^2) for two small tensors of equal shape."""
     return _MsePairFn.apply(a, b, weight)
+
+
+class _DLossesFn(Function):
+    @staticmethod
+    def forward(ctx, label, rows_first, t_first, t_rest, w_class, n_scales, *tensors):
+        outs, logits = tensors[:n_scales], tensors[n_scales:]
+        lib = _lib.load()
+        dev = outs[0].device
+        rows = outs[0].shape[0]
+        o = [t if (t.is_contiguous() or is_nhwc_dense(t)) else t.contiguous() for t in outs]
+        for t in o:
+            _require_gpu(t, "d_losses")
+            if t.dim() == 4 and t.shape[1] != 1:
+                raise _lib.SrganHipError("d_losses: LSGAN maps must have one channel")
+        z = [_dense2d(t) for t in logits]
+        nc = z[0].shape[1] if z else 0
+        d_o = [torch.empty_like(t) for t in o]
+        dz = [torch.empty_like(t) for t in z]
+        vals = torch.empty(4, dtype=torch.float32, device=dev)
+        S = n_scales
+        arr = ctypes.c_void_p * S
+        per = (ctypes.c_longlong * S)(*[t.numel() // rows for t in o])
+        if label is not None:
+            label = label.to(device=dev, dtype=torch.int64).contiguous()
+        _lib.check(lib.srgan_d_losses(arr(*[t.data_ptr() for t in o]), per, arr(*[t.data_ptr() for t in z]) if z else None, S, rows,
+                                      int(rows_first), int(nc), _ptr(label), float(t_first), float(t_rest), float(w_class),
+                                      _ptr(vals), arr(*[t.data_ptr() for t in d_o]), arr(*[t.data_ptr() for t in dz]) if z else None,
+                                      _stream()), "d_losses")
+        ctx.save_for_backward(*d_o, *dz)
+        total, parts = vals[3], vals[:3]
+        ctx.mark_non_differentiable(parts)
+        return total, parts
+
+    @staticmethod
+    def backward(ctx, g, _gp):
+        grads = torch._foreach_mul(list(ctx.saved_tensors), g)      # one multi-tensor launch
+        return (None,) * 6 + tuple(grads)
+
+
+def d_losses(outs, logits, label, rows_first, t_first, t_rest, w_class):
+    """Every loss of one discriminator evaluation in one launch -> (total, tensor([lsgan_first, class, lsgan_rest])):
+    the first ``rows_first`` rows against ``t_first`` (+ softmax / class-MSE against ``label``), the rest against ``t_rest``;
+    total = lsgan_first + w_class * class + lsgan_rest, each term the mean over the scales (util.py:457-468)."""
+    logits = list(logits) if logits else []
+    return _DLossesFn.apply(label, rows_first, t_first, t_rest, w_class, len(outs), *outs, *logits)
+
+
+class _LincombFn(Function):
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        n = len(terms)
+        dev = terms[0].device
+        terms = [t.reshape(()) for t in terms]
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        w = (ctypes.c_float * n)(*[float(v) for v in weights])
+        _lib.check(_lib.load().srgan_lincomb((ctypes.c_void_p * n)(*[t.data_ptr() for t in terms]), w, n, _ptr(out), _stream()),
+                   "lincomb")
+        ctx.weights, ctx.dev = [float(v) for v in weights], dev
+        ctx.keep = terms                  # the launch reads them asynchronously
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n = len(ctx.weights)
+        dx = torch.empty(n, dtype=torch.float32, device=ctx.dev)
+        w = (ctypes.c_float * n)(*ctx.weights)
+        _lib.check(_lib.load().srgan_lincomb_bwd(w, n, _ptr(g.contiguous()), _ptr(dx), _stream()), "lincomb_bwd")
+        return (None,) + tuple(dx[i] if ctx.needs_input_grad[1 + i] else None for i in range(n))
+
+
+def lincomb(pairs):
+    """sum of weight * scalar over [(0-dim device tensor, python float), ...] (<= 16 terms) in one launch; differentiable."""
+    pairs = [(t, w) for t, w in pairs if t is not None]
+    if len(pairs) > 16:
+        return lincomb([(lincomb(pairs[:16]), 1.0)] + pairs[16:])
+    for t, _ in pairs:
+        _require_gpu(t, "lincomb")
+    return _LincombFn.apply([w for _, w in pairs], *[t for t, _ in pairs])
+
+
+class _KlNormalFn(Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, weight):
+        _require_gpu(mu, "kl_normal")
+        mu, logvar = mu.contiguous(), logvar.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=mu.device)
+        dmu = torch.empty_like(mu) if ctx.needs_input_grad[0] else None
+        dlv = torch.empty_like(logvar) if ctx.needs_input_grad[1] else None
+        _lib.check(_lib.load().srgan_kl_normal(_ptr(mu), _ptr(logvar), mu.numel(), float(weight), _ptr(loss), _ptr(dmu), _ptr(dlv),
+                                               _stream()), "kl_normal")
+        ctx.save_for_backward(dmu, dlv)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dmu, dlv = ctx.saved_tensors
+        return (dmu * g if dmu is not None else None, dlv * g if dlv is not None else None, None)
+
+
+def kl_normal(mu, logvar, weight=1.0):
+    """weight * -0.5 * sum(1 + logvar - mu^2 - exp(logvar)): the conventional KL term (util_notebook.py:630-634), value and
+    both gradients in one launch."""
+    return _KlNormalFn.apply(mu, logvar, weight)
 
 
 class _SoftHistFn(Function):

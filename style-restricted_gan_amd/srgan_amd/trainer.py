@@ -235,10 +235,12 @@ class SRGAN_training():
         return target_image, info
 
     # ------------------------------------------------------------------------------------------
-    def update_D(self, _fake=None, _next_fake=None):
+    def update_D(self, _fake=None, _next_fake=None, _defer=False):
         """One discriminator update (util_notebook.py:563-594); returns errD.
-        ``_fake`` / ``_next_fake`` let UnrolledUpdate hand in a pre-computed translation and overlap the next
-        one with this update's gradient all-reduce."""
+        Data parallel: ``_fake`` hands in a pre-computed translation, ``_next_fake`` is work to run UNDER this update's gradient
+        all-reduce (the next translation: G does not change during the discriminator loop), ``_defer`` leaves the wait for the
+        all-reduce and the optimiser step to ``_finish_D()`` so that the caller can put more independent work in between."""
+        self._finish_D()
         self.D.zero_grad()
         if _fake is None:
             self.target_image, self.c_rand = self.G_transformation("target", self.source_image, False)
@@ -249,28 +251,35 @@ class SRGAN_training():
             # real and fake halves through D as ONE batch (per-sample network: exact; 2x the rows per GEMM launch)
             B = self.source_image.shape[0]
             outs, logits = dp.unwrap(self.D).forward_logits(ops.cat_batch([self.source_image, self.target_image.detach()]))
-            errD_real = get_loss_D([o[:B] for o in outs], 1., self.criterion, self.device)
-            errD_fake = get_loss_D([o[B:] for o in outs], 0., self.criterion, self.device)
-            lab, w = self._label_dev("source"), 1.0 / len(logits)
-            errD_class = 0.0
-            for z in logits:
-                errD_class = errD_class + ops.softmax_mse(z[:B], lab, w)[0]
+            # LSGAN(real, 1) + class MSE * lbd + LSGAN(fake, 0) over both scales, values and gradients: one launch
+            errD, parts = ops.d_losses(outs, logits, self._label_dev("source"), B, 1., 0., self.lbd["class"])
+            errD_real, errD_class, errD_fake = parts[0], parts[1], parts[2]
         else:
             errD_real, errD_class = self._d_losses(self.source_image, 1., "source", True)
             errD_fake, _ = self._d_losses(self.target_image.detach(), 0., None, False)
-        errD = errD_real + errD_class * self.lbd["class"] + errD_fake
+            errD = errD_real + errD_class * self.lbd["class"] + errD_fake
         self._reduce_arm("D", self.optD)
         with ops.fused_param_grads(not dp.hooks_need_live_grads()):
             errD.backward()
-        red = self._reduce_start("D", self.optD)
-        nxt = _next_fake() if _next_fake is not None else None      # optional work to overlap with the all-reduce
-        if red is not None:
-            red.finish()
-        self._step(self.optD)
+        self._d_pending = self._reduce_start("D", self.optD) or True
+        dp.launch_pending()                                         # recorded step: the all-reduces start here ...
+        nxt = _next_fake() if _next_fake is not None else None      # ... and this runs under them
+        if not _defer:
+            self._finish_D()
         self.loss_terms.update(errD_real=errD_real.detach(), errD_class=errD_class.detach(), errD_fake=errD_fake.detach())
         if _next_fake is not None:
             return errD, nxt
         return errD
+
+    def _finish_D(self):
+        """Wait for the discriminator's gradient all-reduce (if any) and take its optimiser step, if an ``update_D`` left them."""
+        red = self.__dict__.get("_d_pending")
+        if red is None:
+            return
+        self._d_pending = None
+        if red is not True:
+            red.finish()
+        self._step(self.optD)
 
     # ------------------------------------------------------------------------------------------
     def update_GandE(self):
@@ -302,12 +311,23 @@ class SRGAN_training():
                 recon_image, identity_image = both[:nb], both[nb:]
             else:
                 recon_image, _ = self.G_transformation("source", self.target_image, True, src, _enc_info=source_enc_info)
+            self._finish_D()                               # (data parallel: the last D update's all-reduce ran under the passes above)
+            fused = self._fused_paths()
+            # loss terms as (device scalar, weight) lists: the optimised sums and the two reported sums are each ONE launch
+            # (ops.lincomb) instead of one launch per python-level `+` / `*`
+            g_terms, e_terms, rep_terms = [], [], []
             with _frozen(list(self.D.parameters())):       # D's weight grads would be discarded
-                errG_dis, errG_class = self._d_losses(self.target_image, 1., "target", True)
+                if fused:
+                    outs, logits = dp.unwrap(self.D).forward_logits(self.target_image)
+                    d_total, parts = ops.d_losses(outs, logits, self._label_dev("target"), self.target_image.shape[0], 1., 0., L["class"])
+                    errG_dis, errG_class = parts[0], parts[1]
+                    g_terms.append((d_total, 1.0))
+                else:
+                    errG_dis, errG_class = self._d_losses(self.target_image, 1., "target", True)
+                    g_terms += [(errG_dis, 1.0), (errG_class, L["class"])]
             errG_cycle = ops.l1_mean(src, recon_image, 1.0)
-            errG = errG_dis + errG_class * L["class"] + errG_cycle * L["cycle"]
-            errE = 0
-            errE_output = errG_cycle * L["cycle"]
+            g_terms.append((errG_cycle, L["cycle"]))
+            rep_terms.append((errG_cycle, L["cycle"]))
             terms = dict(errG_dis=errG_dis, errG_class=errG_class, errG_cycle=errG_cycle)
 
             _, mu, logvar, _, _ = source_enc_info
@@ -315,17 +335,17 @@ class SRGAN_training():
                 # a SUM over the rows of the batch (util_notebook.py:630-634): under data parallelism each rank holds the
                 # sum over ITS rows and the gradient all-reduce averages, so the optimised term is pre-scaled by the world
                 # size (as the batch-statistics losses below); the reported value stays the local sum
-                errE_KL = -0.5 * torch.sum(1 + logvar - mu ** 2 - logvar.exp())
-                errE = errE + errE_KL * (L["KL"] * ws if ws > 1 else L["KL"])
-                errE_output = errE_output + errE_KL * L["KL"]
+                errE_KL = ops.kl_normal(mu, logvar)
+                e_terms.append((errE_KL, L["KL"] * ws if ws > 1 else L["KL"]))
+                rep_terms.append((errE_KL, L["KL"]))
                 terms["errE_KL"] = errE_KL
 
             if L["idt"] > 0:
                 if not pair:
                     identity_image, _ = self.G_transformation("source", src, True, src)
                 errG_idt = ops.l1_mean(src, identity_image, 1.0)
-                errG = errG + errG_idt * L["idt"]
-                errE_output = errE_output + errG_idt * L["idt"]
+                g_terms.append((errG_idt, L["idt"]))
+                rep_terms.append((errG_idt, L["idt"]))
                 terms["errG_idt"] = errG_idt
 
             if L["batch_KL"] > 0:
@@ -336,43 +356,60 @@ class SRGAN_training():
                 total, parts, _ = ops.latent_losses(mu_all, self.n_batch, target, L["batch_KL"], w_corr, w_hist)
                 # every rank evaluates the global-batch loss; its local rows' gradient must be SUMMED over ranks
                 # while the all-reduce averages -> pre-scale by the world size
-                errE = errE + (total * ws if ws > 1 else total)
-                errE_output = errE_output + total
+                e_terms.append((total, float(ws) if ws > 1 else 1.0))
+                rep_terms.append((total, 1.0))
                 terms.update(errE_bKL=parts[0], errE_corr=parts[1], errE_hist=parts[2])
 
-            total_p1 = errG + errE if torch.is_tensor(errE) else errG
+            total_p1 = ops.lincomb(g_terms + e_terms)
+            with torch.no_grad():
+                errG = ops.lincomb(g_terms)
+                errE_output = ops.lincomb(rep_terms)
             self._reduce_arm("G", self.optG)
             self._reduce_arm("E", self.optE)
             # the generator's weights are reached twice in this pass (reconstruction / identity graph and the kept target_image
             # graph): their weight-gradient kernels add the second contribution themselves (ops.fused_param_grads)
             with ops.fused_param_grads(not dp.hooks_need_live_grads()):
                 total_p1.backward(retain_graph=True)     # target_image's graph is needed again in phase 2
-        redG = self._reduce_start("G", self.optG)
+        # Data parallel: E's buckets go out first, G's behind them on the same communication stream; E's optimiser step, its
+        # repack and phase 2's E(source) forward (which needs the new E, not the new G) then run UNDER G's all-reduce.  The two
+        # Adam steps touch disjoint parameters, so their order does not matter.
         redE = self._reduce_start("E", self.optE)
+        redG = self._reduce_start("G", self.optG)
+        dp.launch_pending(then_wait=redE)
+        if redE is not None:
+            redE.finish()
+        self._step(self.optE)
+        do_idt_reg = L["idt_reg"] * L["idt"] > 0
+        early_info = None
+        if redG is not None and do_idt_reg and self._fused_paths():
+            nb = src.shape[0]
+            early_noise = [self._noise("normal", nb) for _ in range(3)]     # reference order: E(target_image), E(source), E(idt_random_image)
+            with _frozen(list(self.E.parameters())), torch.no_grad():
+                early_info = self._encode(src, noise=early_noise[1])
         if redG is not None:
             redG.finish()
-            redE.finish()
         self._step(self.optG)
-        self._step(self.optE)
 
         # ---------------- phase 2: G only ----------------
         self.G.zero_grad()
         self.E.zero_grad()
         with _frozen(list(self.E.parameters())):           # only optG steps: E's weight grads are discarded
-            do_idt_reg = L["idt_reg"] * L["idt"] > 0
             if do_idt_reg and self._fused_paths():
                 # reference order of the noise draws: E(target_image), E(source), E(idt_random_image)
                 nb = src.shape[0]
-                n1, n2, n3 = (self._noise("normal", nb) for _ in range(3))
-                with torch.no_grad():                       # its gradient only reaches E's parameters
-                    info = self._encode(src, noise=n2)
+                if early_info is not None:                  # (data parallel: drawn and encoded under G's all-reduce, above)
+                    (n1, n2, n3), info = early_noise, early_info
+                else:
+                    n1, n2, n3 = (self._noise("normal", nb) for _ in range(3))
+                    with torch.no_grad():                   # its gradient only reaches E's parameters
+                        info = self._encode(src, noise=n2)
                 idt_random_image, info = self.G_transformation("source", src, True, src, _enc_info=info)
                 feats = E.features(ops.cat_batch([self.target_image, idt_random_image]))    # ONE batch through E
                 target_cenc = self._encode(None, feats[:nb], n1)[1]
                 idt_cenc_rand = self._encode(None, feats[nb:], n3)[1]
                 errG_reg = ops.l1_mean(self.c_rand, target_cenc, 1.0)
                 errG_idt_reg = ops.l1_mean(info[1], idt_cenc_rand, 1.0)
-                errG_ex = errG_reg * L["reg"] + errG_idt_reg * (L["idt_reg"] * (L["idt"] / L["cycle"]))
+                errG_ex = ops.lincomb([(errG_reg, L["reg"]), (errG_idt_reg, L["idt_reg"] * (L["idt"] / L["cycle"]))])
                 terms["errG_reg"], terms["errG_idt_reg"] = errG_reg, errG_idt_reg
             else:
                 _, target_cenc, _, _, _ = self._encode(self.target_image)
@@ -398,7 +435,8 @@ class SRGAN_training():
 
         self.recon_image = recon_image.detach()
         self.loss_terms.update({k: v.detach() for k, v in terms.items()})
-        errG = errG.detach() + errG_ex.detach()
+        with torch.no_grad():
+            errG = ops.lincomb([(errG, 1.0), (errG_ex, 1.0)])
         return [errG, errE_output.detach()]
 
     # ------------------------------------------------------------------------------------------
@@ -414,6 +452,26 @@ class SRGAN_training():
         # graph is ever back-propagated (phases 1 and 2); the first k-1 run as ONE no-grad batch of (k-1)*B images.
         noises = [self._noise("randn", nb) for _ in range(k)]
         oh = self._onehot("target")
+        if dp.is_distributed():
+            # Data parallel: every discriminator update ends in a gradient all-reduce, and the only work of the loop that does
+            # not depend on it is the NEXT translation (G is fixed during the loop).  So the translations run one at a time, each
+            # under the previous update's all-reduce; the last update's all-reduce runs under the encoder / generator forward
+            # passes of phase 1 (update_GandE calls _finish_D() right before it needs the updated discriminator).
+            def translate(i):
+                if i < k - 1:
+                    with torch.no_grad():
+                        return self.G(src, torch.cat([oh, noises[i]], 1)), noises[i]
+                return self.G(src, torch.cat([oh, noises[i]], 1)), noises[i]       # the graph that phases 1 and 2 back-propagate
+
+            fake = translate(0)
+            for i in range(k):
+                nxt = (lambda j=i + 1: translate(j)) if i + 1 < k else None
+                out = self.update_D(_fake=fake, _next_fake=nxt, _defer=(i == k - 1))
+                errD, fake = out if nxt is not None else (out, None)
+                if i == 0:
+                    errorD = errD.detach()
+            errorG, errorE = self.update_GandE()
+            return [errorG, errorD, errorE]
         fakes = []
         if k > 1 and isinstance(dp.unwrap(self.G), SingleGenerator):     # per-sample network: batching is exact
             # the kernels address an activation with 32-bit byte offsets (< 4 GiB per tensor): translations are batched in
@@ -465,8 +523,10 @@ class SRGAN_training():
         re-create), the second captures and replays, later ones only stage the step's inputs (image batch, labels, the
         CPU-generator noise drawn in the reference's order) into static device buffers and launch the graph.  Inputs of
         another shape (an epoch's last partial batch) run eagerly.  Results are bit-identical to eager execution.
-        Under a process group the recording is cut at every collective (k + 4 graph segments, the collectives issued eagerly
-        between them: ``_Recording``); if any rank fails to record, all ranks drop graph mode together and continue eagerly
+        Under a process group the recording is cut where a collective starts and where its result is needed (2k + 5 graph
+        segments; between them the all-reduces are enqueued on the communication stream and run UNDER the following segment --
+        the next translation, phase 1's forward passes, E's optimiser step: ``_Recording``, ``dp.launch_pending``); if any rank
+        fails to record, all ranks drop graph mode together and continue eagerly
         (``SRGAN_DP_GRAPH=0`` refuses graph mode under a process group altogether)."""
         self._graph = _StepGraph(self)
         return self
@@ -764,16 +824,22 @@ class _Recording:
     """One train step as a chain of hipGraph segments with host callables between them.
 
     Single process: one segment -- the whole step is one graph launch.  Data parallel: ``srgan_amd.dp`` ends the segment being
-    recorded wherever the step exchanges data (the mu all-gather, the bucket all-reduces after each backward) and hands over
-    the collective as a callable; ``replay()`` launches segment, collective, segment, ... on the caller's stream.  The
-    collectives therefore stay ordinary eager RCCL calls on static buffers -- nothing of RCCL is captured, no communication
-    stream is forked into a capture -- and everything between two of them (8 exchange points per step: k discriminator
-    all-reduces, the all-gather, two generator / encoder all-reduces) is one launch.  All segments allocate from one private
-    pool and are replayed in recording order, so a tensor made in one segment is valid in the following ones."""
+    recorded wherever the step starts a collective (``dp.launch_pending``: the bucket all-reduces after a backward; the mu
+    all-gather) and wherever it needs the result (``GradReducer.finish``), and hands over a host callable; ``replay()`` launches
+    segment, callable, segment, ... on the caller's stream.  A "start" callable enqueues the in-place all-reduces of the flat
+    buckets on the communication stream behind a ``ready`` event and returns; the segments launched next -- the work the trainer
+    placed between start and finish: the next translation during the discriminator loop, phase 1's encoder / generator forward
+    under the last discriminator all-reduce, E's optimiser step and phase 2's E(source) under G's -- run UNDER the collectives;
+    the "wait" callable makes the compute stream wait for the ``done`` events right before the optimiser-step segment.  Nothing
+    of RCCL is captured and no stream is forked inside a capture: the collectives stay ordinary eager calls on static buffers in
+    a fixed order.  2k + 5 segments per step (k x (start, wait), the all-gather, start(E, G) + wait(E), wait(G),
+    start(G) + wait(G): a wait that follows its start directly rides in the same callable).  All segments allocate from one private pool and are replayed in recording order, so a tensor made in one segment
+    is valid in the following ones."""
 
     def __init__(self, device):
         self.device = device
         self.segments = []         # [(CUDAGraph, callable or None)]
+        self.trace = None          # tests: a list -> the host-side order of the last replay: ("segment", i) / (comm kind, i)
         self.pending = []          # flat gradient buckets laid out since the last cut (dp.GradReducer)
         self._cur = None
         self._pool = None
@@ -817,11 +883,18 @@ class _Recording:
         return False
 
     def replay(self):
+        trace = self.trace
+        if trace is not None:
+            trace.clear()
         with torch.no_grad():          # the collectives write buffers (views made inside autograd functions) in place
-            for graph, comm in self.segments:
+            for i, (graph, comm) in enumerate(self.segments):
                 graph.replay()
+                if trace is not None:
+                    trace.append(("segment", i))
                 if comm is not None:
                     comm()
+                    if trace is not None:
+                        trace.append((getattr(comm, "kind", "comm"), i))
 
 
 def lib_prof_off():
@@ -965,7 +1038,7 @@ class SingleGAN_training():
         terms = dict(errG_cycle=errG_cycle)
         _, mu, logvar = source_enc_info
         if L["KL"] > 0:
-            errE_KL = -0.5 * torch.sum(1 + logvar - mu ** 2 - logvar.exp())     # [B, ndim] scalars: host-side glue
+            errE_KL = ops.kl_normal(mu, logvar)
             errE = errE + errE_KL * L["KL"]
             errE_output = errE_output + errE_KL * L["KL"]
             terms["errE_KL"] = errE_KL

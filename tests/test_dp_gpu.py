@@ -62,19 +62,43 @@ def _run(rank, world, out_q=None, kl=0.0, graph=False, recipe=None):
         x, label = otrainer.synthetic_batch(gb, 128, 4, seed=300 + s)
         sl = slice(rank * per, (rank + 1) * per)
         lab = {"source": label["source"][sl].cuda(), "target": label["target"][sl]}
+        if graph and sg.graph_active and dp.is_distributed():
+            sg._graph.graph.trace = []          # host-side order of this replay (checked below)
         losses.append([float(v) for v in sg.train(x[sl].cuda(), lab)])
     from srgan_amd import trainer as htrainer
     if graph and htrainer._StepGraph.fault_hook is not None:
         assert sg._graph is None and not sg.graph_active          # every rank gave the recording up together
     elif graph:
-        # data parallel: the recording is cut at each of the K + 3 exchange points (K discriminator all-reduces, the mu
-        # all-gather, the G+E and the G all-reduces) -- K + 4 graph segments with eager collectives between them
-        assert sg.graph_active and len(sg._graph.graph.segments) == (K + 4 if dp.is_distributed() else 1)
+        # data parallel: the recording is cut where a collective starts and where its result is needed -- K x (start, wait) for
+        # the discriminator, the mu all-gather, start(E + G) with wait(E) / wait(G), start(G) with its wait: 2K + 5 graph segments
+        assert sg.graph_active and len(sg._graph.graph.segments) == (2 * K + 5 if dp.is_distributed() else 1)
+        if dp.is_distributed():
+            _check_overlap_order(sg._graph.graph.trace)
     state = {f"{n}.{k}": v.detach().cpu().numpy().copy() for n, net in (("G", sg.G), ("D", sg.D), ("E", sg.E)) for k, v in net.state_dict().items()}
     terms = {k: float(v) for k, v in sg.loss_terms.items()}
     if out_q is not None:
         out_q.put((rank, losses, state if rank == 0 else None, terms))
     return losses, state, terms
+
+
+def _check_overlap_order(tr):
+    """north_star: "all-reduce ... overlapped ... on a side HIP stream".  The host-side trace of the last replay: every
+    discriminator all-reduce i is ENQUEUED (on the communication stream, behind a ``ready`` event) before the segment that holds
+    translation i + 1 is launched, and the compute stream is made to wait for its ``done`` event only after that segment; the
+    last one is awaited after phase 1's forward segment; G's phase-1 all-reduce is started before and awaited after the segment
+    with E's optimiser step.  (Whether the two streams really run side by side is the device's business -- and with gloo the
+    all-reduce blocks the host -- so the ORDER of the enqueues is what is asserted.)"""
+    kinds = [k for k, _ in tr if k != "segment"]
+    assert kinds == ["all_reduce", "wait"] * K + ["all_gather", "all_reduce", "wait", "all_reduce"], kinds
+    pos = {(k, i): n for n, (k, i) in enumerate(tr)}
+    starts = [i for k, i in tr if k == "all_reduce"]
+    waits = [i for k, i in tr if k == "wait"]
+    for d in range(K):                       # discriminator update d: start after segment s, wait after segment s + 1
+        s, w = starts[d], waits[d]
+        assert w == s + 1 and pos[("all_reduce", s)] < pos[("segment", s + 1)] < pos[("wait", w)], (d, s, w)
+    # phase 1: start(E, G) (E awaited in the same callable), wait(G) one segment (E's step + E(source)) later
+    s, wg = starts[K], waits[K]
+    assert wg == s + 1 and pos[("all_reduce", s)] < pos[("segment", s + 1)] < pos[("wait", wg)]
 
 
 def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False, graph=False, recipe=None, inject=None):
@@ -229,3 +253,23 @@ def test_config3_recipe_four_ranks_equal_one_process():
         worst = max(worst, float(d.max()))
         q999 = float(np.quantile(d, 0.999)) if d.size >= 1000 else float(d.max())
         assert float(d.max()) <= 1.5e-4 and q999 <= 4e-5 and float(np.median(d)) <= 5e-6, (key, float(d.max()), q999, float(np.median(d)))
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """``python bench.py --gpus 2`` end to end -- the launcher, two full-width ranks (sharing the test box's one MI355X:
+    SRGAN_DP_DEVICE=0, gloo as the transport), the recorded data-parallel step with its collectives started on the communication
+    stream between graph segments, max-over-ranks timing, rank 0's JSON line with n_gpus = 2 and weak scaling."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SRGAN_DP_DEVICE="0", SRGAN_DP_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
+                        "--batch-per-gpu", "8"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 16
+    assert rec["config"]["parallelism"] == "dp2" and not rec["config"]["graph_fallback"]
+    assert "hipGraph segments" in rec["config"]["execution"] and rec["value"] > 0
+    assert all(np.isfinite(rec["config"]["losses_last_step"]))

@@ -824,7 +824,8 @@ def test_fused_param_grads_equal_autograd_accumulation(ops, mode):
     :689) -- the weight-gradient kernels add the second contribution in their own epilogue (slab reduce with beta = 1,
     central-biasing records with the accumulate flag) instead of autograd's AccumulateGrad input buffer doing it with one
     elementwise launch per parameter.  Same operands, same single addition: every parameter gradient bit-identical; a
-    post-accumulate-grad hook still fires once per parameter; a gradient already in ``p.grad`` is added to, as AccumulateGrad would."""
+    post-accumulate-grad hook still fires once per parameter and backward call (the data-parallel reducer counts on it); a
+    gradient already in ``p.grad`` is added to, as AccumulateGrad would."""
     from srgan_amd import model
     torch.manual_seed(5)
     G = model.SingleGenerator(3, 64, 2, 2, 2, "instance", num_con=12).cuda()      # full width, two residual blocks
@@ -858,3 +859,80 @@ def test_fused_param_grads_equal_autograd_accumulation(ops, mode):
     for stage in (0, 1):
         for n in out[False][stage]:
             assert torch.equal(out[False][stage][n], out[True][stage][n]), (stage, n)
+
+
+@pytest.mark.parametrize("o,i", [(256, 256), (64, 96), (128, 64)])
+def test_multi_pack_launch_equals_single_pack(ops, o, i):
+    """The per-optimiser-step repack (srgan_conv2d_pack_multi: one launch for every cached operand; its F(4x4,3x3) images take the
+    workgroup-cooperative path with coalesced 16-byte reads through LDS) must write the same bytes as the per-layer pack kernel
+    (srgan_conv2d_pack), forward and input-gradient operands."""
+    import os
+    w = (rnd(o, i, 3, 3, seed=7) / np.sqrt(i * 9)).cuda().requires_grad_(True)
+    x = rnd(2, i, 32, 32, seed=8).cuda().requires_grad_(True)
+    os.environ["SRGAN_WINOGRAD_THRESHOLD_SCALE"] = "0"
+    try:
+        ops.invalidate_packed()
+        with ops.pack_cache():
+            ops.conv2d(x, w, None, 1, 1).sum().backward()          # packs kind 0 and kind 1 one by one
+            hits = [h for h in ops._pack_cache.values() if h.weight is w]
+            assert len(hits) == 2
+            single = [h.buf.clone() for h in hits]
+            for h in hits:
+                h.buf.zero_()
+            ops.refresh_packed([w], force=True)                     # the multi-pack launch
+            for h, s in zip(hits, single):
+                assert torch.equal(h.buf, s), (h.kind, o, i)
+    finally:
+        os.environ.pop("SRGAN_WINOGRAD_THRESHOLD_SCALE", None)
+        ops.invalidate_packed()
+
+
+def test_d_losses_lincomb_kl_normal(ops):
+    """The one-launch loss assemblies against plain PyTorch-CPU arithmetic of the reference's formulas: LSGAN + class MSE of a
+    real | fake discriminator batch (util.py:457-468 as used by util_notebook.py:582-590), the weighted sum of a phase's loss
+    terms, the conventional KL (util_notebook.py:630-634) -- values and every gradient."""
+    B, nc = 6, 4
+    o1, o2 = rnd(2 * B, 1, 7, 7, seed=1), rnd(2 * B, 1, 3, 3, seed=2)
+    z1, z2 = rnd(2 * B, nc, seed=3), rnd(2 * B, nc, seed=4)
+    lab = torch.randint(0, nc, (B,), generator=torch.Generator().manual_seed(5))
+    wc = 0.7
+    dev = [t.cuda().requires_grad_(True) for t in (o1, o2, z1, z2)]
+    total, parts = ops.d_losses(dev[:2], dev[2:], lab.cuda(), B, 1.0, 0.0, wc)
+    (total * 1.5).backward()
+    ref = [t.clone().requires_grad_(True) for t in (o1, o2, z1, z2)]
+    mse = torch.nn.MSELoss()
+    onehot = torch.eye(nc)[lab]
+    real = 0.5 * (mse(ref[0][:B], torch.ones_like(ref[0][:B])) + mse(ref[1][:B], torch.ones_like(ref[1][:B])))
+    fake = 0.5 * (mse(ref[0][B:], torch.zeros_like(ref[0][B:])) + mse(ref[1][B:], torch.zeros_like(ref[1][B:])))
+    cls = 0.5 * (mse(torch.softmax(ref[2][:B], 1), onehot) + mse(torch.softmax(ref[3][:B], 1), onehot))
+    want = real + cls * wc + fake
+    (want * 1.5).backward()
+    close(total, want, 1e-5)
+    close(parts, torch.stack([real, cls, fake]).detach(), 1e-5)
+    for a, b in zip(dev, ref):
+        close(a.grad, b.grad, 1e-5)
+    # all rows "first", no class head (the generator's view of D without labels)
+    t2, p2 = ops.d_losses([o1.cuda()], [], None, 2 * B, 1.0, 0.0, 0.0)
+    close(t2, mse(o1, torch.ones_like(o1)), 1e-5)
+    # lincomb
+    xs = [rnd(seed=10 + i).reshape(()).cuda().requires_grad_(i != 1) for i in range(5)]
+    ws = [1.0, 5.0, -0.25, 100.0, 0.5]
+    out = ops.lincomb(list(zip(xs, ws)))
+    (out * 2.0).backward()
+    close(out, sum(w * float(x) for x, w in zip(xs, ws)), 1e-6)
+    for i, (x, w) in enumerate(zip(xs, ws)):
+        if i == 1:
+            assert x.grad is None
+        else:
+            close(x.grad, torch.tensor(2.0 * w), 1e-6)
+    # conventional KL
+    mu, lv = rnd(B, 8, seed=20), rnd(B, 8, seed=21) * 0.3
+    a, b = mu.cuda().requires_grad_(True), lv.cuda().requires_grad_(True)
+    kl = ops.kl_normal(a, b)
+    kl.backward()
+    ra, rb = mu.clone().requires_grad_(True), lv.clone().requires_grad_(True)
+    want = -0.5 * torch.sum(1 + rb - ra ** 2 - rb.exp())
+    want.backward()
+    close(kl, want, 1e-5)
+    close(a.grad, ra.grad, 1e-5)
+    close(b.grad, rb.grad, 1e-5)
