@@ -421,6 +421,7 @@ struct WinoWgradParams {
   int groups_per_split, splits;   // splits = (splits over tile-position groups) x bsplits
   int bsplits, nb_per;             // split of the batch: a workgroup walks images [b0, b0 + nb_per) of its groups
   int o_tiles, i_tiles, Opad;
+  int xcd_splits;                  // 1: the workgroups of one split share an XCD (see the kernel); needs splits % 8 == 0
 };
 
 // MODE 0: 3x3 stride-1 layer (above).  MODE 1: 4x4 stride-2 pad-1 layer, the transpose of wino_kernel<1>:
@@ -433,9 +434,20 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
   __shared__ __attribute__((aligned(16))) float lds[32768];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
+  // Workgroup b runs on XCD b % 8.  The (o tile, i tile) workgroups of one split gather the SAME tile range of x and dy, so a
+  // split's workgroups are dealt to ONE XCD (split = the low three bits of b inside a group of 8 splits): each line of the two
+  // activations goes through one L2 instead of up to eight.
   int bid = blockIdx.x;
-  const int split = bid / (p.o_tiles * p.i_tiles);
-  bid -= split * (p.o_tiles * p.i_tiles);
+  const int tiles_per_split = p.o_tiles * p.i_tiles;
+  int split;
+  if (p.xcd_splits) {
+    const int grp = bid / (8 * tiles_per_split), r = bid - grp * 8 * tiles_per_split;
+    split = grp * 8 + (r & 7);
+    bid = r >> 3;
+  } else {
+    split = bid / tiles_per_split;
+    bid -= split * tiles_per_split;
+  }
   const int o_tile = bid / p.i_tiles, i_tile = bid - o_tile * p.i_tiles;
 
   // gather role: tile of the chunk = 4 * (wave >> 2) + (lane & 3), channel = 16 * (wave & 3) + (lane >> 2)
@@ -733,6 +745,12 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgradParams p) {
 //   g[a][b] = w[n][c][2a+p][2b+q];  kind 1 (its transpose): one image per OUTPUT phase rs, g[a][b] = w[c][n][3-2a-r][3-2b-s]
 __global__ __launch_bounds__(256) void wino_pack_kernel(WinoPackParams p) {
   const long long total = wino_pack_total(p);
+  if (wino43_pack_block_ok(p)) {       // same code as the multi-layer launch (pack_multi_kernel): identical bytes either way
+    __shared__ float tile[32 * WP43_ROW];
+    for (long long base = (long long)blockIdx.x * 256; base < total; base += (long long)gridDim.x * 256)
+      wino43_pack_block(p, base, tile);
+    return;
+  }
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x)
     wino_pack_item(p, idx);
@@ -863,6 +881,8 @@ void wino_pack_params(const srgan_conv_desc* d, int kind, const float* w, float*
   wino_dims(d, kind, &C, &N, &q.n_tiles, &q.nchunk, &q.phases);
   q.variant = wino_variant(d, kind);
   q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW; q.N = N; q.C = C; q.kind = kind;
+  // A/B switch (read per call: the unit test packs both ways in one process): one thread per item, uncoalesced reads
+  q.no_block = std::getenv("SRGAN_PACK_ITEM_PATH") != nullptr ? 1 : 0;
   *out = q;
 }
 
@@ -1032,6 +1052,8 @@ int wino_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, fl
   const int variant = wino_wgrad_geometry(d, &p);
   SRGAN_REQUIRE(variant != 0, "winograd wgrad: layer not applicable");
   p.x = x; p.dy = dy; p.slab = slab;
+  static const bool plain = std::getenv("SRGAN_WGRAD_PLAIN_ORDER") != nullptr;       // A/B switch: the round-2 order
+  p.xcd_splits = (!plain && p.splits % 8 == 0) ? 1 : 0;
   ProfToken tok = prof_begin(variant == 1 ? 15 : 17, conv_flops_of(d), st);   // algorithmic FLOPs, as above
   const dim3 grid((unsigned)(p.o_tiles * p.i_tiles * p.splits));
   if (variant == 1) hipLaunchKernelGGL(wino_wgrad_kernel<0>, grid, dim3(512), 0, st, p);

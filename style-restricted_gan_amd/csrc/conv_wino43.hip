@@ -601,6 +601,7 @@ struct Wino43WgradParams {
   const float* zimg;
   float* slab;
   int C, O, cchunks, ntc, chunks_per_split, splits, c_blocks, o_blocks;
+  int split_minor;     // 1: the split index is the FAST index of blockIdx.x (see the kernel)
 };
 
 struct Wino43DyParams {
@@ -662,10 +663,15 @@ __global__ __launch_bounds__(512) void wino43_wgrad_kernel(Wino43WgradParams p) 
   __shared__ __attribute__((aligned(16))) float lds[2 * BSZ];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
+  // Workgroup b runs on XCD b % 8.  All (o block, c block) workgroups of one split read the SAME 1/splits of the V and Z images
+  // (V once per o block, Z once per c block), so the split index is the fast index: with 8 splits (the 256-channel trunk) every
+  // split's 32 workgroups share one XCD and its L2 -- each line of the two images is fetched from the fabric once instead of
+  // through two (V) / four (Z) different L2s.
   int bid = blockIdx.x;
   const int per_split = p.o_blocks * p.c_blocks;
-  const int split = bid / per_split;
-  bid -= split * per_split;
+  int split;
+  if (p.split_minor) { split = bid % p.splits; bid /= p.splits; }
+  else { split = bid / per_split; bid -= split * per_split; }
   const int o_blk = bid / p.c_blocks, cb = bid - o_blk * p.c_blocks;
   const int tc0 = split * p.chunks_per_split;
   const int nk = min(p.chunks_per_split, p.ntc - tc0);      // >= 2 (wino43_wgrad_plan)
@@ -823,6 +829,8 @@ int wino43_wgrad_launch(const Wino43WgradGeom& g, const float* vimg, const float
   Wino43WgradParams p{};
   p.vimg = vimg; p.zimg = zimg; p.slab = slab; p.C = g.C; p.O = g.O; p.cchunks = g.C / 8; p.ntc = g.ntc;
   p.chunks_per_split = g.chunks_per_split; p.splits = g.splits; p.c_blocks = g.C / 64; p.o_blocks = g.O / 32;
+  static const bool major = std::getenv("SRGAN_W43_WGRAD_SPLIT_MAJOR") != nullptr;      // A/B switch: the round-2 order
+  p.split_minor = major ? 0 : 1;
   ProfToken tok = prof_begin(22, flops, st);
   hipLaunchKernelGGL(wino43_wgrad_kernel, dim3((unsigned)(p.o_blocks * p.c_blocks * p.splits)), dim3(512), 0, st, p);
   prof_end(tok, st);

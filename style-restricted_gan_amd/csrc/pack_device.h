@@ -43,6 +43,7 @@ struct WinoPackParams {
   float* dst;
   long long sO, sI, sH, sW;
   int N, C, kind, nchunk, n_tiles, variant, phases;
+  int no_block;        // 1: never take the workgroup-cooperative path (SRGAN_PACK_ITEM_PATH, A/B)
 };
 
 
@@ -116,7 +117,7 @@ __device__ __forceinline__ void wino43_pack_item(const WinoPackParams& p, long l
 // Measured on the generator's repack (24 F(4x4,3x3) images per optimiser step): see DESIGN.md section 4.
 constexpr int WP43_ROW = 289;
 __device__ __host__ __forceinline__ bool wino43_pack_block_ok(const WinoPackParams& p) {
-  return p.variant == 3 && p.sW == 1 && p.sH == 3 && p.sI == 9 && p.sO % 4 == 0 && p.nchunk % 4 == 0 && p.N % 32 == 0 && p.C % 32 == 0 &&
+  return p.variant == 3 && !p.no_block && p.sW == 1 && p.sH == 3 && p.sI == 9 && p.sO % 4 == 0 && p.nchunk % 4 == 0 && p.N % 32 == 0 && p.C % 32 == 0 &&
          (reinterpret_cast<unsigned long long>(p.w) & 15) == 0;
 }
 __device__ __forceinline__ void wino43_pack_block(const WinoPackParams& p, long long base, float* tile /* [32][WP43_ROW] */) {

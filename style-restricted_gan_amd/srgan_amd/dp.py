@@ -305,13 +305,13 @@ class GradReducer:
         if self._pending is None:
             return
         work, armed = self._pending
-        self._pending = None
         recording = _recorder is not None
         if recording:
             launch_pending(then_wait=self)      # (a no-op when the caller already started the collectives to put work under them)
             if not self._waited:
                 _recorder.cut(_Comm("wait", lambda: _wait_done(work)))
             self._waited = False
+        self._pending = None
         for bk in work:
             if bk.done is not None and not recording:
                 torch.cuda.current_stream(bk.flat.device).wait_event(bk.done)

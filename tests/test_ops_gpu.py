@@ -882,6 +882,19 @@ def test_multi_pack_launch_equals_single_pack(ops, o, i):
             ops.refresh_packed([w], force=True)                     # the multi-pack launch
             for h, s in zip(hits, single):
                 assert torch.equal(h.buf, s), (h.kind, o, i)
+            # the workgroup-cooperative F(4x4,3x3) path against the one-thread-per-item path (different FMA contraction: compared
+            # as floats, to rounding)
+            os.environ["SRGAN_PACK_ITEM_PATH"] = "1"
+            try:
+                ops._tables.clear()
+                for h in hits:
+                    h.buf.zero_()
+                ops.refresh_packed([w], force=True)
+            finally:
+                os.environ.pop("SRGAN_PACK_ITEM_PATH", None)
+                ops._tables.clear()
+            for h, s in zip(hits, single):
+                close(h.buf.view(torch.float32), s.view(torch.float32), 1e-6, what=f"kind {h.kind}")
     finally:
         os.environ.pop("SRGAN_WINOGRAD_THRESHOLD_SCALE", None)
         ops.invalidate_packed()
