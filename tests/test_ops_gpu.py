@@ -85,6 +85,11 @@ CONV_CASES = [
     (2, 64, 16, 64, 128, 4, 2, 1, False, False),  # 64 -> 128 down conv on an 8 x 32 output map (bf16 mode: input gradient on the transposed patch kernel)
     (1, 128, 8, 64, 256, 4, 2, 1, False, False),  # 128 -> 256 down conv, one output patch (same kernel, C = 256 reduce channels)
     (3, 64, 64, 128, 128, 4, 2, 1, False, True),  # same layer class on a wider map: 8 x 2 patches per image, bias
+    (4, 64, 62, 62, 128, 3, 1, 1, True, False),   # round 3, F(4x4,3x3) on a RAGGED, REFLECT-padded map (E.layers.0.cmp: 62 = 15.5 tiles); input gradient: pad-2 correlation onto 64 x 64
+    (4, 128, 31, 31, 128, 3, 1, 1, True, True),   # same on 31 x 31 (E.layers.1), bias; input gradient onto the ragged 33 x 33 padded-gradient image
+    (8, 64, 30, 22, 64, 3, 1, 1, False, True),    # ragged map with ZERO padding: clipped rows (30 = 7.5 tiles) and columns (22 = 5.5), bias
+    (6, 32, 15, 15, 64, 3, 1, 1, True, False),    # 15 x 15 reflect: forward on F(4x4,3x3) (0.88 of the tiles' outputs kept), input gradient (17 x 17: 0.72) stays on F(2x2,3x3)
+    (2, 96, 13, 18, 32, 3, 1, 1, True, True),     # odd sizes in both directions, 3 channel groups, one cout block, bias
 ]
 
 
@@ -894,7 +899,7 @@ def test_multi_pack_launch_equals_single_pack(ops, o, i):
                 os.environ.pop("SRGAN_PACK_ITEM_PATH", None)
                 ops._tables.clear()
             for h, s in zip(hits, single):
-                close(h.buf.view(torch.float32), s.view(torch.float32), 1e-6, what=f"kind {h.kind}")
+                close(h.buf.view(torch.float32), s.view(torch.float32), 1e-6)
     finally:
         os.environ.pop("SRGAN_WINOGRAD_THRESHOLD_SCALE", None)
         ops.invalidate_packed()
