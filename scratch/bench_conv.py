@@ -14,6 +14,12 @@ shapes = [  # name, Cin, H, Cout, k, s, p
     ("D.c4 256->512 k4s2 @16", 256, 16, 512, 4, 2, 1),
     ("E.l0 64->128 k3 @62", 64, 62, 128, 3, 1, 1),
     ("E.l2 256->512 k3 @15", 256, 15, 512, 3, 1, 1),
+    ("Er.l0a 64->64 k3 @62 reflect", 64, 62, 64, 3, 1, 1),
+    ("Er.l0b 64->128 k3 @62 reflect", 64, 62, 128, 3, 1, 1),
+    ("Er.l1a 128->128 k3 @31 reflect", 128, 31, 128, 3, 1, 1),
+    ("Er.l1b 128->256 k3 @31 reflect", 128, 31, 256, 3, 1, 1),
+    ("Er.l2a 256->256 k3 @15 reflect", 256, 15, 256, 3, 1, 1),
+    ("Er.l2b 256->512 k3 @15 reflect", 256, 15, 512, 3, 1, 1),
     ("G.first 3->64 k7 @128", 3, 128, 64, 7, 1, 3),
     ("G.last 64->3 k7 @128", 64, 128, 3, 7, 1, 3),
 ]
@@ -29,10 +35,11 @@ for name, ci, h, co, k, s, p in shapes:
     if only and only not in name: continue
     x = torch.randn(B, h, h, ci, device="cuda").permute(0, 3, 1, 2)
     w = torch.randn(co, ci, k, k, device="cuda") / (ci * k * k) ** 0.5
-    y = ops.conv2d(x, w, None, s, p)
+    pm = 1 if "reflect" in name else 0
+    y = ops.conv2d(x, w, None, s, p, pm)
     gy = torch.randn_like(y)
     ho = y.shape[2]
-    desc = ops._conv_desc(B, h, h, ci, ho, ho, co, k, k, s, p, 0, w)
+    desc = ops._conv_desc(B, h, h, ci, ho, ho, co, k, k, s, p, pm, w)
     dx = torch.empty_like(x); dw = torch.empty_like(w)
     fl = 2.0 * B * ho * ho * co * k * k * ci
     t_f = timeit(lambda: ops._run_conv_fwd(desc, x, w, None, y, 0, 0.0))

@@ -1243,10 +1243,8 @@ extern "C" size_t srgan_conv2d_workspace(const srgan_conv_desc* d) {
   if (validate(d) != 0) return 0;
   size_t bytes = pack_bytes(d);
   // reflect dgrad: padded-gradient temp
-  if (d->pad_mode == SRGAN_PAD_REFLECT) {
+  if (d->pad_mode == SRGAN_PAD_REFLECT)
     bytes += (size_t)d->N * (d->Hi + 2 * d->pad) * (d->Wi + 2 * d->pad) * d->I * sizeof(float);
-    bytes += 256 + wino_scratch_bytes(d, 1);      // F(4x4,3x3) input gradient of a reflect layer: its V image sits behind the temp
-  }
   // split-K slabs of the implicit-GEMM forward / input gradient, behind the packed operand (and the reflect temp)
   bytes += 256 + std::max(conv_splitk_bytes(d, 0), conv_splitk_bytes(d, 1));
   // F(4x4,3x3) layers: the transformed-input image, behind the packed operand (64-float aligned)
@@ -1639,9 +1637,9 @@ static int dgrad_run_core(const srgan_conv_desc* d, const float* dy, const float
     return 0;
   }
   if (g.wino) {
-    // reflect layer: the padded-gradient temp is scratch[0 ..), the V image of an F(4x4,3x3) dispatch sits behind it
-    float* vbuf = scratch ? (g.reflect ? scratch + round_up((long long)d->N * g.Hd * g.Wd * d->I, 64) : scratch) : nullptr;
-    if (int e = wino_run(d, 1, dy, wp, nullptr, g.p.dst, SRGAN_ACT_NONE, 0.f, vbuf, st, g.reflect ? nullptr : res, res_done)) return e;
+    // (F(4,3) needs zero padding, the fold scratch needs reflect padding: the two uses of `scratch` never meet)
+    if (int e = wino_run(d, 1, dy, wp, nullptr, g.p.dst, SRGAN_ACT_NONE, 0.f, g.reflect ? nullptr : scratch, st,
+                         g.reflect ? nullptr : res, res_done)) return e;
   } else {
     // split-K slabs sit behind the padded-gradient temp of a reflect layer
     float* slab = scratch ? (g.reflect ? scratch + round_up((long long)d->N * g.Hd * g.Wd * d->I, 64) : scratch) : nullptr;

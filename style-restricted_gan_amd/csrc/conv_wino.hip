@@ -778,10 +778,6 @@ static bool wino43_disabled() {
   static const bool off = std::getenv("SRGAN_NO_WINOGRAD43") != nullptr;
   return off;
 }
-static bool wino43_ragged_disabled() {
-  static const bool off = std::getenv("SRGAN_NO_WINOGRAD43_RAGGED") != nullptr;
-  return off;
-}
 static bool wino_s2_disabled() {
   static const bool off = std::getenv("SRGAN_NO_WINOGRAD_S2") != nullptr;
   return off;
@@ -813,19 +809,6 @@ static int wino_variant(const srgan_conv_desc* d, int kind) {
       // many workgroups, so the same lower bound (100 of its workgroups = 50 of these) applies
       const long long b43 = ceil_div((long long)d->N * (ho / 4) * (wo / 4), 64) * (N / 32);
       if (b43 >= 50 * wino_threshold_scale()) return 3;
-    }
-    // Round 3: the same pair of kernels on maps that are not whole 4x4 tiles and on reflect-padded layers (the encoder's 3x3
-    // layers on 62x62 / 31x31 maps, model.py:413-437).  Forward: tiles over Ho x Wo; input gradient of a reflect layer: the
-    // full correlation onto the (Hi + 2) x (Wi + 2) padded-gradient image.  36 multiplies per 16 outputs against 16 per 4:
-    // worth it while the ragged tiling keeps >= ~0.8 of the outputs it computes (62 -> 0.94, 31 -> 0.94, 33 -> 0.84; 15 -> 0.88
-    // but 17 -> 0.72 and 7 -> 0.77 stay on F(2x2,3x3)).
-    if (!wino43_disabled() && !wino43_ragged_disabled() && N % 32 == 0 && C % 32 == 0) {
-      const bool reflect = d->pad_mode == SRGAN_PAD_REFLECT;
-      const int eh = ho + (kind == 1 && reflect ? 2 : 0), ew = wo + (kind == 1 && reflect ? 2 : 0);   // extent the tiles cover
-      const long long th = ceil_div(eh, 4), tw = ceil_div(ew, 4);
-      const double eff = (double)eh * ew / (16.0 * th * tw);
-      const long long b43 = ceil_div((long long)d->N * th * tw, 64) * (N / 32);
-      if (eff >= 0.8 && b43 >= 50 * wino_threshold_scale()) return 3;
     }
     const long long blocks = ceil_div((long long)d->N * ceil_div(ho, 2) * ceil_div(wo, 2), WT) * ceil_div(N, WNB);
     return blocks >= 100 * wino_threshold_scale() ? 1 : 0;
@@ -867,9 +850,8 @@ size_t wino_packed_bytes(const srgan_conv_desc* d, int kind) {
 // scratch the run needs beside the packed filters: the transformed-input image of the F(4x4,3x3) pair of kernels
 size_t wino_scratch_bytes(const srgan_conv_desc* d, int kind) {
   if (wino_variant(d, kind) != 3) return 0;
-  const int grow = (kind == 1 && d->pad_mode == SRGAN_PAD_REFLECT) ? 2 : 0;      // reflect input gradient: the padded-gradient image
-  const int ho = (kind == 0 ? d->Ho : d->Hi) + grow, wo = (kind == 0 ? d->Wo : d->Wi) + grow;
-  return wino43_scratch_floats((long long)d->N * ceil_div(ho, 4) * ceil_div(wo, 4), kind == 0 ? d->I : d->O) * sizeof(float);
+  const int ho = kind == 0 ? d->Ho : d->Hi, wo = kind == 0 ? d->Wo : d->Wi;
+  return wino43_scratch_floats((long long)d->N * (ho / 4) * (wo / 4), kind == 0 ? d->I : d->O) * sizeof(float);
 }
 
 // Weight gradient of an F(4x4,3x3) layer from the V image its forward wrote (conv_wino43.hip): applicable when the forward runs
@@ -877,7 +859,6 @@ size_t wino_scratch_bytes(const srgan_conv_desc* d, int kind) {
 bool wino43_wgrad_geometry(const srgan_conv_desc* d, Wino43WgradGeom* g) {
   static const bool off = std::getenv("SRGAN_NO_WINOGRAD43_WGRAD") != nullptr;
   if (off || wino_variant(d, 0) != 3 || d->I % 64 != 0 || d->O % 32 != 0) return false;
-  if (d->pad_mode != SRGAN_PAD_ZERO || d->Ho % 4 != 0 || d->Wo % 4 != 0) return false;      // the ragged / reflect forms keep no V for it
   const long long T = (long long)d->N * (d->Ho / 4) * (d->Wo / 4);
   const long long ntc = ceil_div(T, 64) * 8;
   const int tiles = (d->O / 32) * (d->I / 64);
@@ -950,7 +931,7 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
       p.pad = reflect ? 2 : 2 - d->pad;
       p.Ho = d->Ho + 2 * p.pad - 2; p.Wo = d->Wo + 2 * p.pad - 2;
     }
-    if (variant == 3) { ot = 4; p.TH = (int)ceil_div(p.Ho, 4); p.TW = (int)ceil_div(p.Wo, 4); }
+    if (variant == 3) { ot = 4; p.TH = p.Ho / 4; p.TW = p.Wo / 4; }
     else { p.TH = (p.Ho + 1) / 2; p.TW = (p.Wo + 1) / 2; }
   } else {
     ot = 3;
@@ -968,14 +949,11 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
   SRGAN_REQUIRE(grid < (1LL << 31), "winograd: grid too large");
   // ALGORITHMIC FLOPs of the direct convolution; the kernel issues ~2.25x fewer on the matrix pipe
   if (variant == 3) {
-    SRGAN_REQUIRE((p.pad == 1 || p.pad == 2) && p.Ho == p.H + 2 * p.pad - 2 && p.Wo == p.W + 2 * p.pad - 2 && p.nchunk >= 2 &&
-                  p.Cd % 32 == 0 && p.C % 32 == 0 && (!p.reflect || (p.pad == 1 && p.H >= 2 && p.W >= 2)),
+    SRGAN_REQUIRE(p.pad == 1 && p.Ho == p.H && p.Wo == p.W && p.nchunk >= 2 && p.Cd % 32 == 0 && p.C % 32 == 0,
                   "winograd F(4,3): geometry");
     SRGAN_REQUIRE(scratch, "winograd F(4,3): no scratch for the transformed input");
-    SRGAN_REQUIRE(!v_ready || (p.pad == 1 && !p.reflect && p.Ho % 4 == 0 && p.Wo % 4 == 0), "winograd F(4,3): prepared V image on a ragged map");
-    const bool epi_add = res != nullptr && p.Ho % 4 == 0 && p.Wo % 4 == 0;      // the clipping epilogue has no residual add
-    p.res = epi_add ? res : nullptr;
-    if (res_done) *res_done = epi_add;
+    p.res = res;
+    if (res_done) *res_done = res != nullptr;
     wino43_launch(p, scratch, grid, conv_flops_of(d), st, v_ready);
     return check_launch("wino43_kernel");
   }

@@ -117,72 +117,6 @@ __global__ __launch_bounds__(512) void wino43_input_kernel(WinoParams p, float* 
   }
 }
 
-// The same transform for every other geometry the F(4x4,3x3) multiply serves (round 3: the encoder's 3x3 layers on 62x62 /
-// 31x31 maps with REFLECT padding, model.py:413-437; their input gradients = a zero-pad-2 correlation onto the 64x64 / 33x33
-// padded-gradient image): maps that are not whole 4x4 tiles (the tile grid is ceil(Ho / 4) x ceil(Wo / 4), the multiply kernel
-// clips its stores), pad 1 or 2, mirrored border taps.  A tap's offset is row part + column part (6 + 6 registers and two
-// validity masks instead of the 3 x 3 classes above); taps that lie outside the padded image -- they only feed outputs that are
-// clipped -- read as zeros, so no garbage leaks into kept outputs through rounding.
-__global__ __launch_bounds__(512) void wino43_input_gen_kernel(WinoParams p, float* vimg) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cgs = p.C / 32;
-  int m_tile, cg;
-  if ((p.m_tiles & 7) == 0) {
-    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    cg = k % cgs;
-    m_tile = (k / cgs) * 8 + xcd;
-  } else {
-    m_tile = blockIdx.x / cgs;
-    cg = blockIdx.x - m_tile * cgs;
-  }
-  const int quad = lane & 7, tl = wave * 8 + (lane >> 3);
-  const int t = m_tile * W4T + tl;
-  const bool tv = t < p.T;
-  const int tt = tv ? t : 0;
-  const int per = p.TH * p.TW;
-  const int nb = tt / per;
-  const int r0 = tt - nb * per;
-  const int ty = r0 / p.TW, tx = r0 - ty * p.TW;
-  const int Y = 4 * ty - p.pad, X = 4 * tx - p.pad;
-  const auto rs_x = uniform_rsrc43(p.src, (unsigned)((size_t)p.NB * p.H * p.W * p.C * 4));
-  constexpr unsigned kOutside = 0x80000000u;
-  unsigned rowb[6], colb[6];
-  unsigned rmask = 0, cmask = 0;
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    int iy = Y + r, ix = X + r;
-    bool yok = (unsigned)iy < (unsigned)p.H, xok = (unsigned)ix < (unsigned)p.W;
-    if (p.reflect) {                       // pad 1: rows -1 and H mirror onto 1 and H - 2; anything further out stays zero
-      if (iy == -1) { iy = 1; yok = true; }
-      else if (iy == p.H) { iy = p.H - 2; yok = true; }
-      if (ix == -1) { ix = 1; xok = true; }
-      else if (ix == p.W) { ix = p.W - 2; xok = true; }
-    }
-    rowb[r] = (unsigned)((nb * p.H + (yok ? iy : 0)) * p.W) * (unsigned)(p.C * 4);
-    colb[r] = (unsigned)((xok ? ix : 0) * p.C + cg * 32 + quad * 4) * 4u;
-    rmask |= (yok ? 1u : 0u) << r;
-    cmask |= (xok ? 1u : 0u) << r;
-  }
-  if (!tv) rmask = 0;
-  f32x4 d[6][6];
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const bool ok = ((rmask >> r) & 1u) && ((cmask >> c) & 1u);
-      d[r][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? rowb[r] + colb[c] : kOutside, 0, 0));
-    }
-#pragma unroll
-  for (int c = 0; c < 6; ++c) bt6(d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], d[5][c]);
-  float* out = vimg + ((size_t)m_tile * p.nchunk + cg * 4 + (quad >> 1)) * W4BLK + (quad & 1) * 256 + tl * 4;
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]);
-#pragma unroll
-    for (int c = 0; c < 6; ++c) *reinterpret_cast<f32x4*>(out + (r * 6 + c) * 512) = d[r][c];
-  }
-}
-
 // ---- instance norm + activation + input transform in one pass (32x32 maps: the generator's residual trunk) ----
 // SingleResidualBlock (model.py:196-201): conv -> CBIN -> ReLU -> conv.  The normalised activation h between the two
 // convolutions has exactly one reader -- the second convolution's input transform -- and the F(4x4,3x3) weight gradient reads
@@ -433,9 +367,7 @@ int in_bwd_slab_vz_launch(const float* x, const float* gup, const float* scale, 
 // u = [n_tiles][nchunk][36 pos][64 lanes][4]: lane (lr, lh) holds output channel lr, reduce channels 4 lh .. 4 lh + 3.
 // RES: the epilogue adds p.res (input gradient of a residual block's first convolution: the skip path's gradient rides in
 // here).  A separate instantiation: a run-time branch in the epilogue cost every launch ~6 us (146 -> 154 us average).
-// CLIP: the map is not a whole number of 4x4 tiles -- edge tiles store only their valid rows / columns (a separate
-// instantiation again: the residual-trunk launches keep their unconditional stores).
-template <bool RES, bool CLIP = false>
+template <bool RES>
 __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* vimg) {
   // V image, double-buffered: [buf][36 pos][2 channel quads][64 tiles x 4 ch + 16 pad]: a lane's MFMA fragment is one 16-B
   // slot, a 16-lane read group covers 256 contiguous bytes; the copy writes 1 KB per wave instruction.
@@ -444,7 +376,6 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
   static_assert(36 * XP <= 2 * VSZ, "epilogue image must fit the V buffers");
   __shared__ __attribute__((aligned(16))) float lds[2 * VSZ];
   __shared__ int tile_o[W4T];                      // destination pixel index of the tile's first output, or -1
-  __shared__ int tile_f[W4T];                      // CLIP: valid rows | valid columns << 4 of the tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
@@ -466,7 +397,6 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
       const int r0 = t - nb * per;
       const int ty = r0 / p.TW, tx = r0 - ty * p.TW;
       o = (nb * p.Ho + 4 * ty) * p.Wo + 4 * tx;
-      if constexpr (CLIP) tile_f[tid] = min(4, p.Ho - 4 * ty) | (min(4, p.Wo - 4 * tx) << 4);
     }
     tile_o[tid] = o;
   }
@@ -638,16 +568,6 @@ __global__ __launch_bounds__(512) void wino43_kernel(WinoParams p, const float* 
             at6(hh[a][0], hh[a][1], hh[a][2], hh[a][3], hh[a][4], hh[a][5], y);
 #pragma unroll
             for (int b = 0; b < 4; ++b) dp[(size_t)(a * p.Wo + b) * p.Cd] = apply_act(y[b] + bv, p.act, p.slope) + rv[a * 4 + b];
-          }
-        } else if constexpr (CLIP) {
-          const int f = tile_f[16 * q + et], nr = f & 15, ncl = f >> 4;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            float y[4];
-            at6(hh[a][0], hh[a][1], hh[a][2], hh[a][3], hh[a][4], hh[a][5], y);
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-              if (a < nr && b < ncl) dp[(size_t)(a * p.Wo + b) * p.Cd] = apply_act(y[b] + bv, p.act, p.slope);
           }
         } else {
 #pragma unroll
@@ -883,17 +803,12 @@ int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops
   static const int only = std::getenv("SRGAN_W43_ONLY") ? std::atoi(std::getenv("SRGAN_W43_ONLY")) : 0;
   if (only != 2 && !v_ready) {      // v_ready: the caller's V image already holds B^T d B (in_fwd_slab_v_kernel wrote it)
     ProfToken tok = prof_begin(19, 0.0, st);
-    const bool plain = p.pad == 1 && !p.reflect && p.Ho == p.H && p.Wo == p.W && p.Ho % 4 == 0 && p.Wo % 4 == 0;
-    if (plain) hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)(p.m_tiles * (p.C / 32))), dim3(512), 0, st, p, vimg);
-    else hipLaunchKernelGGL(wino43_input_gen_kernel, dim3((unsigned)(p.m_tiles * (p.C / 32))), dim3(512), 0, st, p, vimg);
+    hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)(p.m_tiles * (p.C / 32))), dim3(512), 0, st, p, vimg);
     prof_end(tok, st);
   }
   if (only != 1) {
     ProfToken tok = prof_begin(18, flops, st);
-    const bool clip = (p.Ho % 4) != 0 || (p.Wo % 4) != 0;
-    if (clip) {       // (no residual add on this path: the caller adds p.res itself, see wino_run)
-      hipLaunchKernelGGL((wino43_kernel<false, true>), dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
-    } else if (p.res) hipLaunchKernelGGL(wino43_kernel<true>, dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
+    if (p.res) hipLaunchKernelGGL(wino43_kernel<true>, dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
     else hipLaunchKernelGGL(wino43_kernel<false>, dim3((unsigned)grid), dim3(512), 0, st, p, (const float*)vimg);
     prof_end(tok, st);
   }

@@ -85,10 +85,10 @@ CONV_CASES = [
     (2, 64, 16, 64, 128, 4, 2, 1, False, False),  # 64 -> 128 down conv on an 8 x 32 output map (bf16 mode: input gradient on the transposed patch kernel)
     (1, 128, 8, 64, 256, 4, 2, 1, False, False),  # 128 -> 256 down conv, one output patch (same kernel, C = 256 reduce channels)
     (3, 64, 64, 128, 128, 4, 2, 1, False, True),  # same layer class on a wider map: 8 x 2 patches per image, bias
-    (4, 64, 62, 62, 128, 3, 1, 1, True, False),   # round 3, F(4x4,3x3) on a RAGGED, REFLECT-padded map (E.layers.0.cmp: 62 = 15.5 tiles); input gradient: pad-2 correlation onto 64 x 64
-    (4, 128, 31, 31, 128, 3, 1, 1, True, True),   # same on 31 x 31 (E.layers.1), bias; input gradient onto the ragged 33 x 33 padded-gradient image
-    (8, 64, 30, 22, 64, 3, 1, 1, False, True),    # ragged map with ZERO padding: clipped rows (30 = 7.5 tiles) and columns (22 = 5.5), bias
-    (6, 32, 15, 15, 64, 3, 1, 1, True, False),    # 15 x 15 reflect: forward on F(4x4,3x3) (0.88 of the tiles' outputs kept), input gradient (17 x 17: 0.72) stays on F(2x2,3x3)
+    (4, 64, 62, 62, 128, 3, 1, 1, True, False),   # the encoder's own shapes (round 3): E.layers.0.cmp, 62 x 62, reflect padding
+    (4, 128, 31, 31, 128, 3, 1, 1, True, True),   # E.layers.1 on 31 x 31, reflect, bias
+    (8, 64, 30, 22, 64, 3, 1, 1, False, True),    # even but not multiple-of-4 map, zero padding, bias
+    (6, 32, 15, 15, 64, 3, 1, 1, True, False),    # E.layers.2 map size, reflect
     (2, 96, 13, 18, 32, 3, 1, 1, True, True),     # odd sizes in both directions, 3 channel groups, one cout block, bias
 ]
 
@@ -933,7 +933,7 @@ def test_d_losses_lincomb_kl_normal(ops):
     t2, p2 = ops.d_losses([o1.cuda()], [], None, 2 * B, 1.0, 0.0, 0.0)
     close(t2, mse(o1, torch.ones_like(o1)), 1e-5)
     # lincomb
-    xs = [rnd(seed=10 + i).reshape(()).cuda().requires_grad_(i != 1) for i in range(5)]
+    xs = [rnd(1, seed=10 + i).reshape(()).cuda().requires_grad_(i != 1) for i in range(5)]
     ws = [1.0, 5.0, -0.25, 100.0, 0.5]
     out = ops.lincomb(list(zip(xs, ws)))
     (out * 2.0).backward()

@@ -79,7 +79,7 @@ def test_train_trajectory_vs_reference_full_size(golden_dir):
 
 def test_train_step_bf16_compute_mode_full_size(golden_dir):
     """BASELINE configs [2]-[4] run the convolutions on the bf16 MFMA (fp32 accumulation, fp32 storage): the full-size train
-    step must track the fp32 reference trajectory within bf16 rounding of the conv operands -- 3e-2 on every loss over two
+    step must track the fp32 reference trajectory within bf16 rounding of the conv operands -- 1e-2 on every loss over two
     steps (measured: <= 6e-3)."""
     from srgan_amd import ops
     gold = np.load(os.path.join(golden_dir, "train_F_b2_k1.npz"))
@@ -88,7 +88,7 @@ def test_train_step_bf16_compute_mode_full_size(golden_dir):
         _, traj = run_hip("F", 2, 1, 2, seed=0)
     finally:
         ops.set_compute_dtype("fp32")
-    np.testing.assert_allclose(traj, gold["losses"], rtol=3e-2)
+    np.testing.assert_allclose(traj, gold["losses"], rtol=1e-2)
     assert not np.allclose(traj, gold["losses"], rtol=1e-6)      # the mode really changed the arithmetic
 
 
@@ -150,7 +150,7 @@ def test_headline_shape_step_bf16_vs_oracle():
     """The same workload in the bf16 mode (BASELINE configs [2]-[4] arithmetic at configs[1]'s shape): at bs=32, k=5 and full
     width the residual trunk runs as ops._ResBlockBf16Fn nodes -- LDS-resident-patch bf16 kernels at batch 32 / 64 / 128 with the
     block's intermediates stored as bf16 -- and the step must stay within bf16 rounding of the fp32 CPU oracle on the same seeds:
-    3e-2 on the three losses and on every loss term (measured: 4.2e-3)."""
+    1e-2 on the three losses and on every loss term (measured: 4.2e-3)."""
     import os
     from srgan_amd import ops
     from srgan_amd.trainer import SRGAN_training
@@ -180,10 +180,10 @@ def test_headline_shape_step_bf16_vs_oracle():
     for a, b in TERM_PAIRS:
         e = abs(t[a] - orc.trace[b]) / max(abs(orc.trace[b]), 1e-3)
         worst = max(worst, e)
-        assert e <= 3e-2, (a, t[a], orc.trace[b])
+        assert e <= 1e-2, (a, t[a], orc.trace[b])
     if os.environ.get("SRGAN_TEST_LOG"):
         print("bf16 headline step: losses", out, "oracle", ref, "worst relative deviation", worst)
-    np.testing.assert_allclose(out, ref, rtol=3e-2)
+    np.testing.assert_allclose(out, ref, rtol=1e-2)
 
 
 def test_config4_full_width_256_step_vs_oracle():
