@@ -937,7 +937,7 @@ def test_d_losses_lincomb_kl_normal(ops):
     ws = [1.0, 5.0, -0.25, 100.0, 0.5]
     out = ops.lincomb(list(zip(xs, ws)))
     (out * 2.0).backward()
-    close(out, sum(w * float(x) for x, w in zip(xs, ws)), 1e-6)
+    close(out, torch.tensor(sum(w * float(x) for x, w in zip(xs, ws))), 1e-6)
     for i, (x, w) in enumerate(zip(xs, ws)):
         if i == 1:
             assert x.grad is None
