@@ -83,13 +83,6 @@ int srgan_conv2d_dgrad_packed(const srgan_conv_desc* d, const float* dy, const v
 int srgan_instnorm_conv_v_applicable(const srgan_conv_desc* d);
 int srgan_instnorm_fwd_v(const srgan_conv_desc* d, const float* x, const float* scale, const float* shift, float* mean,
                          float* rstd, void* v_image, size_t v_bytes, float eps, int act, float slope, void* stream);
-/* srgan_instnorm_fwd_vy: the same pass when the result has a SECOND reader (a skip connection): y = act(norm(x)) (+ res, may be
- * NULL) is written as a tensor as well as the V image of layer `d` -- the output of a residual block (cn2 + skip, model.py:200-201)
- * feeding the next block's c1 and skip, or the last down convolution's norm in front of the trunk (model.py:237-242): the
- * consuming layer then starts from V (srgan_conv2d_fwd_from_v) and no input-transform pass re-reads y. */
-int srgan_instnorm_fwd_vy(const srgan_conv_desc* d, const float* x, const float* scale, const float* shift, const float* res,
-                          float* y, float* mean, float* rstd, void* v_image, size_t v_bytes, float eps, int act, float slope,
-                          void* stream);
 int srgan_conv2d_fwd_from_v(const srgan_conv_desc* d, const void* v_image, const void* packed, const float* bias, float* y,
                             int act, float slope, void* stream);
 /* The backward counterpart.  `d` describes a convolution whose OUTPUT y is normalised (y -> (CB)IN -> activation): the gradient

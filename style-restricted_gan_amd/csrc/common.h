@@ -101,7 +101,7 @@ struct WinoParams {
 size_t wino43_scratch_floats(long long T, int C);
 int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops, hipStream_t st, bool v_ready = false);
 // instance norm + activation of a 32x32 map written straight as the V image of the following F(4x4,3x3) layer (conv_wino43.hip)
-int in_fwd_slab_v_launch(const float* x, const float* scale, const float* shift, const float* res, float* yout, float* mean, float* rstd, float* vimg, int N,
+int in_fwd_slab_v_launch(const float* x, const float* scale, const float* shift, float* mean, float* rstd, float* vimg, int N,
                          int C, float eps, int act, float slope, hipStream_t st);
 // F(4x4,3x3) weight gradient from the forward's V image (conv_wino43.hip; geometry and dispatch in conv_wino.hip)
 struct Wino43WgradGeom { int NB, H, W, C, O, ntc, splits, chunks_per_split; size_t v_bytes, z_bytes, slab_bytes; };

@@ -1780,23 +1780,7 @@ extern "C" int srgan_instnorm_fwd_v(const srgan_conv_desc* d, const float* x, co
   SRGAN_REQUIRE((scale == nullptr) == (shift == nullptr), "instnorm_fwd_v: scale and shift go together");
   SRGAN_REQUIRE(srgan_instnorm_conv_v_applicable(d), "instnorm_fwd_v: layer not applicable (32x32 map into an F(4x4,3x3) layer)");
   SRGAN_REQUIRE(v_bytes >= srgan_conv2d_packed_scratch(d, 0), "instnorm_fwd_v: V image too small (srgan_conv2d_packed_scratch)");
-  return in_fwd_slab_v_launch(x, scale, shift, nullptr, nullptr, mean, rstd, static_cast<float*>(v_image), d->N, d->I, eps, act, slope,
-                              as_stream(stream));
-}
-
-// The same with the result ALSO written as a tensor (y) and an optional residual added first: y = act(norm(x)) (+ res), V = B^T y B.
-// For a 32x32 map that has two readers -- the next F(4x4,3x3) layer (through V) and a skip connection (through y): the output of a
-// residual block (cn2 + skip, model.py:200-201), or of the last down convolution's central-biasing norm in front of the trunk.
-extern "C" int srgan_instnorm_fwd_vy(const srgan_conv_desc* d, const float* x, const float* scale, const float* shift, const float* res,
-                                     float* y, float* mean, float* rstd, void* v_image, size_t v_bytes, float eps, int act, float slope,
-                                     void* stream) {
-  if (int e = validate(d)) return e;
-  SRGAN_REQUIRE(x && y && mean && rstd && v_image, "instnorm_fwd_vy: null pointer");
-  SRGAN_REQUIRE((scale == nullptr) == (shift == nullptr), "instnorm_fwd_vy: scale and shift go together");
-  SRGAN_REQUIRE(srgan_instnorm_conv_v_applicable(d), "instnorm_fwd_vy: layer not applicable (32x32 map into an F(4x4,3x3) layer)");
-  SRGAN_REQUIRE(v_bytes >= srgan_conv2d_packed_scratch(d, 0), "instnorm_fwd_vy: V image too small (srgan_conv2d_packed_scratch)");
-  return in_fwd_slab_v_launch(x, scale, shift, res, y, mean, rstd, static_cast<float*>(v_image), d->N, d->I, eps, act, slope,
-                              as_stream(stream));
+  return in_fwd_slab_v_launch(x, scale, shift, mean, rstd, static_cast<float*>(v_image), d->N, d->I, eps, act, slope, as_stream(stream));
 }
 
 extern "C" int srgan_conv2d_fwd_from_v(const srgan_conv_desc* d, const void* v_image, const void* packed, const float* bias,

@@ -145,12 +145,8 @@ __device__ __forceinline__ f32x4 slab_sum43_q4(f32x4 v, f32x4 (*sh)[4], int q, i
   return t;
 }
 
-// res / yout (round 3, both optional): the normalised, activated slab gets `res` added (a residual block's cn2 + skip) and is ALSO
-// written as a plain tensor -- the form used where the result has a second reader beside the next F(4x4,3x3) layer (the skip
-// path of the next residual block): the next block's c1 then runs straight from the V image (no wino43_input_kernel pass).
 __global__ __launch_bounds__(256, 2) void in_fwd_slab_v16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                                 const float* __restrict__ shift, const float* __restrict__ res,
-                                                                 float* __restrict__ yout, float* __restrict__ mean,
+                                                                 const float* __restrict__ shift, float* __restrict__ mean,
                                                                  float* __restrict__ rstd, float* __restrict__ vimg, int N, int C,
                                                                  float eps, int act, float slope) {
   constexpr int HW = 1024, R = 16, LD = 16;
@@ -200,8 +196,6 @@ __global__ __launch_bounds__(256, 2) void in_fwd_slab_v16_kernel(const float* __
     f32x4 o = ((v[j] - mu) * rs) * sc + sf;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = apply_act(o[e], act, slope);
-    if (res) o += *reinterpret_cast<const f32x4*>(res + base + (size_t)(ty + 64 * j) * C);
-    if (yout) *reinterpret_cast<f32x4*>(yout + base + (size_t)(ty + 64 * j) * C) = o;
     *reinterpret_cast<f32x4*>(&hb[(ty + 64 * j) * LD + q * 4]) = o;
   }
   __syncthreads();
@@ -229,10 +223,10 @@ __global__ __launch_bounds__(256, 2) void in_fwd_slab_v16_kernel(const float* __
   }
 }
 
-int in_fwd_slab_v_launch(const float* x, const float* scale, const float* shift, const float* res, float* yout, float* mean,
-                         float* rstd, float* vimg, int N, int C, float eps, int act, float slope, hipStream_t st) {
-  hipLaunchKernelGGL(in_fwd_slab_v16_kernel, dim3((unsigned)(N * (C / 16))), dim3(256), 0, st, x, scale, shift, res, yout, mean, rstd,
-                     vimg, N, C, eps, act, slope);
+int in_fwd_slab_v_launch(const float* x, const float* scale, const float* shift, float* mean, float* rstd, float* vimg, int N,
+                         int C, float eps, int act, float slope, hipStream_t st) {
+  hipLaunchKernelGGL(in_fwd_slab_v16_kernel, dim3((unsigned)(N * (C / 16))), dim3(256), 0, st, x, scale, shift, mean, rstd, vimg, N,
+                       C, eps, act, slope);
   return check_launch("in_fwd_slab_v_kernel");
 }
 

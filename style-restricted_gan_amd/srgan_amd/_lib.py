@@ -38,7 +38,6 @@ SIGNATURES = {
     "srgan_conv2d_dgrad_packed_add": (c_int, [_DESC, P, P, P, P, P, c_size_t, P]),
     "srgan_instnorm_conv_v_applicable": (c_int, [_DESC]),
     "srgan_instnorm_fwd_v": (c_int, [_DESC, P, P, P, P, P, P, c_size_t, c_float, c_int, c_float, P]),
-    "srgan_instnorm_fwd_vy": (c_int, [_DESC, P, P, P, P, P, P, P, P, c_size_t, c_float, c_int, c_float, P]),
     "srgan_conv2d_fwd_from_v": (c_int, [_DESC, P, P, P, P, c_int, c_float, P]),
     "srgan_instnorm_bwd_vz_applicable": (c_int, [_DESC]),
     "srgan_instnorm_bwd_vz_z_bytes": (c_size_t, [_DESC]),

@@ -178,20 +178,14 @@ class SingleResidualBlock(nn.Module):
 
     def forward(self, x):
         data, con = x[0], x[1]
-        v_in = x[2] if len(x) > 2 else None          # F(4x4,3x3) transformed image of `data`, written by its producer
         if data.is_cuda and isinstance(self.cn1, CBINorm2d) and self.cn1.affine:
             s1, h1 = self.cn1.scale_shift(con, data.device)
             s2, h2 = self.cn2.scale_shift(con, data.device)
             if ops.res_block_fusable(data, self.c1.weight, self.c2.weight, s1, s2):
                 # the whole block as one autograd node: neither the normalised activation nor the gradients w.r.t. the two
-                # conv outputs are ever written (ops._ResBlockFn).  In a chain of such blocks (SingleGenerator sets
-                # `emit_v_next`) cn2 + skip also writes the transformed image the NEXT block's c1 multiplies, so that block runs
-                # no input-transform pass over its input.
+                # conv outputs are ever written (ops._ResBlockFn)
                 self.cn1._check_input_dim(data)
-                if getattr(self, "emit_v_next", False) and not os.environ.get("SRGAN_NO_TRUNK_V_CHAIN"):
-                    out, v = ops.residual_block(data, s1, h1, s2, h2, self.c1.weight, self.c2.weight, self.cn1.eps, v_in, True)
-                    return out, con, v
-                return ops.residual_block(data, s1, h1, s2, h2, self.c1.weight, self.c2.weight, self.cn1.eps, v_in), con
+                return ops.residual_block(data, s1, h1, s2, h2, self.c1.weight, self.c2.weight, self.cn1.eps), con
             if ops.res_block_bf16_fusable(data, self.c1.weight, self.c2.weight, s1, s2):
                 # bf16 mode: one node, its intermediates stored as bf16 (ops._ResBlockBf16Fn)
                 self.cn1._check_input_dim(data)
@@ -227,8 +221,6 @@ class SingleGenerator(nn.Module):
         self.down_cnorms = nn.ModuleList(cnorms)
 
         self.resBlocks = nn.Sequential(*[SingleResidualBlock(nch * 2 ** num_cls, c_norm_layer) for _ in range(res_num)])
-        for blk in list(self.resBlocks)[:-1]:
-            blk.emit_v_next = True                   # its output's only conv reader is the next block's c1 (plus that block's skip)
 
         ups = [_ConvTranspose2d(nch * 2 ** num_cls, nch * 2 ** (num_cls - 1), kernel_size=k, stride=s, padding=p, bias=False)]
         norms = [norm_layer(nch * 2 ** (num_cls - 1))]
@@ -242,21 +234,9 @@ class SingleGenerator(nn.Module):
     def forward(self, x, c):
         if c.is_cuda and not os.environ.get("SRGAN_NO_CBIN_MULTI"):
             c = PrecomputedCon(c, list(self.down_cnorms) + [n for blk in self.resBlocks for n in (blk.cn1, blk.cn2)])
-        for i in range(self.num_cls):
+        for i in range(self.num_cls + 1):
             x = self.down_cnorms[i](self.down_convs[i](x), c, ACT_RELU)
-        y = self.down_convs[self.num_cls](x)
-        cn, first = self.down_cnorms[self.num_cls], (self.resBlocks[0] if len(self.resBlocks) else None)
-        v = None
-        if (first is not None and y.is_cuda and isinstance(cn, CBINorm2d) and not os.environ.get("SRGAN_NO_TRUNK_V_CHAIN")
-                and ops.norm_act_conv_fusable(y, first.c1.weight)):
-            # the norm in front of the trunk writes the first block's transformed input next to the tensor (the skip path reads it)
-            cn._check_input_dim(y)
-            scale, shift = cn.scale_shift(c, y.device)
-            if ops.res_block_fusable(y, first.c1.weight, first.c2.weight, scale, scale):
-                x, v = ops.instance_norm_act_v(y, scale, shift, first.c1.weight, ACT_RELU, 0.0, cn.eps)
-        if v is None:
-            x = cn(y, c, ACT_RELU)
-        x = self.resBlocks([x, c] if v is None else [x, c, v])[0]
+        x = self.resBlocks([x, c])[0]
         for i in range(self.num_cls):
             x = self.up_norms[i](self.up_convs[i](x), ACT_RELU)
         return ops.tanh(self.up_convs[-1](x))

@@ -743,7 +743,7 @@ class _ResBlockFn(Function):
     semantics of SURVEY.md Appendix C-1), the packed operands come from the packed-weight scope."""
 
     @staticmethod
-    def forward(ctx, x, s1, h1, s2, h2, w1, w2, eps, v_in=None, emit_v=False):
+    def forward(ctx, x, s1, h1, s2, h2, w1, w2, eps):
         lib = _lib.load()
         x = to_nhwc(x)
         n, c, h, w = x.shape
@@ -753,16 +753,10 @@ class _ResBlockFn(Function):
         need_w = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
         hit1, sc1 = _packed(d1, w1, 0, ACT_NONE)
         hit2, sc2 = _packed(d2, w2, 0, ACT_NONE)
+        v0 = torch.empty(max(sc1, 16), dtype=torch.uint8, device=dev) if need_w else workspace(dev, sc1)
         y1 = nhwc_empty(n, w1.shape[0], h, w, dev)
-        if v_in is not None:
-            # the producer of x (the previous block's cn2 + skip, or the norm in front of the trunk) already wrote B^T x B
-            v0 = v_in
-            _lib.check(lib.srgan_conv2d_fwd_from_v(ctypes.byref(d1), _ptr(v0), _ptr(hit1.buf), None, _ptr(y1), ACT_NONE, 0.0, _stream()),
-                       "conv2d_fwd_from_v")
-        else:
-            v0 = torch.empty(max(sc1, 16), dtype=torch.uint8, device=dev) if need_w else workspace(dev, sc1)
-            _lib.check(lib.srgan_conv2d_fwd_packed(ctypes.byref(d1), _ptr(x), _ptr(hit1.buf), None, _ptr(y1), ACT_NONE, 0.0, _ptr(v0),
-                                                   sc1, _stream()), "conv2d_fwd_packed")
+        _lib.check(lib.srgan_conv2d_fwd_packed(ctypes.byref(d1), _ptr(x), _ptr(hit1.buf), None, _ptr(y1), ACT_NONE, 0.0, _ptr(v0), sc1,
+                                               _stream()), "conv2d_fwd_packed")
         v1 = torch.empty(max(sc2, 16), dtype=torch.uint8, device=dev) if need_w else workspace(dev, sc2)
         c1 = w1.shape[0]
         mean1 = torch.empty(n * c1, dtype=torch.float32, device=dev)
@@ -776,28 +770,17 @@ class _ResBlockFn(Function):
         out = torch.empty_like(y2)
         mean2 = torch.empty(n * c2, dtype=torch.float32, device=dev)
         rstd2 = torch.empty_like(mean2)
-        v_out = None
-        if emit_v:
-            # cn2 + skip written as the tensor AND as the V image of the next block's c1 (same C -> C 3x3 geometry as d1)
-            v_out = torch.empty(max(sc1, 16), dtype=torch.uint8, device=dev)
-            _lib.check(lib.srgan_instnorm_fwd_vy(ctypes.byref(d1), _ptr(y2), _ptr(s2), _ptr(h2), _ptr(x), _ptr(out), _ptr(mean2),
-                                                 _ptr(rstd2), _ptr(v_out), v_out.numel(), float(eps), ACT_NONE, 0.0, _stream()),
-                       "instnorm_fwd_vy")
-        else:
-            nb = lib.srgan_instnorm_workspace(n, h * w, c2)
-            ws = workspace(dev, nb)
-            _lib.check(lib.srgan_instnorm_fwd(_ptr(y2), _ptr(s2), _ptr(h2), _ptr(x), _ptr(out), _ptr(mean2), _ptr(rstd2), n, h * w, c2,
-                                              float(eps), ACT_NONE, 0.0, _ptr(ws), nb, _stream()), "instnorm_fwd")
+        nb = lib.srgan_instnorm_workspace(n, h * w, c2)
+        ws = workspace(dev, nb)
+        _lib.check(lib.srgan_instnorm_fwd(_ptr(y2), _ptr(s2), _ptr(h2), _ptr(x), _ptr(out), _ptr(mean2), _ptr(rstd2), n, h * w, c2,
+                                          float(eps), ACT_NONE, 0.0, _ptr(ws), nb, _stream()), "instnorm_fwd")
         ctx.d1, ctx.d2, ctx.w1, ctx.w2 = d1, d2, w1, w2
         ctx.v0, ctx.v1 = (v0, v1) if need_w else (None, None)
         ctx.save_for_backward(y1, y2, s1, h1, s2, h2, mean1, rstd1, mean2, rstd2)
-        if emit_v:
-            ctx.mark_non_differentiable(v_out)
-            return out, v_out
         return out
 
     @staticmethod
-    def backward(ctx, g, _gv=None):
+    def backward(ctx, g):
         lib = _lib.load()
         y1, y2, s1, h1, s2, h2, mean1, rstd1, mean2, rstd2 = ctx.saved_tensors
         g = to_nhwc(g)
@@ -844,7 +827,7 @@ class _ResBlockFn(Function):
         vimg, zimg, ds1, dh1 = norm_bwd_vz(d1, y1, dh, s1, h1, mean1, rstd1, ACT_RELU, c1)
         dw1 = wgrad_vz(d1, w1, ctx.v0, zimg) if (ctx.needs_input_grad[5] and ctx.v0 is not None) else None
         dx = dgrad_from_v(d1, w1, vimg, g, d1.I) if ctx.needs_input_grad[0] else None
-        return dx, ds1, dh1, ds2, dh2, dw1, dw2, None, None, None
+        return dx, ds1, dh1, ds2, dh2, dw1, dw2, None
 
 
 class _ResBlockBf16Fn(Function):
@@ -980,45 +963,9 @@ def res_block_fusable(x, w1, w2, s1, s2):
     return True
 
 
-def residual_block(x, s1, h1, s2, h2, w1, w2, eps=1e-5, v_in=None, emit_v=False):
-    """cbin2(c2(relu(cbin1(c1(x))))) + x with (scale, shift) = (s1, h1), (s2, h2) -- see _ResBlockFn.
-    ``v_in``: the F(4x4,3x3) transformed-input image of x, written by x's producer (``emit_v`` of the previous block, or
-    ``instance_norm_act_v``): c1 starts from it and no input-transform pass reads x.  ``emit_v``: -> (out, V image of out) for
-    the next block."""
-    return _ResBlockFn.apply(x, s1, h1, s2, h2, w1, w2, eps, v_in, emit_v)
-
-
-class _NormActVFn(Function):
-    """instance_norm_act on a 32x32 map that ALSO writes the result's F(4x4,3x3) transformed-input image for the layer that
-    consumes it next (``srgan_instnorm_fwd_vy``): -> (y, V).  Backward = _InstNormFn's (V is a by-product, not differentiable)."""
-
-    @staticmethod
-    def forward(ctx, x, scale, shift, weight_next, act, slope, eps):
-        lib = _lib.load()
-        x = to_nhwc(x)
-        n, c, h, w = x.shape
-        desc = _conv_desc(n, h, w, c, h, w, weight_next.shape[0], 3, 3, 1, 1, PAD_ZERO, weight_next)
-        nv = lib.srgan_conv2d_packed_scratch(ctypes.byref(desc), 0)
-        v = torch.empty(max(nv, 16), dtype=torch.uint8, device=x.device)
-        y = torch.empty_like(x)
-        mean = torch.empty(n * c, dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
-        _lib.check(lib.srgan_instnorm_fwd_vy(ctypes.byref(desc), _ptr(x), _ptr(scale), _ptr(shift), None, _ptr(y), _ptr(mean), _ptr(rstd),
-                                             _ptr(v), v.numel(), float(eps), act, float(slope), _stream()), "instnorm_fwd_vy")
-        ctx.act, ctx.slope, ctx.has_res = act, slope, False
-        ctx.save_for_backward(x, scale, shift, mean, rstd)
-        ctx.mark_non_differentiable(v)
-        return y, v
-
-    @staticmethod
-    def backward(ctx, gy, _gv=None):
-        dx, dscale, dshift, _, _, _, _ = _InstNormFn.backward(ctx, gy)
-        return dx, dscale, dshift, None, None, None, None
-
-
-def instance_norm_act_v(x, scale, shift, weight_next, act=ACT_NONE, slope=0.0, eps=1e-5):
-    """-> (act(instance_norm(x) * scale + shift), its F(4x4,3x3) V image for the 3x3 layer with ``weight_next``)."""
-    return _NormActVFn.apply(x, scale, shift, weight_next, act, slope, eps)
+def residual_block(x, s1, h1, s2, h2, w1, w2, eps=1e-5):
+    """cbin2(c2(relu(cbin1(c1(x))))) + x with (scale, shift) = (s1, h1), (s2, h2) -- see _ResBlockFn."""
+    return _ResBlockFn.apply(x, s1, h1, s2, h2, w1, w2, eps)
 
 
 def norm_act_conv_fusable(x, weight):

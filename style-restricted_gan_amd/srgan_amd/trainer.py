@@ -480,8 +480,6 @@ class SRGAN_training():
             Gm = dp.unwrap(self.G)
             widest = max(int(Gm.down_convs[0].weight.shape[0]), 3) * src.shape[2] * src.shape[3] * 4
             per_group = max(1, min(k - 1, (((1 << 32) - (1 << 26)) // widest) // nb))
-            if os.environ.get("SRGAN_TRANSLATE_GROUP"):        # A/B: translations per no-grad generator pass
-                per_group = max(1, min(per_group, int(os.environ["SRGAN_TRANSLATE_GROUP"])))
             with torch.no_grad():
                 for lo in range(0, k - 1, per_group):
                     zs = noises[lo:min(lo + per_group, k - 1)]
