@@ -438,7 +438,6 @@ class fused_param_grads:
     def __exit__(self, et, ev, tb):
         global _grad_sink
         sink, _grad_sink = _grad_sink, self._prev
-        _side_join()
         if et is None and sink:
             with torch.no_grad():
                 for p, buf in sink.values():
@@ -465,64 +464,18 @@ def _sink_slots(*params):
     return [_grad_sink[id(p)][1] for p in params], seen[0]
 
 
-# Weight gradients are needed at the optimiser step only, while the input gradient of the same layer is what the rest of the
-# backward waits for.  Inside a ``fused_param_grads`` scope the weight-gradient launches (and their slab reduces) go to a SIDE
-# stream, ordered behind what the compute stream has queued so far by an event; the backward chain continues on the compute
-# stream at once.  Both kinds of kernel fill the chip on their own, so what is gained is the tails: the last, partially filled
-# round of one kernel runs beside the first round of the other (and the drain / launch gap between dependent kernels
-# disappears).  The scope's exit joins the side stream.  Tensors the side launches read are kept alive until that join (the
-# caching allocator would otherwise hand their memory to later compute-stream allocations); each stream has its own workspace.
-_side_streams = {}
-_side_keep = []
-_side_used = False
-_WGRAD_SIDE = not _os.environ.get("SRGAN_NO_WGRAD_SIDE_STREAM")
+class _wgrad_accumulate:
+    """``srgan_set_wgrad_accumulate`` around the weight-gradient calls of one Function.backward (thread-local in the library)."""
 
-
-def _side_stream(device):
-    st = _side_streams.get(device.index)
-    if st is None:
-        st = _side_streams[device.index] = torch.cuda.Stream(device=device)
-    return st
-
-
-def _side_join():
-    global _side_used
-    if _side_used:
-        for idx, st in _side_streams.items():
-            torch.cuda.current_stream(torch.device("cuda", idx)).wait_stream(st)
-        _side_used = False
-    _side_keep.clear()
-
-
-class _wgrad_scope:
-    """Around the weight-gradient launches of one Function.backward: ``srgan_set_wgrad_accumulate`` (thread-local in the
-    library) when the sink already holds a first contribution, and -- when the gradients go to the sink (``side``) -- the side
-    stream (see above).  ``keep``: every tensor those launches read or write."""
-
-    def __init__(self, accumulate, side, keep=()):
-        self._acc, self._side, self._keep = bool(accumulate), bool(side) and _WGRAD_SIDE and _grad_sink is not None, keep
-        self._ctx = None
+    def __init__(self, on):
+        self._on = bool(on)
 
     def __enter__(self):
-        global _side_used
-        if self._acc:
+        if self._on:
             _lib.load().srgan_set_wgrad_accumulate(1)
-        if self._side:
-            dev = next(t.device for t in self._keep if t is not None)
-            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            _side_keep.extend(t for t in self._keep if t is not None)
-            _side_used = True
-            self._ctx = torch.cuda.stream(side)
-            self._ctx.__enter__()
-        return self
 
     def __exit__(self, *exc):
-        if self._ctx is not None:
-            self._ctx.__exit__(*exc)
-        if self._acc:
+        if self._on:
             _lib.load().srgan_set_wgrad_accumulate(0)
         return False
 
@@ -595,7 +548,7 @@ class _Conv2dFn(Function):
                     db = torch.empty(weight.shape[0], dtype=torch.float32, device=weight.device)
             desc = ConvDesc.from_buffer_copy(ctx.desc)
             desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
-            with _wgrad_scope(acc, slots is not None, (x, gy, dw, db, ctx.v_image)):
+            with _wgrad_accumulate(acc):
                 _run_conv_wgrad(desc, x, gy, dw, db, ctx.v_image)
             if slots is not None:
                 dw = db = None
@@ -647,7 +600,7 @@ class _ConvTranspose2dFn(Function):
             (dw,), acc = slots if slots is not None else ([torch.empty(weight.shape, dtype=torch.float32, device=weight.device)], False)
             desc = ConvDesc.from_buffer_copy(ctx.desc)
             desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
-            with _wgrad_scope(acc, slots is not None, (x, gy, dw)):
+            with _wgrad_accumulate(acc):
                 _run_conv_wgrad(desc, gy, x, dw, None)
             if slots is not None:
                 dw = None
@@ -751,7 +704,7 @@ class _NormActConvFn(Function):
             (dw,), acc = slots if slots is not None else ([torch.empty(weight.shape, dtype=torch.float32, device=weight.device)], False)
             desc = ConvDesc.from_buffer_copy(ctx.desc)
             desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
-            with _wgrad_scope(acc, slots is not None and ctx.v_image is not None, (gy, dw, ctx.v_image)):
+            with _wgrad_accumulate(acc):
                 if ctx.v_image is not None:
                     _run_conv_wgrad(desc, None, gy, dw, None, ctx.v_image)
                 else:   # no V kept (layer outside the F(4x4,3x3) weight-gradient geometry): recompute the normalised input
@@ -853,9 +806,9 @@ class _ResBlockFn(Function):
             (dw,), acc = slots if slots is not None else ([torch.empty(weight.shape, dtype=torch.float32, device=dev)], False)
             dd = ConvDesc.from_buffer_copy(desc)
             dd.sO, dd.sI, dd.sH, dd.sW = dw.stride()
-            with _wgrad_scope(acc, slots is not None, (v_fwd, zimg, dw)):
-                ws, nb = _conv_ws(dd, dev)              # (the side stream has its own workspace)
-                _lib.check(lib.srgan_conv2d_wgrad_vz(ctypes.byref(dd), _ptr(v_fwd), _ptr(zimg), _ptr(dw), _ptr(ws), nb, _stream()),
+            ws, nb = _conv_ws(dd, dev)
+            with _wgrad_accumulate(acc):
+                _lib.check(lib.srgan_conv2d_wgrad_vz(ctypes.byref(dd), _ptr(v_fwd), _ptr(zimg), _ptr(dw), _ptr(ws), nb, st),
                            "conv2d_wgrad_vz")
             return None if slots is not None else dw
 
@@ -948,9 +901,9 @@ class _ResBlockBf16Fn(Function):
             (dw,), acc = slots if slots is not None else ([torch.empty(weight.shape, dtype=torch.float32, device=dev)], False)
             dd = ConvDesc.from_buffer_copy(desc)
             dd.sO, dd.sI, dd.sH, dd.sW = dw.stride()
-            with _wgrad_scope(acc, slots is not None, (xin, dy, dw)):
-                ws, nb = _conv_ws(dd, dev)
-                _lib.check(lib.srgan_halo16_wgrad(ctypes.byref(dd), _ptr(xin), xin16, _ptr(dy), 1, _ptr(dw), _ptr(ws), nb, _stream()),
+            ws, nb = _conv_ws(dd, dev)
+            with _wgrad_accumulate(acc):
+                _lib.check(lib.srgan_halo16_wgrad(ctypes.byref(dd), _ptr(xin), xin16, _ptr(dy), 1, _ptr(dw), _ptr(ws), nb, st),
                            "halo16_wgrad")
             return None if slots is not None else dw
 
