@@ -131,7 +131,7 @@ def cpu_baseline(size, k, batch):
     orc_w.train(x2, l2)                                   # warm-up (thread pool, allocator, oneDNN primitives): k=1, 4 images
     log(f"cpu baseline: timed steps at batch {batch}")
     steps, dt = 0, 0.0
-    while steps < 2 and (steps == 0 or dt < 40.0):        # bounded sample: ~10-30 s of CPU work on the GPU box's host cores
+    while steps < 2 and (steps == 0 or dt < 15.0):        # bounded sample: ~10-30 s of CPU work on the GPU box's host cores
         x, label = ot.synthetic_batch(batch, size, 4, seed=3 + steps)
         t0 = time.perf_counter()
         orc.train(x, label)

@@ -487,7 +487,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 }
 
 // ---- weight repack ------------------------------------------------------------------------
-__global__ void pack_weights_kernel(PackParams p) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackParams p) {
+  if (pack_weights_block_ok(p)) {
+    __shared__ float tile[PACK_LDS_FLOATS];
+    pack_weights_rows(p, tile);
+    return;
+  }
   const long long total = pack_weights_total(p);
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x)
@@ -497,13 +502,15 @@ __global__ void pack_weights_kernel(PackParams p) {
 // every cached operand of a network in one launch: blockIdx.y = entry, blockIdx.x grid-strides over its elements
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackEntry* __restrict__ entries) {
   const PackEntry& e = entries[blockIdx.y];
+  __shared__ float tile[PACK_LDS_FLOATS];
+  static_assert(PACK_LDS_FLOATS >= 32 * WP43_ROW, "one LDS tile serves both cooperative paths");
   if (e.type == 0) {
+    if (pack_weights_block_ok(e.ig)) { pack_weights_rows(e.ig, tile); return; }
     const long long total = pack_weights_total(e.ig);
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x)
       pack_weights_item(e.ig, idx);
   } else if (wino43_pack_block_ok(e.wn)) {
-    __shared__ float tile[32 * WP43_ROW];
     const long long total = wino_pack_total(e.wn);       // a multiple of 256 (nchunk % 4 == 0)
     for (long long base = (long long)blockIdx.x * 256; base < total; base += (long long)gridDim.x * 256)
       wino43_pack_block(e.wn, base, tile);

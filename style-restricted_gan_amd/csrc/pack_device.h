@@ -38,6 +38,52 @@ __device__ __forceinline__ void pack_weights_item(const PackParams& p, long long
   p.dst[idx] = v;
 }
 
+// The same rows for one WORKGROUP of 256 threads: one (phase, n) row of K = taps x Cs entries at a time.  With OIHW weights the
+// row's source is Cs runs of `taps` contiguous floats (mode 0: ONE contiguous run of Cs * taps floats), read tap-fastest --
+// lanes walk along memory -- into LDS [tap][Cs + 1] and written back channel-fastest, the destination order: both sides
+// coalesced, where the one-thread-per-entry loop reads 4 bytes every taps * 4 bytes (36-64 B apart) and walks the weight tensor
+// `taps` times.  Pure data movement: identical bytes.  PACK_LDS_FLOATS bounds taps * (Cs + 1).
+constexpr int PACK_LDS_FLOATS = 12288;
+__device__ __host__ __forceinline__ bool pack_weights_block_ok(const PackParams& p) {
+  return (long long)p.Ty * p.Tx * (p.Cs + 1) <= PACK_LDS_FLOATS && p.Cs >= 8;
+}
+__device__ __forceinline__ void pack_weights_rows(const PackParams& p, float* tile) {
+  const int taps = p.Ty * p.Tx, LD = p.Cs + 1;
+  const long long rows = (long long)p.phases * p.Npad;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = (int)(row % p.Npad), phase = (int)(row / p.Npad);
+    float* dst = p.dst + row * p.Kpad;
+    if (n >= p.N) {
+      for (int k = threadIdx.x; k < p.Kpad; k += blockDim.x) dst[k] = 0.f;
+      continue;
+    }
+    __syncthreads();                      // the previous row has left the tile
+    for (int i = threadIdx.x; i < taps * p.Cs; i += blockDim.x) {
+      const int c = i / taps, t = i - c * taps;
+      const int ty = t / p.Tx, tx = t - ty * p.Tx;
+      float v = 0.f;
+      if (p.mode == 0) {
+        v = p.w[n * p.sO + c * p.sI + ty * p.sH + tx * p.sW];
+      } else {
+        const int py = phase / p.stride, px = phase % p.stride;
+        const int ky = (py + p.pad) % p.stride + p.stride * ty;
+        const int kx = (px + p.pad) % p.stride + p.stride * tx;
+        if (ky < p.kh && kx < p.kw) v = p.w[c * p.sO + n * p.sI + ky * p.sH + kx * p.sW];
+      }
+      tile[t * LD + c] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < p.Kpad; k += blockDim.x) {
+      float v = 0.f;
+      if (k < p.K) {
+        const int t = k / p.Cs, c = k - t * p.Cs;
+        v = tile[t * LD + c];
+      }
+      dst[k] = v;
+    }
+  }
+}
+
 struct WinoPackParams {
   const float* w;
   float* dst;

@@ -954,3 +954,29 @@ def test_d_losses_lincomb_kl_normal(ops):
     close(kl, want, 1e-5)
     close(a.grad, ra.grad, 1e-5)
     close(b.grad, rb.grad, 1e-5)
+
+
+@pytest.mark.parametrize("o,i,k,s,p", [(128, 64, 4, 2, 1), (96, 40, 3, 1, 1), (512, 256, 4, 2, 1), (64, 3, 4, 2, 1)])
+def test_multi_pack_launch_equals_single_pack_implicit_gemm(ops, o, i, k, s, p):
+    """The implicit-GEMM operands ([phase][Npad][(tap, channel)] with zero padding) through the per-layer pack kernel and through
+    the multi-layer launch: identical bytes, forward and input-gradient (per-output-phase) operands; the map is small enough
+    that no Winograd form applies.  Both take the row-cooperative path (a (phase, n) row transposed through LDS) where it fits."""
+    w = (rnd(o, i, k, k, seed=11) / np.sqrt(i * k * k)).cuda().requires_grad_(True)
+    x = rnd(2, i, 8, 8, seed=12).cuda().requires_grad_(True)
+    ops.invalidate_packed()
+    try:
+        with ops.pack_cache():
+            y = ops.conv2d(x, w, None, s, p)
+            y.sum().backward()
+            hits = [h for h in ops._pack_cache.values() if h.weight is w]
+            assert len(hits) == 2
+            single = [h.buf.clone() for h in hits]
+            for h in hits:
+                h.buf.fill_(255)
+            ops.refresh_packed([w], force=True)
+            for h, sgl in zip(hits, single):
+                assert torch.equal(h.buf, sgl), (h.kind, o, i, k)
+        ref = F.conv2d(x.detach().cpu(), w.detach().cpu(), None, s, p)
+        close(y, ref, 2e-5)
+    finally:
+        ops.invalidate_packed()
