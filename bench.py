@@ -356,7 +356,8 @@ def main():
         ws = int(os.environ.get("WORLD_SIZE", "1"))
         if ws > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo", rank=int(os.environ.get("RANK", "0")), world_size=ws)
+            with dp._stdout_to_stderr():         # gloo's connection banner must not precede the JSON line on stdout
+                dist.init_process_group("gloo", rank=int(os.environ.get("RANK", "0")), world_size=ws)
         if ws != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}")
         return launch_check(int(os.environ.get("RANK", "0")), ws, "unopened")

@@ -48,7 +48,8 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if use_gpu else "gloo")
-        dist.init_process_group(backend, rank=rk, world_size=ws)
+        with _stdout_to_stderr():
+            dist.init_process_group(backend, rank=rk, world_size=ws)
         if backend == "nccl":
             # create the RCCL communicator HERE, on the main thread and on this rank's device: otherwise the first collective
             # -- a bucket all-reduce issued from an autograd hook in the backward thread of step 0 -- would also be the one
@@ -402,6 +403,25 @@ def launch_pending(then_wait=None):
 _control = None
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """gloo announces its connections on the process's stdout ("[Gloo] Rank 0 is connected to ..."): a launcher that expects ONE
+    JSON line there (bench.py's contract) must not see it -- route file descriptor 1 to stderr while a gloo group is made."""
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def control_group():
     """Host-side agreement between ranks (which execution mode a step takes, whether a recording succeeded) travels over a
     gloo group on CPU tensors: no RCCL kernel in the compute stream and no device synchronisation to read the answer.
@@ -409,7 +429,11 @@ def control_group():
     every rank reaches at the same point of its program."""
     global _control
     if _control is None:
-        _control = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+        if dist.get_backend() == "gloo":
+            _control = dist.group.WORLD
+        else:
+            with _stdout_to_stderr():
+                _control = dist.new_group(backend="gloo")
     return _control
 
 
