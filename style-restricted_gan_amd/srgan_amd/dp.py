@@ -54,9 +54,11 @@ def init_from_env(backend=None):
             # create the RCCL communicator HERE, on the main thread and on this rank's device: otherwise the first collective
             # -- a bucket all-reduce issued from an autograd hook in the backward thread of step 0 -- would also be the one
             # that initialises it
-            warm = torch.zeros(1, device=device)
-            dist.all_reduce(warm)
-            torch.cuda.synchronize(device)
+            # (RCCL prints its version banner on stdout when the communicator comes up: keep it off the JSON line's channel)
+            with _stdout_to_stderr():
+                warm = torch.zeros(1, device=device)
+                dist.all_reduce(warm)
+                torch.cuda.synchronize(device)
         global _control
         _control = None
         control_group()
