@@ -711,7 +711,11 @@ extern "C" int srgan_instnorm_fwd(const float* x, const float* scale, const floa
   }
   float2* part = reinterpret_cast<float2*>(ws);
   dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
-  if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4, g, dim3(256), 0, st, x, part, HW, C, S, rps);
+  static const bool exp_skip = std::getenv("SRGAN_EXP_SKIP_STATS") != nullptr;      // timing experiment (wrong results): no statistics pass
+  if (exp_skip) {      // one row per split: finite statistics from a negligible read
+    if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4, g, dim3(256), 0, st, x, part, HW, C, S, 1);
+    else hipLaunchKernelGGL(in_stats_partial, g, dim3(256), 0, st, x, part, HW, C, S, 1);
+  } else if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4, g, dim3(256), 0, st, x, part, HW, C, S, rps);
   else hipLaunchKernelGGL(in_stats_partial, g, dim3(256), 0, st, x, part, HW, C, S, rps);
   hipLaunchKernelGGL(in_stats_final, dim3((N * C + 255) / 256), dim3(256), 0, st, x, (const float2*)part, mean, rstd, N, HW, C, S, eps);
   const long long total = (long long)N * HW * C;
