@@ -138,6 +138,11 @@ int halo16_wgrad_run(const srgan_conv_desc* d, const void* x, const void* dy, fl
                      bool x16 = false, bool d16 = false);
 
 // conv_rgbin.hip: 3-channel-input 7x7 stride-1 layers on the MFMA (LDS-staged halo)
+// conv_rgbout.hip: 7x7 / stride-1 / pad-3 layers with <= 4 OUTPUT channels on the 4x4x1 MFMA (direct, LDS-resident halo and filter)
+bool rgbout_applicable(const srgan_conv_desc* d);
+size_t rgbout_packed_elems(const srgan_conv_desc* d);
+int rgbout_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st);
+int rgbout_run(const srgan_conv_desc* d, const float* x, const float* packed, const float* bias, float* y, hipStream_t st);
 bool rgbin_applicable(const srgan_conv_desc* d);
 size_t rgbin_packed_elems(const srgan_conv_desc* d);
 int rgbin_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st);

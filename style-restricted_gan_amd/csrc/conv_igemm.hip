@@ -44,8 +44,8 @@ static const char* const kProfNames[] = {
     "wgrad_kernel<gen>", "wgrad_kernel<vec>", "igemm_kernel<256,128,4,2,gen>", "igemm_kernel<256,128,4,2,vec>",
     "igemm_kernel<256,64,4,2,gen>", "igemm_kernel<256,64,4,2,vec>", "wino_kernel", "wino_wgrad_kernel", "wino_kernel<4x4s2>", "wino_wgrad_kernel<4x4s2>",
     "wino43_kernel", "wino43_input_kernel", "rgbin_conv_kernel", "rgb_wgrad_kernel", "wino43_wgrad_kernel", "wino43_dy_kernel",
-    "halo16_kernel", "halo16_wgrad_kernel", "halo16s2_wgrad_kernel", "halo16t_kernel"};
-constexpr int kProfKernels = 28;
+    "halo16_kernel", "halo16_wgrad_kernel", "halo16s2_wgrad_kernel", "halo16t_kernel", "rgbout_conv_kernel"};
+constexpr int kProfKernels = 29;
 
 struct ProfScope {
   bool on;
@@ -1288,7 +1288,10 @@ static bool rowconv_applicable(const srgan_conv_desc* d) {
 }
 constexpr int RC_N = 21, RC_NPAD = 32;
 static size_t rowconv_weight_elems(const srgan_conv_desc* d) { return (size_t)RC_NPAD * d->kh * d->I; }
+// (round 3: where conv_rgbout.hip's direct 4x4x1-MFMA kernel applies it takes the layer over -- same dispatch slot, own packed
+// filter, no intermediate)
 static size_t rowconv_packed_elems(const srgan_conv_desc* d) {
+  if (rgbout_applicable(d)) return rgbout_packed_elems(d);
   return round_up((long long)rowconv_weight_elems(d), 64) + (size_t)d->N * d->Ho * d->Wi * RC_N;
 }
 
@@ -1330,6 +1333,7 @@ __global__ void rowconv_shift_add_kernel(const float* __restrict__ P, const floa
 }
 
 static int rowconv_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st) {
+  if (rgbout_applicable(d)) return rgbout_pack(d, w, dst, st);
   const int total = RC_NPAD * d->kh * d->I;
   hipLaunchKernelGGL(rowconv_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, dst, d->sO, d->sI, d->sH, d->sW, d->I,
                      d->kh, d->kw);
@@ -1394,6 +1398,7 @@ static int fwd_pack(const srgan_conv_desc* d, int act, const float* w, float* ds
 
 // `packed` = [32 x 7*I weights | P scratch]
 static int rowconv_run(const srgan_conv_desc* d, const float* x, const float* packed, const float* bias, float* y, hipStream_t st) {
+  if (rgbout_applicable(d)) return rgbout_run(d, x, packed, bias, y, st);
   float* P = const_cast<float*>(packed) + round_up((long long)rowconv_weight_elems(d), 64);
   IgemmParams p{};
   p.src = x; p.wp = packed; p.bias = nullptr; p.dst = P;

@@ -85,6 +85,9 @@ CONV_CASES = [
     (2, 64, 16, 64, 128, 4, 2, 1, False, False),  # 64 -> 128 down conv on an 8 x 32 output map (bf16 mode: input gradient on the transposed patch kernel)
     (1, 128, 8, 64, 256, 4, 2, 1, False, False),  # 128 -> 256 down conv, one output patch (same kernel, C = 256 reduce channels)
     (3, 64, 64, 128, 128, 4, 2, 1, False, True),  # same layer class on a wider map: 8 x 2 patches per image, bias
+    (2, 64, 40, 70, 3, 7, 1, 3, False, True),     # round 3: RGB head on the 4x4x1 MFMA (direct, LDS halo): ragged 32 x 64 tiles, bias
+    (3, 3, 128, 128, 64, 7, 1, 3, False, False),  # RGB input layer at full size: its input gradient on the same kernel (flipped, transposed filter)
+    (2, 32, 64, 96, 3, 7, 1, 3, False, False),    # same kernel, 32 reduce channels (8 channel quads), 2 column tiles
     (4, 64, 62, 62, 128, 3, 1, 1, True, False),   # the encoder's own shapes (round 3): E.layers.0.cmp, 62 x 62, reflect padding
     (4, 128, 31, 31, 128, 3, 1, 1, True, True),   # E.layers.1 on 31 x 31, reflect, bias
     (8, 64, 30, 22, 64, 3, 1, 1, False, True),    # even but not multiple-of-4 map, zero padding, bias
