@@ -10,27 +10,37 @@
 // 32x32x2 form).  Here block b = four consecutive output pixels of a row, j = output channel (3 of 4 used: 75 % of the pipe),
 // one instruction per reduce index (ky, kx, c): a DIRECT convolution, nothing but x, w and y ever leaves the chip.
 //
-//   workgroup (8 waves) = 32 rows x 64 columns of one image; lane = pixel column, wave w = rows 4w .. 4w + 3 (4 accumulators
-//   of 4 registers);
-//   the reduce channels are walked in quads: the (32 + 6) x (64 + 6) halo of ONE channel quad is 16 bytes per pixel in LDS
-//   (42.5 KB, double-buffered, consecutive lanes read consecutive 16-byte slots: conflict-free ds_read_b128), so the A operands of
-//   the four instructions (pixel, tap, c .. c + 3) are one read; the whole packed filter (7 x 7 x C x 4 floats = 50 KB at C = 64)
-//   sits in LDS as [ky][quad][kx][cout][4 c] and the B operands of a (ky, quad) -- 7 reads -- stay in registers for the wave's
-//   four rows: 5 LDS reads per 16 instructions;
-//   global loads of the next quad's halo are issued before the current quad's 784 instructions per wave and written to the other
-//   buffer after them: one barrier per quad.
-// 128x128 maps at batch 32 are 256 workgroups: one round.
+//   workgroup (8 waves) = 16 rows x 64 columns of one image; lane = pixel column, wave w = rows 2w, 2w + 1 (2 accumulators of 4
+//   registers);
+//   the reduce channels are walked in chunks of 16: the (16 + 6) x (64 + 6) halo of a chunk sits in LDS as four channel-quad
+//   planes of 16 bytes per pixel (98.6 KB; consecutive lanes read consecutive 16-byte slots: conflict-free ds_read_b128), so the A
+//   operands of the four instructions (pixel, tap, c .. c + 3) are one read, and a pixel's 64 contiguous bytes are fetched by four
+//   adjacent lanes (a first version with one-quad chunks asked the texture path for 64 different lines per load instruction --
+//   16 bytes of each -- and spent as long on its halo as on its products: 194 -> 147 us without those loads);
+//   the whole packed filter (7 x 7 x C x 4 floats = 50 KB at C = 64) sits in LDS as [ky][quad][kx][cout][4 c]; an item =
+//   (quad, kx): seven filter reads + eight halo-row reads feed 56 instructions, ONE read of halo row r serving the (output row,
+//   ky) pairs with row + ky = r; two register sets, the next item's reads fenced in front of the current item's products;
+//   the next chunk's halo is loaded into registers (buffer loads: the range check supplies the zero padding) under the current
+//   chunk's 1568 instructions per wave and stored between two barriers (single LDS buffer).
+// 128x128 maps at batch 32 are 512 workgroups: two rounds.  Measured (scratch/rgbout_phases.py, -DRGBOUT_EXP=8 stamps): prologue
+// 5-6.6 us, 18 us per chunk against 14 for the instructions alone at the clock the chip holds under them; forward at batch 32
+// 172 us against 237 for the row convolution + shift-add, +0.6 % on the step.
 #include <algorithm>
 #include <cstdlib>
 #include "common.h"
 
+#ifndef RGBOUT_EXP
+#define RGBOUT_EXP 0
+#endif
+
 namespace srgan {
 namespace {
 
-constexpr int RO_TR = 32, RO_TC = 64, RO_K = 7, RO_PAD = 3;
-constexpr int RO_HR = RO_TR + RO_K - 1, RO_HC = RO_TC + RO_K - 1;      // 38 x 70 halo pixels
-constexpr int RO_HALO = RO_HR * RO_HC;                                  // 2660 pixels = float4 slots per buffer
-constexpr int RO_LOADS = (RO_HALO + 511) / 512;                         // halo pixels per thread and quad (6)
+constexpr int RO_TR = 16, RO_TC = 64, RO_K = 7, RO_PAD = 3, RO_T = 2;   // tile, taps, output rows per wave
+constexpr int RO_HR = RO_TR + RO_K - 1, RO_HC = RO_TC + RO_K - 1;      // 22 x 70 halo pixels
+constexpr int RO_HALO = RO_HR * RO_HC;                                  // 1540 pixels = float4 slots per quad plane
+constexpr int RO_CQ = 4;                                                // channel quads per chunk (16 channels)
+constexpr int RO_LOADS = (RO_HALO * RO_CQ + 511) / 512;                 // (pixel, quad) items per thread and chunk (13)
 constexpr int RO_MAXQ = 16;                                             // up to 64 reduce channels (the filter must fit LDS)
 
 struct RgboutParams {
@@ -41,8 +51,17 @@ struct RgboutParams {
   int NB, H, W, C, Ho, Wo, O, ncq, tiles_x, tiles_y;
 };
 
+constexpr unsigned kRoOutside = 0x80000000u;
+
+__device__ __forceinline__ auto ro_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 __global__ __launch_bounds__(512) void rgbout_conv_kernel(RgboutParams p) {
-  __shared__ f32x4 halo[2 * RO_HALO];                                   // [2][38 x 70 pixels] x 16 bytes = 85 KB
+  __shared__ f32x4 halo[RO_CQ * RO_HALO];                               // [4 quads][22 x 70 pixels] x 16 bytes = 98.6 KB
   __shared__ __attribute__((aligned(16))) float wl[RO_K * RO_MAXQ * RO_K * 16];      // [ky][quad][kx][4 couts][4 c]: 50 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int b = blockIdx.x;
@@ -51,78 +70,172 @@ __global__ __launch_bounds__(512) void rgbout_conv_kernel(RgboutParams p) {
   const int n = b / p.tiles_y;
   const int X0 = tx * RO_TC, Y0 = ty * RO_TR;
 
+#if RGBOUT_EXP & 8      // phase stamps (100 MHz wall clock) instead of the output: scratch/rgbout_phases.py
+  const long long t_start = wall_clock64();
+  long long t_pro = 0, t_chunk[4] = {0, 0, 0, 0};
+#endif
+  // the packed filter: all of a thread's loads are issued (with the first halo chunk's, below) before the first LDS store -- a
+  // load -> store loop paid one memory latency per trip and the prologue took 8 us of a workgroup's 78
   const int nw = RO_K * p.ncq * RO_K * 4;                               // float4 count of the packed filter
-  for (int e = tid; e < nw; e += 512) reinterpret_cast<f32x4*>(wl)[e] = reinterpret_cast<const f32x4*>(p.wp)[e];
+  constexpr int RO_WLOADS = (RO_K * RO_MAXQ * RO_K * 4 + 511) / 512;
+  const auto rs_w = ro_rsrc(p.wp, (unsigned)(nw * sizeof(f32x4)));
+  f32x4 wst[RO_WLOADS];
+#pragma unroll
+  for (int j = 0; j < RO_WLOADS; ++j)
+    wst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)((tid + 512 * j) * sizeof(f32x4)), 0, 0));
 
-  // this thread's halo pixels: byte-free offsets of channel quad 0, or -1 outside the image (zero padding)
-  long long hoff[RO_LOADS];
+  // this thread's (halo pixel, quad) items: element offsets of chunk 0, or -1 outside the image (zero padding); the four quads
+  // of a pixel are four adjacent lanes = 64 contiguous bytes
+  // byte offsets for buffer loads (rgbout_applicable: the input is under 2^31 bytes); kRoOutside is beyond every range the
+  // resource describes, so the hardware returns the zero padding and the loads need neither pointers nor branches
+  const auto rs_x = ro_rsrc(p.x, (unsigned)((size_t)p.NB * p.H * p.W * p.C * sizeof(float)));
+  unsigned hoff[RO_LOADS];
 #pragma unroll
   for (int j = 0; j < RO_LOADS; ++j) {
-    const int hp = tid + 512 * j;
+    const int it = tid + 512 * j;
+    const int hp = it >> 2, q = it & 3;
     const int r = hp / RO_HC, c = hp - r * RO_HC;
     const int gy = Y0 - RO_PAD + r, gx = X0 - RO_PAD + c;
     const bool ok = hp < RO_HALO && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-    hoff[j] = ok ? (((long long)n * p.H + gy) * p.W + gx) * p.C : -1;
+    hoff[j] = ok ? (unsigned)((((n * p.H + gy) * p.W + gx) * p.C + q * 4) * (int)sizeof(float)) : kRoOutside;
   }
   f32x4 stage[RO_LOADS];
-  auto load_quad = [&](int cq) __attribute__((always_inline)) {
+  auto load_chunk = [&](int ch) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < RO_LOADS; ++j)
-      stage[j] = hoff[j] >= 0 ? *reinterpret_cast<const f32x4*>(p.x + hoff[j] + cq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      stage[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, hoff[j], ch * (RO_CQ * 4 * (int)sizeof(float)), 0));
   };
-  auto store_quad = [&](int buf) __attribute__((always_inline)) {
+  auto store_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < RO_LOADS; ++j) {
-      const int hp = tid + 512 * j;
-      if (hp < RO_HALO) halo[buf * RO_HALO + hp] = stage[j];
+      const int it = tid + 512 * j;
+      if ((it >> 2) < RO_HALO) halo[(it & 3) * RO_HALO + (it >> 2)] = stage[j];
     }
   };
 
-  f32x4 acc[4];
+  // one accumulator per (output row, channel of the quad): 8 independent chains, so an instruction never waits for the result of
+  // one issued fewer than 8 instructions earlier (with one accumulator per row the two rows' chains alternated: 147 -> 169 us)
+  f32x4 acc[RO_T][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < RO_T; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[t][e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_quad(0);
-  store_quad(0);
+  const int nchunk = p.ncq / RO_CQ;
+  load_chunk(0);
+#pragma unroll
+  for (int j = 0; j < RO_WLOADS; ++j)
+    if (tid + 512 * j < nw) reinterpret_cast<f32x4*>(wl)[tid + 512 * j] = wst[j];
+  store_chunk();
   __syncthreads();
   const int co4 = (lane & 3) * 4;
-  for (int cq = 0; cq < p.ncq; ++cq) {
-    if (cq + 1 < p.ncq) load_quad(cq + 1);
-    const f32x4* H = halo + (cq & 1) * RO_HALO + (4 * wave) * RO_HC + lane;
-#pragma unroll 1
-    for (int ky = 0; ky < RO_K; ++ky) {
-      f32x4 B[RO_K];
-      const float* wq = wl + ((ky * p.ncq + cq) * RO_K) * 16 + co4;
+#if RGBOUT_EXP & 8
+  t_pro = wall_clock64();
+#endif
+  for (int ch = 0; ch < nchunk; ++ch) {
+#if !(RGBOUT_EXP & 1)   // -DRGBOUT_EXP=<bits>: timing ablations (wrong results): 1 no in-loop halo loads, 2 no in-loop LDS reads, 4 no stores/barriers
+    if (ch + 1 < nchunk) load_chunk(ch + 1);
+#endif
+    // (quad, kx) items of the chunk, two register sets: the 15 reads of item i + 1 are issued before the 56 instructions of item i
+    // and nothing may be scheduled across the fence between them (left alone, the compiler sinks each read to just before its
+    // first use and the wave waits out the LDS latency fifteen times per item: 170 us instead of ~110)
+    const f32x4* Hw = halo + (RO_T * wave) * RO_HC + lane;
+    const float* wq = wl + (size_t)ch * RO_CQ * RO_K * 16 + co4;
+    auto fetch_b = [&](f32x4 (&B)[RO_K], int it) __attribute__((always_inline)) {
+      const int q = it / RO_K, kx = it - q * RO_K;
 #pragma unroll
-      for (int kx = 0; kx < RO_K; ++kx) B[kx] = *reinterpret_cast<const f32x4*>(wq + kx * 16);
+      for (int ky = 0; ky < RO_K; ++ky) B[ky] = *reinterpret_cast<const f32x4*>(wq + ((ky * p.ncq + q) * RO_K + kx) * 16);
+    };
+    auto fetch_a = [&](f32x4 (&A)[RO_T + RO_K - 1], int it) __attribute__((always_inline)) {
+      const int q = it / RO_K, kx = it - q * RO_K;
 #pragma unroll
-      for (int kx = 0; kx < RO_K; ++kx) {
-        f32x4 A[4];
+      for (int r = 0; r < RO_T + RO_K - 1; ++r) A[r] = Hw[q * RO_HALO + r * RO_HC + kx];
+    };
+    auto products = [&](const f32x4 (&B)[RO_K], const f32x4 (&A)[RO_T + RO_K - 1], int r0, int r1) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) A[t] = H[(t + ky) * RO_HC + kx];
+      for (int r = r0; r < r1; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[t][e], B[kx][e], acc[t], 0, 0, 0);
-      }
+          for (int ky = 0; ky < RO_K; ++ky) {
+            const int t = r - ky;
+            if (t >= 0 && t < RO_T) acc[t][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[r][e], B[ky][e], acc[t][e], 0, 0, 0);
+          }
+    };
+    // the next item's 7 filter reads go out before the first half of this item's products and its 8 halo reads before the second
+    // half, so every wait is for reads a half-item old (s_waitcnt counts at most 15 and a merge point takes the strictest count:
+    // no conditional fetch -- the last item is simply fetched twice)
+    constexpr int NIT = RO_CQ * RO_K, RH = (RO_T + RO_K - 1) / 2, RE = RO_T + RO_K - 1;
+    f32x4 B0[RO_K], A0[RE], B1[RO_K], A1[RE];
+    fetch_b(B0, 0);
+    fetch_a(A0, 0);
+#pragma unroll 1
+    for (int it = 0; it < NIT; it += 2) {
+#if RGBOUT_EXP & 2
+      if (it == 0) { fetch_b(B1, 1); fetch_a(A1, 1); }
+#else
+      fetch_b(B1, it + 1);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      products(B0, A0, 0, RH);
+      __builtin_amdgcn_sched_barrier(0);
+#if !(RGBOUT_EXP & 2)
+      fetch_a(A1, it + 1);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      products(B0, A0, RH, RE);
+      __builtin_amdgcn_sched_barrier(0);
+      const int nx = it + 2 < NIT ? it + 2 : NIT - 1;
+#if !(RGBOUT_EXP & 2)
+      fetch_b(B0, nx);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      products(B1, A1, 0, RH);
+      __builtin_amdgcn_sched_barrier(0);
+#if !(RGBOUT_EXP & 2)
+      fetch_a(A0, nx);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      products(B1, A1, RH, RE);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (cq + 1 < p.ncq) store_quad((cq + 1) & 1);
+#if !(RGBOUT_EXP & 4)
+    __syncthreads();                       // every wave is done with this chunk's halo
+    if (ch + 1 < nchunk) store_chunk();
     __syncthreads();
+#endif
+#if RGBOUT_EXP & 8
+    if (ch < 4) t_chunk[ch] = wall_clock64();
+#endif
   }
+#if RGBOUT_EXP & 8
+#pragma unroll
+  for (int t = 0; t < RO_T; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(acc[t][e]));
+  if (tid == 0) {
+    long long* o = reinterpret_cast<long long*>(p.y) + (size_t)blockIdx.x * 8;
+    o[0] = t_start; o[1] = t_pro; o[2] = t_chunk[0]; o[3] = t_chunk[1]; o[4] = t_chunk[2]; o[5] = t_chunk[3]; o[6] = wall_clock64();
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    o[7] = ((long long)xcc << 32) | hw;
+  }
+  if (p.O >= 0) return;
+#endif
 
   // D[pixel 4b + i][cout j] sits in register i of lane 4b + j: lane = (pixel group, cout)
   const int co = lane & 3, pg = lane >> 2;
   if (co < p.O) {
     const float bv = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int oy = Y0 + 4 * wave + t;
+    for (int t = 0; t < RO_T; ++t) {
+      const int oy = Y0 + RO_T * wave + t;
       if (oy >= p.Ho) continue;
       float* row = p.y + (((size_t)n * p.Ho + oy) * p.Wo) * p.O + co;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ox = X0 + 4 * pg + i;
-        if (ox < p.Wo) row[(size_t)ox * p.O] = acc[t][i] + bv;
+        if (ox < p.Wo) row[(size_t)ox * p.O] = ((acc[t][0][i] + acc[t][1][i]) + (acc[t][2][i] + acc[t][3][i])) + bv;
       }
     }
   }
@@ -147,8 +260,8 @@ bool rgbout_applicable(const srgan_conv_desc* d) {
   static const bool off = std::getenv("SRGAN_NO_RGBOUT") != nullptr;
   if (off) return false;
   return d->O >= 1 && d->O <= 4 && d->kh == RO_K && d->kw == RO_K && d->stride == 1 && d->pad == RO_PAD && d->pad_mode == SRGAN_PAD_ZERO &&
-         d->I % 4 == 0 && d->I >= 16 && d->I <= 4 * RO_MAXQ && d->Wo >= 64 && d->Ho >= 32 && d->Hi == d->Ho &&
-         d->Wi == d->Wo && (long long)d->N * d->Hi * d->Wi * d->I < (1LL << 31);
+         d->I % 16 == 0 && d->I >= 16 && d->I <= 4 * RO_MAXQ && d->Wo >= 64 && d->Ho >= 32 && d->Hi == d->Ho &&
+         d->Wi == d->Wo && (long long)d->N * d->Hi * d->Wi * d->I * 4 < (1LL << 31);
 }
 
 size_t rgbout_packed_elems(const srgan_conv_desc* d) { return (size_t)RO_K * (d->I / 4) * RO_K * 16; }
