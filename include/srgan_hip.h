@@ -122,6 +122,19 @@ int srgan_conv2d_pack_multi(const void* entries_dev, int n_entries, void* stream
  * (dw += ...): the reference's autograd sums the two uses of the generator's weights inside one backward call
  * (util_notebook.py:664, :689; torch's AccumulateGrad input buffer) -- here without a separate elementwise pass. */
 int srgan_set_wgrad_accumulate(int on);
+
+/* Deferred slab sums (round 3).  Every weight-gradient entry point ends in a split-K slab sum of ~12 us that cannot fill the
+ * chip; the reference's step has 145 of them.  Between srgan_wgrad_defer_begin(arena, bytes) and srgan_wgrad_defer_end()
+ * (process-wide -- autograd calls the entry points from its own thread -- so one backward pass at a time) a call made with bit 1 of the switch above set -- srgan_set_wgrad_accumulate(2 | accumulate): "nobody reads dw
+ * before _end", true for the gradient buffers autograd's AccumulateGrad (util_notebook.py:664, :689 `.backward()`) would fill --
+ * takes its workspace from the arena (256-byte aligned device memory, the caller keeps it alive and untouched until _end; `ws`
+ * is then unused) and queues its sum; queued sums run as ONE launch when 40 are waiting, when the arena is full, when a second
+ * sum for the same dw arrives, and at _end -- all on the stream of the calls.  Same per-output loop and rounding as the
+ * immediate sums: identical bits.  dbias column sums are not deferred. */
+int srgan_wgrad_defer_begin(void* arena, size_t arena_bytes);
+int srgan_wgrad_defer_end(void);
+/* Process totals since load: slab sums that went through the queue, and the launches that ran them. */
+int srgan_wgrad_defer_stats(long long* sums, long long* launches);
 int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, const float* dy, float* dw,
                        float* dbias, void* ws, size_t ws_bytes, void* stream);
 

@@ -906,46 +906,127 @@ struct WgradReduceParams {
   int accumulate;      // 1: dw += the slab sum (a second use of the same weight in one backward pass: srgan_set_wgrad_accumulate)
 };
 
-__global__ void wgrad_reduce_kernel(WgradReduceParams p) {
-  const long long total = (long long)p.O * p.kh * p.kw * p.I;
+// Workgroup = one output channel x 64 input channels x all taps: the slab row is read in its own order ([tap][i]: runs of 64
+// floats), summed over the splits in split order, transposed in LDS and written in dW's order ([i][tap]: one contiguous run for
+// the standard weight layout).  Round 3: the first version walked a flat 64-bit index (three 64-bit divisions per output, every
+// store 36 bytes from its neighbour's) and ran at a sixth of the memory rate -- 145 launches, 1.7 ms of the step.
+constexpr int kReduceIC = 64, kReduceMaxTaps = 64;      // (validate: at most 64 taps)
+
+__device__ __forceinline__ int reduce_row_blocks(const WgradReduceParams& p) { return p.O * ((p.I + kReduceIC - 1) / kReduceIC); }
+
+__device__ __forceinline__ void reduce_row_block(const WgradReduceParams& p, int blk, float* sm) {
+  const int ichunks = (p.I + kReduceIC - 1) / kReduceIC;
+  const int o = blk / ichunks, i0 = (blk - o * ichunks) * kReduceIC;
+  const int ic = min(kReduceIC, p.I - i0), taps = p.kh * p.kw, n = ic * taps;
   const size_t slab_stride = (size_t)p.Cdpad * p.NNpad;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int i = (int)(idx % p.I);
-    long long r = idx / p.I;
-    const int kx = (int)(r % p.kw); r /= p.kw;
-    const int ky = (int)(r % p.kh);
-    const int o = (int)(r / p.kh);
-    const size_t off = (size_t)o * p.NNpad + (size_t)(ky * p.kw + kx) * p.I + i;
-    float v = 0.f;
-    for (int s = 0; s < p.splits; ++s) v += p.slab[s * slab_stride + off];
+  const float* row = p.slab + (size_t)o * p.NNpad + i0;
+  if (((p.I | p.NNpad | ic) & 3) == 0 && (slab_stride & 3) == 0) {
+    // 16 bytes per lane and four splits in flight: with one dword load per wave between dependent adds the sums ran at the
+    // round-trip latency (1.7 TB/s over the step's 2.4 GB of slabs)
+    const int icq = ic >> 2, nq = icq * taps;
+    for (int e = threadIdx.x; e < nq; e += blockDim.x) {
+      const int tap = e / icq, il = (e - tap * icq) * 4;
+      const float* src = row + tap * p.I + il;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      int s = 0;
+      for (; s + 4 <= p.splits; s += 4) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (size_t)s * slab_stride);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 1) * slab_stride);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 2) * slab_stride);
+        const f32x4 a3 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 3) * slab_stride);
+        v += a0; v += a1; v += a2; v += a3;             // split order, one rounding per addition, as the scalar loop
+      }
+      for (; s < p.splits; ++s) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * slab_stride);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sm[(il + c) * taps + tap] = v[c];
+    }
+  } else {
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+      const int tap = e / ic, il = e - tap * ic;
+      const float* src = row + tap * p.I + il;
+      float v = 0.f;
+      for (int s = 0; s < p.splits; ++s) v += src[s * slab_stride];
+      sm[il * taps + tap] = v;
+    }
+  }
+  __syncthreads();
+  float* dst0 = p.dw + o * p.sO;
+  for (int w = threadIdx.x; w < n; w += blockDim.x) {
+    const int il = w / taps, tap = w - il * taps;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+    float* dst = dst0 + ((i0 + il) * p.sI + ky * p.sH + kx * p.sW);
+    *dst = p.accumulate ? *dst + sm[w] : sm[w];
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceParams p) {
+  __shared__ float sm[kReduceIC * kReduceMaxTaps];
+  reduce_row_block(p, blockIdx.x, sm);
+}
+
+// many slabs, few outputs (first-layer weights: 64x3x4x4 summed over 1024 pixel ranges; the discriminator heads): workgroup =
+// 64 consecutive elements of one slab row x 4 waves; wave w sums splits w, w + 4, ... (eight 256-byte loads in flight), the
+// four partial sums meet in LDS and are added in wave order: fixed order, deterministic.  (Round 3; before, one wave per output
+// with the lanes striding over the splits: every load touched 64 different lines for 4 bytes each.)
+__device__ __forceinline__ int reduce_col_blocks(const WgradReduceParams& p) { return p.O * ((p.kh * p.kw * p.I + 63) / 64); }
+
+__device__ __forceinline__ void reduce_col_block(const WgradReduceParams& p, int blk, float* sm) {
+  const int nn = p.kh * p.kw * p.I, cols = (nn + 63) / 64;
+  const int o = blk / cols, e = (blk - o * cols) * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+  const size_t slab_stride = (size_t)p.Cdpad * p.NNpad;
+  float v = 0.f;
+  if (e < nn) {
+    const float* src = p.slab + (size_t)o * p.NNpad + e;
+    int s = wave;
+    for (; s + 28 < p.splits; s += 32) {
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = src[(size_t)(s + 4 * j) * slab_stride];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v += a[j];
+    }
+    for (; s < p.splits; s += 4) v += src[(size_t)s * slab_stride];
+  }
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  if (wave == 0 && e < nn) {
+    v = ((sm[threadIdx.x] + sm[threadIdx.x + 64]) + sm[threadIdx.x + 128]) + sm[threadIdx.x + 192];
+    const int tap = e / p.I, i = e - tap * p.I;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
     float* dst = p.dw + (o * p.sO + i * p.sI + ky * p.sH + kx * p.sW);
     *dst = p.accumulate ? *dst + v : v;
   }
 }
 
-// many slabs, few outputs (first-layer weights: 64x3x4x4 summed over 512 pixel ranges): one WAVE per output element,
-// lanes stride over the slabs, 64-lane shuffle sum -- the thread-per-output loop above would chain 512 dependent loads
 __global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(WgradReduceParams p) {
-  const long long total = (long long)p.O * p.kh * p.kw * p.I;
-  const size_t slab_stride = (size_t)p.Cdpad * p.NNpad;
-  const int lane = threadIdx.x & 63;
-  for (long long idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; idx < total;
-       idx += ((long long)gridDim.x * blockDim.x) >> 6) {
-    const int i = (int)(idx % p.I);
-    long long r = idx / p.I;
-    const int kx = (int)(r % p.kw); r /= p.kw;
-    const int ky = (int)(r % p.kh);
-    const int o = (int)(r / p.kh);
-    const size_t off = (size_t)o * p.NNpad + (size_t)(ky * p.kw + kx) * p.I + i;
-    float v = 0.f;
-    for (int s = lane; s < p.splits; s += 64) v += p.slab[s * slab_stride + off];
-    v = wave_sum(v);
-    if (lane == 0) {
-      float* dst = p.dw + (o * p.sO + i * p.sI + ky * p.sH + kx * p.sW);
-      *dst = p.accumulate ? *dst + v : v;
-    }
-  }
+  __shared__ float sm[256];
+  reduce_col_block(p, blockIdx.x, sm);
+}
+
+// Many slab sums in one launch (srgan_wgrad_defer_begin: the weight gradients of a whole backward pass leave their slabs in an
+// arena and are summed together when the pass ends -- 145 launches of ~12 us per train step, each too small to fill the chip,
+// become a handful that run at the memory rate).  The records travel in the kernel arguments (a captured train step replays
+// them as they were); a workgroup = one row block (reduce_row_block) or one column block (reduce_col_block) of one record: the
+// same code, order and single store as the one-record kernels above: identical bits.
+constexpr int kMultiReduceMax = 40;
+struct MultiReduceEntry {
+  WgradReduceParams r;
+  int first_block;     // first workgroup of this record
+  int wave;            // 1: column blocks (wgrad_reduce_wave_kernel's rule: many splits, few outputs)
+};
+struct MultiReduceArgs {
+  int n;
+  MultiReduceEntry e[kMultiReduceMax];
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(MultiReduceArgs a) {
+  __shared__ float sm[kReduceIC * kReduceMaxTaps];
+  int k = 0;
+  while (k + 1 < a.n && (int)blockIdx.x >= a.e[k + 1].first_block) ++k;
+  const WgradReduceParams& p = a.e[k].r;
+  const int blk = blockIdx.x - a.e[k].first_block;
+  if (a.e[k].wave) reduce_col_block(p, blk, sm);
+  else reduce_row_block(p, blk, sm);
 }
 
 // column sums of a dense [M][C] matrix -> out[C] (bias gradients); two-stage, deterministic.
@@ -1857,6 +1938,7 @@ extern "C" int srgan_conv2d_dgrad_packed_add(const srgan_conv_desc* d, const flo
 namespace srgan {
 static int finish_wgrad(const srgan_conv_desc* d, const WgradPlan& w, const float* dy, float* dw, float* dbias, void* ws,
                         hipStream_t st);
+static int defer_take(const srgan_conv_desc* d, void** ws, size_t* ws_bytes, hipStream_t st);
 }
 
 // Weight gradient of a layer whose forward kept its F(4x4,3x3) V image (srgan_conv2d_wgrad_v_bytes(d) != 0 bytes, handed to
@@ -1875,6 +1957,7 @@ extern "C" int srgan_conv2d_wgrad_v(const srgan_conv_desc* d, const float* v_ima
   Wino43WgradGeom g{};
   SRGAN_REQUIRE(wino43_wgrad_geometry(d, &g), "conv2d_wgrad_v: layer not applicable");
   hipStream_t st = as_stream(stream);
+  if (int e = defer_take(d, &ws, &ws_bytes, st)) return e;
   const size_t cs = (size_t)1024 * d->O * sizeof(float);
   float* zimg = reinterpret_cast<float*>(static_cast<char*>(ws) + round_up((long long)(g.slab_bytes + cs), 256));
   if (int e = wino43_wgrad_launch(g, v_image, dy, zimg, (float*)ws, conv_flops(d), st)) return e;
@@ -1893,6 +1976,7 @@ extern "C" int srgan_conv2d_wgrad_vz(const srgan_conv_desc* d, const float* v_im
   Wino43WgradGeom g{};
   SRGAN_REQUIRE(wino43_wgrad_geometry(d, &g), "conv2d_wgrad_vz: layer not applicable");
   hipStream_t st = as_stream(stream);
+  if (int e = defer_take(d, &ws, &ws_bytes, st)) return e;
   if (int e = wino43_wgrad_launch(g, v_image, nullptr, const_cast<float*>(z_image), (float*)ws, conv_flops(d), st, true)) return e;
   if (int e = check_launch("wino43_wgrad_kernel")) return e;
   WgradPlan w = plan_wgrad(d);
@@ -1926,6 +2010,7 @@ extern "C" int srgan_halo16_wgrad(const srgan_conv_desc* d, const void* x, int x
   SRGAN_REQUIRE(srgan_halo16_applicable(d), "halo16_wgrad: layer / compute mode not applicable (srgan_halo16_applicable)");
   SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "halo16_wgrad: workspace too small (srgan_conv2d_workspace)");
   hipStream_t st = as_stream(stream);
+  if (int e = defer_take(d, &ws, &ws_bytes, st)) return e;
   WgradPlan w = plan_wgrad(d);
   halo16_wgrad_slab(d, &w.splits, &w.Cdpad, &w.NNpad);
   if (int e = halo16_wgrad_run(d, x, dy, (float*)ws, conv_flops(d), st, x_bf16 != 0, dy_bf16 != 0)) return e;
@@ -1946,6 +2031,86 @@ static int launch_wgrad(const WgradParams& p, const WgradPlan& w, hipStream_t st
 namespace srgan {
 // srgan_set_wgrad_accumulate: while on, the weight-gradient entry points of this host thread ADD to dw / dbias
 static thread_local int g_wgrad_accumulate = 0;
+// bit 1 of the same switch: nobody reads dw before srgan_wgrad_defer_end (the caller's gradient sink) -- the call may be deferred
+static thread_local int g_wgrad_deferrable = 0;
+
+// srgan_wgrad_defer_begin .. _end (process-wide: autograd runs the backward functions on its own device thread, not on the thread
+// that opened the scope; one backward pass at a time, g_defer_mutex only keeps a misuse from corrupting the queue):
+// deferrable weight-gradient calls take their workspace (slab first) from the arena
+// instead of the caller's shared scratch and queue their slab sum; the queue is launched as wgrad_reduce_multi_kernel when it
+// is full, when the arena is, when a second record for the same dw arrives (stream order then keeps the two sums in call
+// order), and at _end.
+struct WgradDefer {
+  bool active = false;
+  char* arena = nullptr;
+  size_t bytes = 0, used = 0;
+  hipStream_t st = nullptr;
+  std::vector<MultiReduceEntry> pending;
+};
+static WgradDefer g_defer;
+static std::mutex g_defer_mutex;
+static long long g_defer_sums = 0, g_defer_launches = 0;      // srgan_wgrad_defer_stats
+static thread_local bool g_call_deferred = false;
+
+static bool reduce_by_wave(const WgradReduceParams& r) {
+  return r.splits >= 64 && (long long)r.O * r.kh * r.kw * r.I <= 131072;
+}
+static long long reduce_row_blocks_host(const WgradReduceParams& r) { return (long long)r.O * ceil_div(r.I, kReduceIC); }
+static long long reduce_col_blocks_host(const WgradReduceParams& r) { return (long long)r.O * ceil_div((long long)r.kh * r.kw * r.I, 64); }
+
+static int defer_launch_pending(bool reset_arena) {
+  WgradDefer& q = g_defer;
+  if (!q.pending.empty()) {
+    MultiReduceArgs a{};
+    a.n = (int)q.pending.size();
+    long long blocks = 0;
+    for (int k = 0; k < a.n; ++k) {
+      a.e[k] = q.pending[k];
+      a.e[k].first_block = (int)blocks;
+      blocks += a.e[k].wave ? reduce_col_blocks_host(a.e[k].r) : reduce_row_blocks_host(a.e[k].r);
+    }
+    q.pending.clear();
+    static const bool dbg = std::getenv("SRGAN_DEBUG_REDUCE") != nullptr;
+    if (dbg) {
+      double bytes = 0;
+      for (int k = 0; k < a.n; ++k) {
+        const WgradReduceParams& r = a.e[k].r;
+        bytes += 4.0 * r.O * r.kh * r.kw * r.I * (r.splits + 1 + r.accumulate);
+        std::fprintf(stderr, "  sum O %d I %d k %dx%d splits %d Cdpad %d NNpad %d wave %d acc %d\n", r.O, r.I, r.kh, r.kw, r.splits, r.Cdpad,
+                     r.NNpad, a.e[k].wave, r.accumulate);
+      }
+      std::fprintf(stderr, "multi launch: %d sums, %lld blocks, %.1f MB\n", a.n, blocks, bytes / 1e6);
+    }
+    g_defer_sums += a.n;
+    ++g_defer_launches;
+    SRGAN_REQUIRE(blocks < (1LL << 31), "wgrad defer: grid too large");
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, q.st, a);
+    if (int e = check_launch("wgrad_reduce_multi_kernel")) return e;
+  }
+  if (reset_arena) q.used = 0;
+  return 0;
+}
+
+// Called first by every weight-gradient entry point: when the call can be deferred, *ws / *ws_bytes become a fresh piece of the arena
+static int defer_take(const srgan_conv_desc* d, void** ws, size_t* ws_bytes, hipStream_t st) {
+  g_call_deferred = false;
+  if (!g_wgrad_deferrable) return 0;
+  std::lock_guard<std::mutex> lock(g_defer_mutex);
+  WgradDefer& q = g_defer;
+  if (!q.active) return 0;
+  const size_t need = (size_t)round_up((long long)srgan_conv2d_workspace(d), 256);
+  if (need == 0 || need > q.bytes) return 0;
+  if (!q.pending.empty() && q.st != st)
+    if (int e = defer_launch_pending(true)) return e;
+  if (q.used + need > q.bytes)
+    if (int e = defer_launch_pending(true)) return e;
+  q.st = st;
+  *ws = q.arena + q.used;
+  *ws_bytes = need;
+  q.used += need;
+  g_call_deferred = true;
+  return 0;
+}
 
 // slab sum -> dW (through the weight strides) and optional bias column sums
 static int finish_wgrad(const srgan_conv_desc* d, const WgradPlan& w, const float* dy, float* dw, float* dbias, void* ws,
@@ -1955,11 +2120,24 @@ static int finish_wgrad(const srgan_conv_desc* d, const WgradPlan& w, const floa
   r.O = d->O; r.I = d->I; r.kh = d->kh; r.kw = d->kw; r.splits = w.splits; r.Cdpad = w.Cdpad; r.NNpad = w.NNpad;
   r.accumulate = g_wgrad_accumulate;
   long long total = (long long)d->O * d->kh * d->kw * d->I;
-  if (w.splits >= 64 && total <= 131072)
-    hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 4), 8192)), dim3(256), 0, st, r);
+  if (g_call_deferred) {
+    g_call_deferred = false;
+    std::lock_guard<std::mutex> lock(g_defer_mutex);
+    WgradDefer& q = g_defer;
+    bool again = false;
+    for (const MultiReduceEntry& e : q.pending) again = again || e.r.dw == dw;
+    if (again || (int)q.pending.size() == kMultiReduceMax)
+      if (int e = defer_launch_pending(false)) return e;
+    MultiReduceEntry me{};
+    me.r = r;
+    me.wave = reduce_by_wave(r) ? 1 : 0;
+    q.pending.push_back(me);
+  } else if (reduce_by_wave(r))
+    hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((unsigned)reduce_col_blocks_host(r)), dim3(256), 0, st, r);
   else
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)reduce_row_blocks_host(r)), dim3(256), 0, st, r);
   if (int e2 = check_launch("wgrad_reduce_kernel")) return e2;
+  (void)total;
   if (dbias) {
     const int M = d->N * d->Ho * d->Wo;
     float* part = (float*)ws + (size_t)w.splits * w.Cdpad * w.NNpad;
@@ -1983,6 +2161,7 @@ extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, cons
   SRGAN_REQUIRE(x && dy && dw && ws, "conv2d_wgrad: null pointer");
   SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "conv2d_wgrad: workspace too small");
   hipStream_t st = as_stream(stream);
+  if (int e = defer_take(d, &ws, &ws_bytes, st)) return e;
   WgradPlan w = plan_wgrad(d);
   if (wino_wgrad_applicable(d)) {
     wino_wgrad_slab(d, &w.splits, &w.Cdpad, &w.NNpad);
@@ -2015,8 +2194,38 @@ extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, cons
 // A weight used more than once in one backward pass (the generator runs twice inside util_notebook.py:664 and :689) gets its
 // later contributions added by the split-K slab reduce instead of by a separate elementwise pass of the caller.
 extern "C" int srgan_set_wgrad_accumulate(int on) {
-  srgan::g_wgrad_accumulate = on != 0;
+  srgan::g_wgrad_accumulate = (on & 1) != 0;
+  srgan::g_wgrad_deferrable = (on & 2) != 0;
   return 0;
+}
+
+extern "C" int srgan_wgrad_defer_begin(void* arena, size_t arena_bytes) {
+  SRGAN_REQUIRE(arena && arena_bytes >= 4096, "wgrad_defer_begin: null or tiny arena");
+  SRGAN_REQUIRE((reinterpret_cast<uintptr_t>(arena) & 255) == 0, "wgrad_defer_begin: the arena must be 256-byte aligned");
+  std::lock_guard<std::mutex> lock(srgan::g_defer_mutex);
+  SRGAN_REQUIRE(!srgan::g_defer.active, "wgrad_defer_begin: already active");
+  srgan::g_defer.active = true;
+  srgan::g_defer.arena = static_cast<char*>(arena);
+  srgan::g_defer.bytes = arena_bytes & ~(size_t)255;
+  srgan::g_defer.used = 0;
+  srgan::g_defer.pending.clear();
+  return 0;
+}
+
+extern "C" int srgan_wgrad_defer_stats(long long* sums, long long* launches) {
+  SRGAN_REQUIRE(sums && launches, "wgrad_defer_stats: null pointer");
+  std::lock_guard<std::mutex> lock(srgan::g_defer_mutex);
+  *sums = srgan::g_defer_sums;
+  *launches = srgan::g_defer_launches;
+  return 0;
+}
+
+extern "C" int srgan_wgrad_defer_end(void) {
+  std::lock_guard<std::mutex> lock(srgan::g_defer_mutex);
+  if (!srgan::g_defer.active) return 0;
+  const int e = srgan::defer_launch_pending(true);
+  srgan::g_defer.active = false;
+  return e;
 }
 
 // ---- compute mode (BASELINE configs [2]-[4] are bf16): process-wide, set between steps ----

@@ -422,7 +422,23 @@ def _run_conv_wgrad(desc, x, dy, dw, dbias, v_image=None):
 # (``dp.GradReducer`` while a step is recorded), wrong for hooks that read the gradient, which is why the eager data-parallel
 # step (buckets sent from the hooks) keeps the ordinary path.  Opt-in (the trainer wraps its backward calls): plain
 # ``.backward()`` / ``autograd.grad`` on the modules are untouched.
+#
+# The sink's buffers are read by nobody until the scope closes, which also lets the library DEFER the split-K slab sums of the
+# weight-gradient calls (``srgan_wgrad_defer_begin``): they wait in an arena and run as a few large launches instead of one
+# ~12 us launch per layer (145 per train step).  ``SRGAN_NO_WGRAD_DEFER=1`` keeps the immediate sums.
 _grad_sink = None
+_defer_depth = 0
+_NO_WGRAD_DEFER = bool(_os.environ.get("SRGAN_NO_WGRAD_DEFER"))
+_WGRAD_ARENA_BYTES = int(_os.environ.get("SRGAN_WGRAD_ARENA_MB", "1024")) << 20
+
+
+def _wgrad_arena():
+    dev = torch.device("cuda", torch.cuda.current_device())
+    key = ("wgrad_arena", dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    a = _workspaces.get(key)
+    if a is None:
+        a = _workspaces[key] = torch.empty(_WGRAD_ARENA_BYTES, dtype=torch.uint8, device=dev)
+    return a
 
 
 class fused_param_grads:
@@ -430,14 +446,25 @@ class fused_param_grads:
         self._enabled = enabled
 
     def __enter__(self):
-        global _grad_sink
+        global _grad_sink, _defer_depth
         self._prev = _grad_sink
         _grad_sink = {} if self._enabled else None
+        self._defer = False
+        if self._enabled and not _NO_WGRAD_DEFER and _defer_depth == 0:
+            a = _wgrad_arena()
+            _lib.check(_lib.load().srgan_wgrad_defer_begin(_ptr(a), a.numel()), "wgrad_defer_begin")
+            self._defer = True
+            _defer_depth = 1
         return self
 
     def __exit__(self, et, ev, tb):
-        global _grad_sink
+        global _grad_sink, _defer_depth
         sink, _grad_sink = _grad_sink, self._prev
+        if self._defer:
+            _defer_depth = 0
+            err = _lib.load().srgan_wgrad_defer_end()          # the queued sums, before anyone binds or reads the buffers
+            if et is None:
+                _lib.check(err, "wgrad_defer_end")
         if et is None and sink:
             with torch.no_grad():
                 for p, buf in sink.values():
@@ -465,17 +492,19 @@ def _sink_slots(*params):
 
 
 class _wgrad_accumulate:
-    """``srgan_set_wgrad_accumulate`` around the weight-gradient calls of one Function.backward (thread-local in the library)."""
+    """``srgan_set_wgrad_accumulate`` around the weight-gradient calls of one Function.backward (thread-local in the library):
+    bit 0 = add to the buffer (a later use of the parameter in this pass), bit 1 = the buffer is a sink slot, so the slab sum
+    may wait for the end of the scope."""
 
-    def __init__(self, on):
-        self._on = bool(on)
+    def __init__(self, on, sink=False):
+        self._mode = (1 if on else 0) | (2 if sink and _defer_depth else 0)
 
     def __enter__(self):
-        if self._on:
-            _lib.load().srgan_set_wgrad_accumulate(1)
+        if self._mode:
+            _lib.load().srgan_set_wgrad_accumulate(self._mode)
 
     def __exit__(self, *exc):
-        if self._on:
+        if self._mode:
             _lib.load().srgan_set_wgrad_accumulate(0)
         return False
 
@@ -548,7 +577,7 @@ class _Conv2dFn(Function):
                     db = torch.empty(weight.shape[0], dtype=torch.float32, device=weight.device)
             desc = ConvDesc.from_buffer_copy(ctx.desc)
             desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
-            with _wgrad_accumulate(acc):
+            with _wgrad_accumulate(acc, slots is not None):
                 _run_conv_wgrad(desc, x, gy, dw, db, ctx.v_image)
             if slots is not None:
                 dw = db = None
@@ -600,7 +629,7 @@ class _ConvTranspose2dFn(Function):
             (dw,), acc = slots if slots is not None else ([torch.empty(weight.shape, dtype=torch.float32, device=weight.device)], False)
             desc = ConvDesc.from_buffer_copy(ctx.desc)
             desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
-            with _wgrad_accumulate(acc):
+            with _wgrad_accumulate(acc, slots is not None):
                 _run_conv_wgrad(desc, gy, x, dw, None)
             if slots is not None:
                 dw = None
@@ -704,7 +733,7 @@ class _NormActConvFn(Function):
             (dw,), acc = slots if slots is not None else ([torch.empty(weight.shape, dtype=torch.float32, device=weight.device)], False)
             desc = ConvDesc.from_buffer_copy(ctx.desc)
             desc.sO, desc.sI, desc.sH, desc.sW = dw.stride()
-            with _wgrad_accumulate(acc):
+            with _wgrad_accumulate(acc, slots is not None):
                 if ctx.v_image is not None:
                     _run_conv_wgrad(desc, None, gy, dw, None, ctx.v_image)
                 else:   # no V kept (layer outside the F(4x4,3x3) weight-gradient geometry): recompute the normalised input
@@ -807,7 +836,7 @@ class _ResBlockFn(Function):
             dd = ConvDesc.from_buffer_copy(desc)
             dd.sO, dd.sI, dd.sH, dd.sW = dw.stride()
             ws, nb = _conv_ws(dd, dev)
-            with _wgrad_accumulate(acc):
+            with _wgrad_accumulate(acc, slots is not None):
                 _lib.check(lib.srgan_conv2d_wgrad_vz(ctypes.byref(dd), _ptr(v_fwd), _ptr(zimg), _ptr(dw), _ptr(ws), nb, st),
                            "conv2d_wgrad_vz")
             return None if slots is not None else dw
@@ -902,7 +931,7 @@ class _ResBlockBf16Fn(Function):
             dd = ConvDesc.from_buffer_copy(desc)
             dd.sO, dd.sI, dd.sH, dd.sW = dw.stride()
             ws, nb = _conv_ws(dd, dev)
-            with _wgrad_accumulate(acc):
+            with _wgrad_accumulate(acc, slots is not None):
                 _lib.check(lib.srgan_halo16_wgrad(ctypes.byref(dd), _ptr(xin), xin16, _ptr(dy), 1, _ptr(dw), _ptr(ws), nb, st),
                            "halo16_wgrad")
             return None if slots is not None else dw

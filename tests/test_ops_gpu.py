@@ -826,15 +826,32 @@ def test_pack_cache_never_serves_a_stale_operand(ops):
         close(conv(), ref())
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_fused_param_grads_equal_autograd_accumulation(ops, mode):
+@pytest.mark.parametrize("mode,defer", [("fp32", "arena"), ("bf16", "arena"), ("fp32", "arena48m"), ("fp32", "immediate")])
+def test_fused_param_grads_equal_autograd_accumulation(ops, mode, defer):
     """ops.fused_param_grads: a generator reached through TWO graphs in one backward call (as inside util_notebook.py:664 and
     :689) -- the weight-gradient kernels add the second contribution in their own epilogue (slab reduce with beta = 1,
     central-biasing records with the accumulate flag) instead of autograd's AccumulateGrad input buffer doing it with one
     elementwise launch per parameter.  Same operands, same single addition: every parameter gradient bit-identical; a
     post-accumulate-grad hook still fires once per parameter and backward call (the data-parallel reducer counts on it); a
-    gradient already in ``p.grad`` is added to, as AccumulateGrad would."""
+    gradient already in ``p.grad`` is added to, as AccumulateGrad would.
+    ``defer``: inside the scope the split-K slab sums wait in an arena and run as few launches (srgan_wgrad_defer_begin; a second
+    sum for the same buffer, a full queue or a full arena launch what is waiting) -- default arena, one so small that it
+    overflows and the largest layers do not fit at all, and the immediate sums: the same bits every time."""
     from srgan_amd import model
+    saved = (ops._NO_WGRAD_DEFER, ops._WGRAD_ARENA_BYTES)
+    arena_keys = lambda: [k for k in ops._workspaces if k[0] == "wgrad_arena"]
+    for k in arena_keys():
+        del ops._workspaces[k]
+    ops._NO_WGRAD_DEFER = defer == "immediate"
+    ops._WGRAD_ARENA_BYTES = (48 << 20) if defer == "arena48m" else saved[1]
+
+    def defer_stats():
+        import ctypes
+        from srgan_amd import _lib
+        a, b = ctypes.c_longlong(), ctypes.c_longlong()
+        _lib.check(_lib.load().srgan_wgrad_defer_stats(ctypes.byref(a), ctypes.byref(b)), "defer_stats")
+        return a.value, b.value
+    stats0 = defer_stats()
     torch.manual_seed(5)
     G = model.SingleGenerator(3, 64, 2, 2, 2, "instance", num_con=12).cuda()      # full width, two residual blocks
     x1, x2 = rnd(2, 3, 128, 128, seed=1).cuda(), rnd(3, 3, 128, 128, seed=2).cuda()
@@ -864,6 +881,16 @@ def test_fused_param_grads_equal_autograd_accumulation(ops, mode):
         ops.invalidate_packed()
         for h in handles:
             h.remove()
+        ops._NO_WGRAD_DEFER, ops._WGRAD_ARENA_BYTES = saved
+        sums, launches = (b - a for a, b in zip(stats0, defer_stats()))
+        if defer == "immediate":
+            assert sums == 0 and not arena_keys()
+        elif defer == "arena48m":     # the arena holds two of the trunk's slabs: queued, but launched almost one by one
+            assert sums >= 30, (sums, launches)
+        else:       # every layer's sum is queued twice per backward call (two uses): a handful of launches
+            assert sums >= 30 and launches < sums / 3, (sums, launches)
+        for k in arena_keys():
+            del ops._workspaces[k]
     for stage in (0, 1):
         for n in out[False][stage]:
             assert torch.equal(out[False][stage][n], out[True][stage][n]), (stage, n)
