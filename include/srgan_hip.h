@@ -129,9 +129,9 @@ int srgan_set_wgrad_accumulate(int on);
  * before _end", true for the gradient buffers autograd's AccumulateGrad (util_notebook.py:664, :689 `.backward()`) would fill --
  * takes its workspace from the arena (256-byte aligned device memory, the caller keeps it alive and untouched until _end; `ws`
  * is then unused) and queues its sum; queued sums run as ONE launch when 40 are waiting, when the arena is full, when a second
- * sum for the same dw arrives, and at _end -- all on the stream of the calls.  Same per-output loop and rounding as the
+ * sum for the same dw arrives, and at _end -- all on `stream`; calls made on any other stream are not deferred.  Same per-output loop and rounding as the
  * immediate sums: identical bits.  dbias column sums are not deferred. */
-int srgan_wgrad_defer_begin(void* arena, size_t arena_bytes);
+int srgan_wgrad_defer_begin(void* arena, size_t arena_bytes, void* stream);
 int srgan_wgrad_defer_end(void);
 /* Process totals since load: slab sums that went through the queue, and the launches that ran them. */
 int srgan_wgrad_defer_stats(long long* sums, long long* launches);

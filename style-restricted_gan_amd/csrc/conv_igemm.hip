@@ -2098,13 +2098,11 @@ static int defer_take(const srgan_conv_desc* d, void** ws, size_t* ws_bytes, hip
   std::lock_guard<std::mutex> lock(g_defer_mutex);
   WgradDefer& q = g_defer;
   if (!q.active) return 0;
+  if (st != q.st) return 0;          // a call on another stream (the discriminator's second scale): immediate sum, own scratch
   const size_t need = (size_t)round_up((long long)srgan_conv2d_workspace(d), 256);
   if (need == 0 || need > q.bytes) return 0;
-  if (!q.pending.empty() && q.st != st)
-    if (int e = defer_launch_pending(true)) return e;
   if (q.used + need > q.bytes)
     if (int e = defer_launch_pending(true)) return e;
-  q.st = st;
   *ws = q.arena + q.used;
   *ws_bytes = need;
   q.used += need;
@@ -2199,7 +2197,7 @@ extern "C" int srgan_set_wgrad_accumulate(int on) {
   return 0;
 }
 
-extern "C" int srgan_wgrad_defer_begin(void* arena, size_t arena_bytes) {
+extern "C" int srgan_wgrad_defer_begin(void* arena, size_t arena_bytes, void* stream) {
   SRGAN_REQUIRE(arena && arena_bytes >= 4096, "wgrad_defer_begin: null or tiny arena");
   SRGAN_REQUIRE((reinterpret_cast<uintptr_t>(arena) & 255) == 0, "wgrad_defer_begin: the arena must be 256-byte aligned");
   std::lock_guard<std::mutex> lock(srgan::g_defer_mutex);
@@ -2208,6 +2206,7 @@ extern "C" int srgan_wgrad_defer_begin(void* arena, size_t arena_bytes) {
   srgan::g_defer.arena = static_cast<char*>(arena);
   srgan::g_defer.bytes = arena_bytes & ~(size_t)255;
   srgan::g_defer.used = 0;
+  srgan::g_defer.st = as_stream(stream);
   srgan::g_defer.pending.clear();
   return 0;
 }

@@ -51,7 +51,7 @@ SIGNATURES = {
     "srgan_instnorm_slab_fwd_io": (c_int, [P, c_int, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_float, P]),
     "srgan_instnorm_slab_bwd_io": (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "srgan_set_wgrad_accumulate": (c_int, [c_int]),
-    "srgan_wgrad_defer_begin": (c_int, [P, c_size_t]),
+    "srgan_wgrad_defer_begin": (c_int, [P, c_size_t, P]),
     "srgan_wgrad_defer_end": (c_int, []),
     "srgan_wgrad_defer_stats": (c_int, [POINTER(c_longlong), POINTER(c_longlong)]),
     "srgan_conv2d_wgrad": (c_int, [_DESC, P, P, P, P, P, c_size_t, P]),

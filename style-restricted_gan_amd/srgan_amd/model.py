@@ -95,6 +95,58 @@ class _AvgPool3s2(nn.Module):
         return ops.avgpool3s2(x)
 
 
+# The two scales of a multi-scale discriminator (model.py:303-337, :339-346: discriminator1 on the image, discriminator2 at half
+# the width on the 3x3 / stride-2 average of it) share nothing but the input.  The second scale is 1/16 of the first one's FLOPs
+# in launches of 4-128 workgroups that cannot fill 256 CUs (1.07 GFLOP layers at 23-28 us each: 40-47 TFLOP/s), so it runs on a
+# SIDE STREAM forked from the caller's: forward here, backward wherever autograd replays it (the engine runs a node's backward on
+# its forward's stream and orders the streams with events) -- inside a captured train step the two scales become parallel
+# branches of the hipGraph.  Same kernels, same operands, same accumulation order of the two input gradients (the engine's,
+# by topological order): identical results.  ``SRGAN_NO_PARALLEL_SCALES=1`` keeps everything on one stream.
+_PARALLEL_SCALES = not os.environ.get("SRGAN_NO_PARALLEL_SCALES")
+_side_streams = {}
+
+
+class _second_scale:
+    """``with _second_scale(x) as fork: ...`` runs the block on the device's side stream after everything queued on the current
+    one; ``fork.join(*tensors)`` (after the block) makes the current stream wait for it and tells the allocator where the
+    block's results are used."""
+
+    def __init__(self, x):
+        self._on = _PARALLEL_SCALES and x.is_cuda
+        if self._on:
+            self._main = torch.cuda.current_stream(x.device)
+            side = _side_streams.get(x.device.index)
+            if side is None:
+                side = _side_streams[x.device.index] = torch.cuda.Stream(x.device)
+            self._side = side
+            self._x = x
+
+    def __enter__(self):
+        if self._on:
+            self._side.wait_stream(self._main)
+            self._ctx = torch.cuda.stream(self._side)
+            self._ctx.__enter__()
+            self._x.record_stream(self._side)
+        return self
+
+    def __exit__(self, *exc):
+        if self._on:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self._on:
+            self._main.wait_stream(self._side)
+            for t in tensors:
+                t.record_stream(self._main)
+
+
+def _fork_input(x):
+    """A leaf input that wants a gradient gets it from both scales; behind a view node of the caller's stream the two meet in an
+    ordinary input buffer and the leaf's AccumulateGrad node sees one producer on its own stream (no stream-mismatch warning)."""
+    return x.view_as(x) if (_PARALLEL_SCALES and x.is_cuda and x.is_leaf and x.requires_grad) else x
+
+
 class _AvgPool2(nn.Module):
     def forward(self, x):
         return ops.avgpool2(x)
@@ -290,7 +342,12 @@ class SingleDiscriminator_original_multi(nn.Module):
         self.discriminator2 = SingleDiscriminator_original(nch_in, nch // 2, reduce, num_cls, norm_type, num_con)
 
     def forward(self, x):
-        return [self.discriminator1(x), self.discriminator2(self.down(x))]
+        x = _fork_input(x)
+        with _second_scale(x) as fork:
+            d2 = self.discriminator2(self.down(x))
+        d1 = self.discriminator1(x)
+        fork.join(d2)
+        return [d1, d2]
 
 
 class SingleDiscriminator_solo(nn.Module):
@@ -320,11 +377,15 @@ class SingleDiscriminator_solo_multi(nn.Module):
     def forward_logits(self, x):
         """-> ([out1, out2], [logits1, logits2]); logits are [B, n_class] pre-softmax (used by the
         fused softmax+MSE loss kernel in the trainer)."""
+        x = _fork_input(x)
+        with _second_scale(x) as fork:
+            d2 = self.discriminator2(self.down(x))
+            o2 = self.last_layer2(d2)
+            z2 = self.classification_layer2[0](d2).reshape(-1, self.n_class)
         d1 = self.discriminator1(x)
-        d2 = self.discriminator2(self.down(x))
-        o1, o2 = self.last_layer1(d1), self.last_layer2(d2)
+        o1 = self.last_layer1(d1)
         z1 = self.classification_layer1[0](d1).reshape(-1, self.n_class)
-        z2 = self.classification_layer2[0](d2).reshape(-1, self.n_class)
+        fork.join(o2, z2)
         return [o1, o2], [z1, z2]
 
     def forward(self, x):

@@ -452,7 +452,7 @@ class fused_param_grads:
         self._defer = False
         if self._enabled and not _NO_WGRAD_DEFER and _defer_depth == 0:
             a = _wgrad_arena()
-            _lib.check(_lib.load().srgan_wgrad_defer_begin(_ptr(a), a.numel()), "wgrad_defer_begin")
+            _lib.check(_lib.load().srgan_wgrad_defer_begin(_ptr(a), a.numel(), _stream()), "wgrad_defer_begin")
             self._defer = True
             _defer_depth = 1
         return self
