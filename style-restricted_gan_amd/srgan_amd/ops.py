@@ -360,8 +360,30 @@ def refresh_packed(params, force=False):
         _lib.check(lib.srgan_conv2d_pack_multi(_ptr(dev), len(multi), _stream()), "conv2d_pack_multi")
         for h in multi:
             h.version, h.fresh = h.weight._version, True
+    # The operands outside the multi-pack launch (narrow-output layers, the RGB layers: one small kernel each, four for a
+    # stride-2 input gradient) are re-packed at their next USE instead: the discriminator's image-gradient operands are used
+    # once per train step (generator update) but went stale -- and were re-packed -- after each of its k optimiser steps.
     for h in singles:
-        _pack_one(h)
+        if _EAGER_SINGLE_PACKS:
+            _pack_one(h)
+        else:
+            h.fresh = False
+
+
+_EAGER_SINGLE_PACKS = bool(_os.environ.get("SRGAN_EAGER_SINGLE_PACKS"))
+
+
+def mark_singles_stale():
+    """Before a train step is RECORDED: every operand that is re-packed at use (see refresh_packed) is marked stale, so that the
+    recording holds a pack launch at the first use of each one -- a replay starts from whatever the previous step's optimisers
+    left, not from the state the cache happened to be in when the step was captured."""
+    lib = _lib.load()
+    nb = lib.srgan_pack_entry_bytes()
+    rec = (ctypes.c_char * nb)()
+    for h in _pack_cache.values():
+        if h.weight is not None and lib.srgan_conv2d_pack_entry(ctypes.byref(h.desc), h.kind, h.act, _ptr(h.weight), _ptr(h.buf),
+                                                                 ctypes.byref(rec)) == 1:
+            h.fresh = False
 
 
 def _run_conv_fwd(desc, x, weight, bias, y, act, slope, keep_v=None):

@@ -730,6 +730,7 @@ class _StepGraph:
         hook = type(self).fault_hook
         if hook is not None:
             hook("before")
+        ops.mark_singles_stale()          # their pack launches belong to the recording (ops.refresh_packed)
         g = _Recording(self.x.device)
         sg._g_active = True
         self._noise_i, self._onehot = 0, {}

@@ -1005,6 +1005,8 @@ def test_multi_pack_launch_equals_single_pack_implicit_gemm(ops, o, i, k, s, p):
                 h.buf.fill_(255)
             ops.refresh_packed([w], force=True)
             for h, sgl in zip(hits, single):
+                if not h.fresh:          # an operand outside the multi-pack launch (3-channel layers): re-packed at its next use
+                    assert ops._packed(h.desc, w, h.kind, h.act)[0] is h and h.fresh
                 assert torch.equal(h.buf, sgl), (h.kind, o, i, k)
         ref = F.conv2d(x.detach().cpu(), w.detach().cpu(), None, s, p)
         close(y, ref, 2e-5)
