@@ -258,6 +258,11 @@ class GradReducer:
         bk = self._buckets_cache[b]
         bk.materialise()
         on_gpu = bk.flat.is_cuda
+        if on_gpu and _recorder is None:
+            # sent from a hook, inside the backward pass: the bucket's gradients may have been written on more than one stream
+            # (the discriminator's second scale runs on a side stream) -- this one waits for the others before it reads them
+            from . import ops
+            ops.wait_compute_streams(bk.flat.device)
         srcs, dsts, holes = [], [], []
         for p, v in zip(bk.params, bk.views):
             g = p.grad

@@ -120,6 +120,7 @@ class _second_scale:
                 side = _side_streams[x.device.index] = torch.cuda.Stream(x.device)
             self._side = side
             self._x = x
+            ops.register_compute_streams(x.device, self._main, side)
 
     def __enter__(self):
         if self._on:

@@ -57,6 +57,28 @@ def workspace(device, nbytes):
     return ws
 
 
+# Streams that carry parts of one backward pass (model._second_scale: the discriminator's second scale runs on a side stream).
+# Code that reads gradients from INSIDE the pass -- the eager data-parallel reducer sends a bucket from the hook of its last
+# parameter, on whatever stream that parameter's node ran -- first makes its stream wait for the others.
+_compute_streams = {}
+
+
+def register_compute_streams(device, *streams):
+    known = _compute_streams.setdefault(device.index, [])
+    for s in streams:
+        if all(s != k for k in known):
+            known.append(s)
+        if len(known) > 8:          # callers' streams come and go (tests); keep the recent ones
+            del known[0]
+
+
+def wait_compute_streams(device):
+    cur = torch.cuda.current_stream(device)
+    for s in _compute_streams.get(device.index, ()):
+        if s != cur:
+            cur.wait_stream(s)
+
+
 def upload_small(blob, device, out=None):
     """bytes / bytearray (a pointer table of a few KB, multiple of 4 bytes) -> device uint8 tensor.  The bytes travel in the
     arguments of a tiny kernel (C ABI ``srgan_upload_small``): no pinned staging buffer to keep alive, and inside a captured
