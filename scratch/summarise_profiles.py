@@ -27,6 +27,8 @@ def prof_name(n):
         return "rgbin_conv_kernel"
     if n.startswith("rgb_wgrad_kernel"):
         return "rgb_wgrad_kernel"
+    if "rgbout_conv_kernel" in n:
+        return "rgbout_conv_kernel"
     if n.startswith("wino43_wgrad_kernel"):
         return "wino43_wgrad_kernel"
     if n.startswith("wino43_dy_kernel"):
