@@ -159,3 +159,34 @@ def test_config1_modules_vs_oracle():
     assert [tuple(o.shape) for o in outs] == [(2, 1, 3, 3), (2, 1, 1, 1)]
     for o, r in zip(outs, outs_r):
         close(o, r, TOL)
+
+
+@pytest.mark.parametrize("leaf_input", [False, True])
+def test_second_scale_on_a_side_stream_changes_no_bit(leaf_input):
+    """model._second_scale: discriminator2 (+ its heads) runs on a side stream, forward and -- replayed by autograd -- backward.
+    Same kernels, same operands, same accumulation order of the two input gradients: outputs, input gradient and every
+    parameter gradient bit-identical to the single-stream run, for a leaf input (its two gradients meet behind a view node of
+    the caller's stream) and for a non-leaf one (the generator's output in the trainer); full width, batch 8."""
+    from srgan_amd import model
+    _, D, _ = build_hip_nets("F")
+    x0, _ = otrainer.synthetic_batch(8, 128, 4, seed=21)
+    saved = model._PARALLEL_SCALES
+    runs = {}
+    try:
+        for par in (False, True):
+            model._PARALLEL_SCALES = par
+            for p in D.parameters():
+                p.grad = None
+            x = x0.cuda().requires_grad_(True)
+            xin = x if leaf_input else x * 1.0
+            (o1, o2), (c1, c2) = D(xin)
+            ((o1 ** 2).mean() + (o2 * 0.5).sum() + (c1 * torch.arange(4.0).cuda()).sum() + (c2 ** 2).sum()).backward()
+            torch.cuda.synchronize()
+            runs[par] = ([t.detach().clone() for t in (o1, o2, c1, c2, x.grad)], {k: p.grad.clone() for k, p in D.named_parameters()})
+    finally:
+        model._PARALLEL_SCALES = saved
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert torch.equal(a, b)
+    for k in runs[False][1]:
+        assert torch.equal(runs[False][1][k], runs[True][1][k]), k
+    assert model._side_streams                     # the fork really happened
