@@ -105,6 +105,13 @@ int srgan_conv2d_wgrad_vz(const srgan_conv_desc* d, const float* v_image, const 
  * convolution AND to the skip connection, so the gradient of the block input is the sum of the two paths; handing the skip
  * path's gradient to the convolution's input-gradient kernel (added in the F(4x4,3x3) epilogue; one in-place pass on the other
  * dispatches) replaces autograd's separate accumulation pass over the tensor.  res: dense, shape of dx, must not alias dx. */
+/* dx = (input gradient of the convolution) * LeakyReLU'(mask): a discriminator trunk is conv -> LeakyReLU(0.2) -> conv -> ...
+ * (model.py:303-309), so the gradient this layer hands to the previous one must still be multiplied by that layer's LeakyReLU
+ * derivative -- 1 or `slope` after the sign of its activated output, which IS this layer's input tensor (`mask`).  Folded into
+ * the epilogue of the transposed F(3x3,2x2) kernel (one in-place elementwise pass on the other dispatches) it replaces the
+ * read-read-write pass in front of the previous layer's backward.  mask: dense, shape of dx, must not alias dx. */
+int srgan_conv2d_dgrad_packed_mask(const srgan_conv_desc* d, const float* dy, const void* packed, const float* mask, float slope,
+                                   float* dx, void* ws, size_t ws_bytes, void* stream);
 int srgan_conv2d_dgrad_packed_add(const srgan_conv_desc* d, const float* dy, const void* packed, const float* res, float* dx,
                                   void* ws, size_t ws_bytes, void* stream);
 

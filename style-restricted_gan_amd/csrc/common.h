@@ -95,6 +95,8 @@ struct WinoParams {
   int act;            // fused activation of the epilogue (SRGAN_ACT_*)
   float slope;
   const float* res;   // F(4x4,3x3) only: tensor of the destination's shape added in the epilogue (residual gradient), or null
+  const float* mask;  // transposed F(3x3,2x2) only: tensor of the destination's shape whose sign selects 1 / mask_slope per element
+  float mask_slope;   //   (the LeakyReLU backward of the layer that produced the destination's forward tensor), or null
 };
 
 // conv_wino43.hip: F(4x4,3x3) kernel behind wino_run
@@ -117,7 +119,7 @@ bool wino_applicable(const srgan_conv_desc* d, int kind);
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind);
 int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hipStream_t st);
 size_t wino_scratch_bytes(const srgan_conv_desc* d, int kind);
-int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst, int act, float slope, float* scratch, hipStream_t st, const float* res = nullptr, bool* res_done = nullptr, bool v_ready = false);
+int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst, int act, float slope, float* scratch, hipStream_t st, const float* res = nullptr, bool* res_done = nullptr, bool v_ready = false, const float* mask = nullptr, float mask_slope = 0.f, bool* mask_done = nullptr);
 bool wino43_fwd_applicable(const srgan_conv_desc* d);      // the forward of d runs on F(4x4,3x3)
 bool wino_wgrad_applicable(const srgan_conv_desc* d);
 void wino_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad);

@@ -1682,26 +1682,30 @@ static size_t conv_splitk_bytes(const srgan_conv_desc* d, int kind) {
 }
 
 static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp, float* dx, float* scratch, hipStream_t st,
-                     const float* res = nullptr);
+                     const float* res = nullptr, const float* mask = nullptr, float mask_slope = 0.f);
 static int dgrad_run_core(const srgan_conv_desc* d, const float* dy, const float* wp, float* dx, float* scratch, hipStream_t st,
-                          const float* res, bool* res_done);
+                          const float* res, bool* res_done, const float* mask, float mask_slope, bool* mask_done);
 
 // dx = dgrad(dy) (+ res): the F(4x4,3x3) kernel adds `res` in its epilogue; every other dispatch gets one in-place add pass
+// ... (* mask): the LeakyReLU backward of the layer that produced this layer's input (mask = that activated tensor): in the
+// epilogue of the transposed F(3x3,2x2) kernel, one in-place elementwise pass behind every other dispatch
 static int dgrad_run(const srgan_conv_desc* d, const float* dy, const float* wp, float* dx, float* scratch, hipStream_t st,
-                     const float* res) {
-  bool done = false;
-  if (int e = dgrad_run_core(d, dy, wp, dx, scratch, st, res, &done)) return e;
+                     const float* res, const float* mask, float mask_slope) {
+  bool done = false, mdone = false;
+  if (int e = dgrad_run_core(d, dy, wp, dx, scratch, st, res, &done, mask, mask_slope, &mdone)) return e;
   if (res && !done) {
     const long long n = (long long)d->N * d->Hi * d->Wi * d->I, n4 = n / 4;
     hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(ceil_div(n4, 256), 8192))),
                        dim3(256), 0, st, dx, res, n4, n);
-    return check_launch("add_inplace_kernel");
+    if (int e = check_launch("add_inplace_kernel")) return e;
   }
+  if (mask && !mdone)
+    return srgan_act_bwd(mask, dx, dx, (long long)d->N * d->Hi * d->Wi * d->I, SRGAN_ACT_LRELU, mask_slope, st);
   return 0;
 }
 
 static int dgrad_run_core(const srgan_conv_desc* d, const float* dy, const float* wp, float* dx, float* scratch, hipStream_t st,
-                          const float* res, bool* res_done) {
+                          const float* res, bool* res_done, const float* mask, float mask_slope, bool* mask_done) {
   DgradGeom g = dgrad_geometry(d);
   g.p.src = dy; g.p.wp = wp;
   g.p.dst = g.reflect ? scratch : dx;
@@ -1731,8 +1735,9 @@ static int dgrad_run_core(const srgan_conv_desc* d, const float* dy, const float
   }
   if (g.wino) {
     // (F(4,3) needs zero padding, the fold scratch needs reflect padding: the two uses of `scratch` never meet)
+    // (the mask rides in the epilogue only when nothing is added to dx afterwards)
     if (int e = wino_run(d, 1, dy, wp, nullptr, g.p.dst, SRGAN_ACT_NONE, 0.f, g.reflect ? nullptr : scratch, st,
-                         g.reflect ? nullptr : res, res_done)) return e;
+                         g.reflect ? nullptr : res, res_done, false, (g.reflect || res) ? nullptr : mask, mask_slope, mask_done)) return e;
   } else {
     // split-K slabs sit behind the padded-gradient temp of a reflect layer
     float* slab = scratch ? (g.reflect ? scratch + round_up((long long)d->N * g.Hd * g.Wd * d->I, 64) : scratch) : nullptr;
@@ -1923,6 +1928,16 @@ extern "C" int srgan_conv2d_dgrad_from_v(const srgan_conv_desc* d, const void* v
   SRGAN_REQUIRE(dg.wino && !dg.reflect && wino43_dgrad_applicable(d), "conv2d_dgrad_from_v: the input gradient does not run on F(4x4,3x3)");
   return wino_run(d, 1, nullptr, (const float*)packed, nullptr, dx, SRGAN_ACT_NONE, 0.f,
                   const_cast<float*>(static_cast<const float*>(v_image)), as_stream(stream), res, nullptr, true);
+}
+
+extern "C" int srgan_conv2d_dgrad_packed_mask(const srgan_conv_desc* d, const float* dy, const void* packed, const float* mask,
+                                              float slope, float* dx, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(dy && packed && dx && mask, "conv2d_dgrad_packed_mask: null pointer");
+  SRGAN_REQUIRE(mask != dx, "conv2d_dgrad_packed_mask: mask must not alias dx");
+  const size_t need = srgan_conv2d_packed_scratch(d, 1);
+  SRGAN_REQUIRE(need == 0 || (ws && ws_bytes >= need), "conv2d_dgrad_packed_mask: workspace too small (srgan_conv2d_packed_scratch)");
+  return dgrad_run(d, dy, (const float*)packed, dx, (float*)ws, as_stream(stream), nullptr, mask, slope);
 }
 
 extern "C" int srgan_conv2d_dgrad_packed_add(const srgan_conv_desc* d, const float* dy, const void* packed, const float* res,

@@ -56,8 +56,12 @@ __device__ __forceinline__ auto uniform_rsrc(const float* base, unsigned bytes) 
 //         blockIdx.y is a 2x2 stride-1 correlation over dy with taps w[3-2a-r][3-2b-s]; F(3x3,2x2) on the phase image,
 //         outputs scattered with pixel stride 2.
 
-template <int MODE>
+// MASK (MODE 2 only): the epilogue multiplies every output by 1 or p.mask_slope after the sign of p.mask at the same element --
+// the LeakyReLU backward of the PREVIOUS layer, whose activated output is this input gradient's forward tensor: one read of
+// that tensor here instead of a three-tensor elementwise pass (act_bwd_kernel) in front of the previous layer's backward.
+template <int MODE, bool MASK = false>
 __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
+  static_assert(!MASK || MODE == 2, "the mask epilogue exists for the transposed form only");
   // V image, double-buffered: [buf][16 pos][2 channel halves][64 tiles x 4 ch + 16 pad] (+32 pad per position).
   // A lane's MFMA fragment (4 channels of one tile) is one 16-B slot and a 16-lane read group covers 256 contiguous
   // bytes (conflict-free ds_read_b128); the 16-float pad puts the two halves a gather wave writes on different
@@ -355,6 +359,19 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
     const bool nok = n < p.Cd;                       // Cd % 4 == 0 (wino_variant): the four channels are in or out together
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (nok && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    const int o = tile_o[et], f = tile_f[et];
+    // MASK: requested before the LDS reads and the output transform, consumed at the stores (loads next to stores are exposed)
+    f32x4 mk[OT][OT];
+    if constexpr (MASK) {
+      if (nok && o >= 0) {
+        const float* mp = p.mask + (size_t)o * p.Cd + n;
+#pragma unroll
+        for (int a = 0; a < OT; ++a)
+#pragma unroll
+          for (int b2 = 0; b2 < OT; ++b2)
+            if (a < (f & 15) && b2 < (f >> 4)) mk[a][b2] = *reinterpret_cast<const f32x4*>(mp + (size_t)(a * p.Wo + b2) * PS * p.Cd);
+      }
+    }
     f32x4 m[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) m[k] = *reinterpret_cast<const f32x4*>(lds + k * 2048 + et * 32 + cq * 4);
@@ -383,7 +400,6 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
         y[a][2] = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
       }
     }
-    const int o = tile_o[et], f = tile_f[et];
     if (nok && o >= 0) {
       const int nr = f & 15, nc = f >> 4;
       float* dp = p.dst + (size_t)o * p.Cd + n;
@@ -395,6 +411,10 @@ __global__ __launch_bounds__(512) void wino_kernel(WinoParams p) {
             f32x4 v = y[a][b2] + bv;
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], p.act, p.slope);
+            if constexpr (MASK) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) v[c] *= act_grad(mk[a][b2][c], SRGAN_ACT_LRELU, p.mask_slope);
+            }
             *reinterpret_cast<f32x4*>(dp + (size_t)(a * p.Wo + b2) * PS * p.Cd) = v;
           }
     }
@@ -902,8 +922,10 @@ bool wino43_fwd_applicable(const srgan_conv_desc* d) { return wino_variant(d, 0)
 bool wino43_dgrad_applicable(const srgan_conv_desc* d) { return d->pad_mode == SRGAN_PAD_ZERO && wino_variant(d, 1) == 3; }
 
 int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* packed, const float* bias, float* dst,
-             int act, float slope, float* scratch, hipStream_t st, const float* res, bool* res_done, bool v_ready) {
+             int act, float slope, float* scratch, hipStream_t st, const float* res, bool* res_done, bool v_ready,
+             const float* mask, float mask_slope, bool* mask_done) {
   if (res_done) *res_done = false;
+  if (mask_done) *mask_done = false;
   WinoParams p{};
   p.act = act; p.slope = slope;
   int C, N, phases;
@@ -961,7 +983,11 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
   ProfToken tok = prof_begin(variant == 1 ? 14 : 16, conv_flops_of(d), st);
   if (variant == 1) hipLaunchKernelGGL(wino_kernel<0>, dim3((unsigned)grid), dim3(512), 0, st, p);
   else if (kind == 0) hipLaunchKernelGGL(wino_kernel<1>, dim3((unsigned)grid), dim3(512), 0, st, p);
-  else hipLaunchKernelGGL(wino_kernel<2>, dim3((unsigned)grid, 4), dim3(512), 0, st, p);
+  else if (mask) {
+    p.mask = mask; p.mask_slope = mask_slope;
+    if (mask_done) *mask_done = true;
+    hipLaunchKernelGGL((wino_kernel<2, true>), dim3((unsigned)grid, 4), dim3(512), 0, st, p);
+  } else hipLaunchKernelGGL(wino_kernel<2>, dim3((unsigned)grid, 4), dim3(512), 0, st, p);
   prof_end(tok, st);
   return check_launch("wino_kernel");
 }

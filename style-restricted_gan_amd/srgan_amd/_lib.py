@@ -35,6 +35,7 @@ SIGNATURES = {
     "srgan_conv2d_pack_signature": (ctypes.c_ulonglong, [_DESC, c_int, c_int]),
     "srgan_conv2d_fwd_packed": (c_int, [_DESC, P, P, P, P, c_int, c_float, P, c_size_t, P]),
     "srgan_conv2d_dgrad_packed": (c_int, [_DESC, P, P, P, P, c_size_t, P]),
+    "srgan_conv2d_dgrad_packed_mask": (c_int, [_DESC, P, P, P, c_float, P, P, c_size_t, P]),
     "srgan_conv2d_dgrad_packed_add": (c_int, [_DESC, P, P, P, P, P, c_size_t, P]),
     "srgan_instnorm_conv_v_applicable": (c_int, [_DESC]),
     "srgan_instnorm_fwd_v": (c_int, [_DESC, P, P, P, P, P, P, c_size_t, c_float, c_int, c_float, P]),

@@ -36,9 +36,9 @@ E_SLOPE = 0.2    # nn.LeakyReLU(0.2) in the encoders               (model.py:357
 class _Conv2d(nn.Conv2d):
     """nn.Conv2d parameters; forward = implicit-GEMM MFMA kernel (optionally fused LeakyReLU)."""
 
-    def forward(self, x, act=ACT_NONE, slope=0.0):
+    def forward(self, x, act=ACT_NONE, slope=0.0, in_slope=None, act_bwd_by_consumer=False):
         mode = PAD_REFLECT if self.padding_mode == "reflect" else PAD_ZERO
-        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], mode, act, slope)
+        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], mode, act, slope, in_slope, act_bwd_by_consumer)
 
 
 class _ConvTranspose2d(nn.ConvTranspose2d):
@@ -309,17 +309,34 @@ def _d_trunk_layers(nch_in, nch, reduce, num_cls):
     return layers, dim_in
 
 
+_CHAIN_ACT_BWD = not os.environ.get("SRGAN_NO_CHAIN_ACT_BWD")
+
+
 def _run_trunk(seq, x):
-    """conv + LeakyReLU pairs run as one fused kernel each; a trailing bias conv runs plain."""
+    """conv + LeakyReLU pairs run as one fused kernel each; a trailing bias conv runs plain.  Inside the chain a pair's
+    LeakyReLU backward is done by the NEXT conv's input-gradient kernel (ops._Conv2dFn: the intermediate tensors have no other
+    consumer); the last pair -- its output leaves the trunk -- keeps its own."""
     mods = list(seq)
+    steps = []                                   # (conv, slope or None)
     i = 0
     while i < len(mods):
         if i + 1 < len(mods) and isinstance(mods[i + 1], _LeakyReLU):
-            x = mods[i](x, ACT_LRELU, mods[i + 1].negative_slope)
+            steps.append((mods[i], mods[i + 1].negative_slope))
             i += 2
         else:
-            x = mods[i](x)
+            steps.append((mods[i], None))
             i += 1
+    prev_slope = None                            # slope of the previous pair when its backward was handed to this conv
+    for j, (m, slope) in enumerate(steps):
+        hand_on = (_CHAIN_ACT_BWD and slope is not None and j + 1 < len(steps) and isinstance(m, _Conv2d)
+                   and isinstance(steps[j + 1][0], _Conv2d) and torch.is_grad_enabled())
+        if isinstance(m, _Conv2d):
+            x = m(x, ACT_LRELU if slope is not None else ACT_NONE, slope or 0.0, prev_slope, hand_on)
+        elif slope is not None:
+            x = m(x, ACT_LRELU, slope)
+        else:
+            x = m(x)
+        prev_slope = slope if hand_on else None
     return x
 
 

@@ -422,13 +422,22 @@ def _run_conv_fwd(desc, x, weight, bias, y, act, slope, keep_v=None):
                                     float(slope), _ptr(ws), nb, _stream()), "conv2d_fwd")
 
 
-def _run_conv_dgrad(desc, dy, weight, dx, res=None):
+def _run_conv_dgrad(desc, dy, weight, dx, res=None, mask=None, mask_slope=0.0):
     """dx = input gradient (+ res: the gradient of a skip connection that shares the conv's input, added in the kernel's
-    epilogue where the dispatch supports it)."""
+    epilogue where the dispatch supports it) (* LeakyReLU'(mask): the activation backward of the layer that produced the
+    conv's input, in the epilogue of the transposed stride-2 Winograd kernel, else one in-place pass)."""
     lib = _lib.load()
+    if mask is not None and (res is not None or not _pack_cache_on):
+        _run_conv_dgrad(desc, dy, weight, dx, res)
+        _lib.check(lib.srgan_act_bwd(_ptr(mask), _ptr(dx), _ptr(dx), dx.numel(), ACT_LRELU, float(mask_slope), _stream()), "act_bwd")
+        return
     if _pack_cache_on:
         hit, scratch = _packed(desc, weight, 1, ACT_NONE)
         ws = workspace(dy.device, scratch) if scratch else None
+        if mask is not None:
+            _lib.check(lib.srgan_conv2d_dgrad_packed_mask(ctypes.byref(desc), _ptr(dy), _ptr(hit.buf), _ptr(mask), float(mask_slope),
+                                                          _ptr(dx), _ptr(ws), scratch, _stream()), "conv2d_dgrad_packed_mask")
+            return
         if res is not None:
             _lib.check(lib.srgan_conv2d_dgrad_packed_add(ctypes.byref(desc), _ptr(dy), _ptr(hit.buf), _ptr(res), _ptr(dx), _ptr(ws),
                                                          scratch, _stream()), "conv2d_dgrad_packed_add")
@@ -562,10 +571,16 @@ def _act_bwd(y, gy, act, slope):
 class _Conv2dFn(Function):
     """``skip=True``: also returns the input itself as a second output -- the tensor a residual connection should use.  Its
     gradient then arrives in THIS backward next to the conv output's, and the input-gradient kernel adds it in its epilogue
-    (``srgan_conv2d_dgrad_packed_add``) instead of autograd accumulating the two paths with a separate pass."""
+    (``srgan_conv2d_dgrad_packed_add``) instead of autograd accumulating the two paths with a separate pass.
+
+    A chain conv + LeakyReLU -> conv (+ LeakyReLU) -> ... whose intermediate tensors have no other consumer (the discriminator
+    trunk, ``model._run_trunk``) moves each activation's backward into the NEXT layer's input-gradient kernel: the producer is
+    called with ``act_bwd_by_consumer=True`` (its backward takes the incoming gradient as already multiplied by its own
+    activation's derivative) and the consumer with ``in_slope`` = the producer's slope (its input gradient is multiplied by 1 or
+    ``in_slope`` after the sign of its input: ``srgan_conv2d_dgrad_packed_mask``)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, pad_mode, act, slope, skip=False):
+    def forward(ctx, x, weight, bias, stride, pad, pad_mode, act, slope, skip=False, in_slope=None, act_bwd_by_consumer=False):
         x = to_nhwc(x)
         _require_gpu(weight, "conv2d weight")
         n, i, hi, wi = x.shape
@@ -588,7 +603,10 @@ class _Conv2dFn(Function):
         ctx.weight = weight            # by reference: read at backward time (torch 1.4 semantics)
         ctx.has_bias = bias is not None
         ctx.bias = bias
-        ctx.save_for_backward(x, y if act != ACT_NONE else None)
+        ctx.in_slope, ctx.act_bwd_by_consumer = in_slope, bool(act_bwd_by_consumer) and act == ACT_LRELU
+        if in_slope is not None and skip:
+            raise _lib.SrganHipError("conv2d: in_slope and skip do not combine")
+        ctx.save_for_backward(x, y if (act != ACT_NONE and not ctx.act_bwd_by_consumer) else None)
         if skip:
             return y, x
         return y
@@ -599,16 +617,19 @@ class _Conv2dFn(Function):
         weight = ctx.weight
         dx = dw = db = None
         if gy is None:                     # only the skip path was used downstream
-            return (to_nhwc(gskip) if gskip is not None else None), None, None, None, None, None, None, None, None
+            return (to_nhwc(gskip) if gskip is not None else None), None, None, None, None, None, None, None, None, None, None
         gy = to_nhwc(gy)
-        if ctx.act != ACT_NONE:
+        if ctx.act != ACT_NONE and not ctx.act_bwd_by_consumer:
             gy = _act_bwd(y, gy, ctx.act, ctx.slope)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             res = to_nhwc(gskip) if gskip is not None else None
             if res is not None and res.data_ptr() == dx.data_ptr():
                 res = res.clone()
-            _run_conv_dgrad(ctx.desc, gy, weight, dx, res)
+            if ctx.in_slope is not None:
+                _run_conv_dgrad(ctx.desc, gy, weight, dx, res, x, ctx.in_slope)
+            else:
+                _run_conv_dgrad(ctx.desc, gy, weight, dx, res)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             slots = _sink_slots(*((weight, ctx.bias) if ctx.has_bias else (weight,)))
             acc = False
@@ -625,11 +646,12 @@ class _Conv2dFn(Function):
                 _run_conv_wgrad(desc, x, gy, dw, db, ctx.v_image)
             if slots is not None:
                 dw = db = None
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0):
-    return _Conv2dFn.apply(x, weight, bias, stride, padding, pad_mode, act, slope)
+def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, in_slope=None,
+           act_bwd_by_consumer=False):
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, pad_mode, act, slope, False, in_slope, act_bwd_by_consumer)
 
 
 def conv2d_skip(x, weight, bias=None, stride=1, padding=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0):

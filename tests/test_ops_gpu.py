@@ -1012,3 +1012,35 @@ def test_multi_pack_launch_equals_single_pack_implicit_gemm(ops, o, i, k, s, p):
         close(y, ref, 2e-5)
     finally:
         ops.invalidate_packed()
+
+
+@pytest.mark.parametrize("n,c0,c1,c2,hw,packed", [(8, 64, 128, 256, 64, True), (2, 8, 16, 24, 16, True), (2, 32, 64, 64, 32, False)])
+def test_leaky_relu_backward_in_the_consumers_input_gradient(ops, n, c0, c1, c2, hw, packed):
+    """conv(4x4, s2) + LeakyReLU(0.2) -> conv(4x4, s2): the first layer is told that its activation's backward is done by its
+    consumer (``act_bwd_by_consumer``), the second one multiplies its input gradient by LeakyReLU'(its input)
+    (``in_slope`` -> srgan_conv2d_dgrad_packed_mask: in the epilogue of the transposed F(3x3,2x2) kernel for the first shape,
+    one in-place pass behind the implicit GEMM for the second, the unpacked entry points for the third).  Outputs and all three
+    gradients against PyTorch on the CPU, and against the unchained call of the same kernels."""
+    import contextlib
+    x = rnd(n, c0, hw, hw, seed=31)
+    w1 = rnd(c1, c0, 4, 4, seed=32) / np.sqrt(c0 * 16)
+    w2 = rnd(c2, c1, 4, 4, seed=33) / np.sqrt(c1 * 16)
+    gy = rnd(n, c2, hw // 4, hw // 4, seed=34)
+    xr, w1r, w2r = (t.clone().requires_grad_(True) for t in (x, w1, w2))
+    F.conv2d(F.leaky_relu(F.conv2d(xr, w1r, None, 2, 1), 0.2), w2r, None, 2, 1).backward(gy)
+    res = {}
+    ops.invalidate_packed()
+    try:
+        for chained in (False, True):
+            xg, w1g, w2g = (t.clone().cuda().requires_grad_(True) for t in (x, w1, w2))
+            with (ops.pack_cache() if packed else contextlib.nullcontext()):
+                h = ops.conv2d(xg, w1g, None, 2, 1, ops.PAD_ZERO, ops.ACT_LRELU, 0.2, None, chained)
+                y = ops.conv2d(h, w2g, None, 2, 1, ops.PAD_ZERO, ops.ACT_NONE, 0.0, 0.2 if chained else None, False)
+                y.backward(gy.cuda())
+            res[chained] = (y.detach(), xg.grad, w1g.grad, w2g.grad)
+    finally:
+        ops.invalidate_packed()
+    for got, want in zip(res[True][1:], (xr.grad, w1r.grad, w2r.grad)):
+        close(got, want, 3e-5)
+    for a, b in zip(res[True], res[False]):
+        close(a, b, 1e-6)
