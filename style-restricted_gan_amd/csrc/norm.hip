@@ -118,6 +118,17 @@ __global__ __launch_bounds__(256) void in_bwd_partial_v4(const float* __restrict
   }
 }
 
+// {sum (x - x0), sum (x - x0)^2} over the image -> mean, 1 / sqrt(var + eps); one definition for the stand-alone final kernel
+// and for the apply kernels that finish the statistics themselves (same expression, same contraction, same bits)
+__device__ __forceinline__ void stats_finish(float a, float b, float x0, int HW, float eps, float* mu, float* rs) {
+  const float inv = 1.f / (float)HW;
+  const float dm = a * inv;
+  float var = b * inv - dm * dm;
+  var = var < 0.f ? 0.f : var;
+  *mu = x0 + dm;
+  *rs = 1.0f / sqrtf(var + eps);
+}
+
 __global__ void in_stats_final(const float* __restrict__ x, const float2* __restrict__ part, float* __restrict__ mean,
                                float* __restrict__ rstd, int N, int HW, int C, int S, float eps) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,12 +140,20 @@ __global__ void in_stats_final(const float* __restrict__ x, const float2* __rest
     a += p.x;
     b += p.y;
   }
-  const float inv = 1.f / (float)HW;
-  const float dm = a * inv;
-  float var = b * inv - dm * dm;
-  var = var < 0.f ? 0.f : var;
-  mean[idx] = x[(size_t)n * HW * C + c] + dm;
-  rstd[idx] = 1.0f / sqrtf(var + eps);
+  stats_finish(a, b, x[(size_t)n * HW * C + c], HW, eps, &mean[idx], &rstd[idx]);
+}
+
+// the S partial pairs of this thread's four channels, summed in split order (what in_stats_final / in_bwd_final do per channel)
+__device__ __forceinline__ void sum_partials4(const float2* __restrict__ part, int n, int S, int C, int c, f32x4* a, f32x4* b) {
+  f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(part + ((size_t)n * S + s) * C + c);      // (x0 y0 x1 y1), (x2 y2 x3 y3)
+    const f32x4 lo = q[0], hi = q[1];
+    sa[0] += lo[0]; sb[0] += lo[1]; sa[1] += lo[2]; sb[1] += lo[3];
+    sa[2] += hi[0]; sb[2] += hi[1]; sa[3] += hi[2]; sb[3] += hi[3];
+  }
+  *a = sa;
+  *b = sb;
 }
 
 template <bool V4>
@@ -171,15 +190,37 @@ __global__ void in_apply(const float* __restrict__ x, const float* __restrict__ 
 // Fast apply passes for power-of-two channel counts (C | 1024): with a float4 stride of 256*G per image a thread
 // always lands on the same 4 channels, so mean / rstd / scale / shift live in registers and the streaming loop has
 // no index arithmetic (grid = (G, N)).
+// `part` != null (round 3): the statistics arrive as the S partial pairs of in_stats_partial and every thread finishes its own
+// four channels (a few KB from L2) -- the 5.6 us in_stats_final launch between the two passes is gone; workgroup x = 0 of an
+// image stores mean / rstd for the backward pass.
 __global__ __launch_bounds__(256) void in_apply_pow2(const float* __restrict__ x, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, const float* __restrict__ res,
-                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     float* __restrict__ y, int HWC4, int C, int act, float slope) {
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     float* __restrict__ y, int HWC4, int C, int act, float slope,
+                                                     const float2* __restrict__ part, int S, int HW, float eps) {
   const int n = blockIdx.y;
   const int c = (threadIdx.x * 4) % C;
   const int nc = n * C + c;
-  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + nc);
-  const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + nc);
+  f32x4 mu, rs;
+  if (part) {
+    f32x4 a, b;
+    sum_partials4(part, n, S, C, c, &a, &b);
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + (size_t)n * HWC4 * 4 + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float m1, r1;
+      stats_finish(a[e], b[e], x0[e], HW, eps, &m1, &r1);
+      mu[e] = m1;
+      rs[e] = r1;
+    }
+    if (blockIdx.x == 0 && threadIdx.x * 4 < C) {
+      *reinterpret_cast<f32x4*>(mean + nc) = mu;
+      *reinterpret_cast<f32x4*>(rstd + nc) = rs;
+    }
+  } else {
+    mu = *reinterpret_cast<const f32x4*>(mean + nc);
+    rs = *reinterpret_cast<const f32x4*>(rstd + nc);
+  }
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
   if (scale) {
     sc = *reinterpret_cast<const f32x4*>(scale + nc);
@@ -201,9 +242,9 @@ __global__ __launch_bounds__(256) void in_apply_pow2(const float* __restrict__ x
 __global__ __launch_bounds__(256) void in_bwd_apply_pow2(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* __restrict__ dshift, const float* __restrict__ dscale,
+                                                         float* __restrict__ dshift, float* __restrict__ dscale,
                                                          float* __restrict__ dx, int HWC4, int C, float inv_hw, int act,
-                                                         float slope) {
+                                                         float slope, const float2* __restrict__ part, int S) {
   const int n = blockIdx.y;
   const int c = (threadIdx.x * 4) % C;
   const int nc = n * C + c;
@@ -214,8 +255,19 @@ __global__ __launch_bounds__(256) void in_bwd_apply_pow2(const float* __restrict
     sc = *reinterpret_cast<const f32x4*>(scale + nc);
     sf = *reinterpret_cast<const f32x4*>(shift + nc);
   }
-  const f32x4 mg = *reinterpret_cast<const f32x4*>(dshift + nc) * inv_hw;
-  const f32x4 mgx = *reinterpret_cast<const f32x4*>(dscale + nc) * inv_hw;
+  f32x4 ds, dsc;
+  if (part) {              // the sums of in_bwd_partial finished here instead of by an in_bwd_final launch (see in_apply_pow2)
+    sum_partials4(part, n, S, C, c, &ds, &dsc);
+    if (blockIdx.x == 0 && threadIdx.x * 4 < C) {
+      *reinterpret_cast<f32x4*>(dshift + nc) = ds;
+      *reinterpret_cast<f32x4*>(dscale + nc) = dsc;
+    }
+  } else {
+    ds = *reinterpret_cast<const f32x4*>(dshift + nc);
+    dsc = *reinterpret_cast<const f32x4*>(dscale + nc);
+  }
+  const f32x4 mg = ds * inv_hw;
+  const f32x4 mgx = dsc * inv_hw;
   const f32x4 k = rs * sc;
   const size_t base = (size_t)n * HWC4;
   const f32x4* xp = reinterpret_cast<const f32x4*>(x) + base;
@@ -717,12 +769,21 @@ extern "C" int srgan_instnorm_fwd(const float* x, const float* scale, const floa
     else hipLaunchKernelGGL(in_stats_partial, g, dim3(256), 0, st, x, part, HW, C, S, 1);
   } else if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4, g, dim3(256), 0, st, x, part, HW, C, S, rps);
   else hipLaunchKernelGGL(in_stats_partial, g, dim3(256), 0, st, x, part, HW, C, S, rps);
-  hipLaunchKernelGGL(in_stats_final, dim3((N * C + 255) / 256), dim3(256), 0, st, x, (const float2*)part, mean, rstd, N, HW, C, S, eps);
   const long long total = (long long)N * HW * C;
+  static const bool fuse_final = std::getenv("SRGAN_NORM_SEPARATE_FINAL") == nullptr;
+  if (pow2_fast(C, HW) && fuse_final) {
+    const int hwc4 = HW * C / 4;
+    dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
+    hipLaunchKernelGGL(in_apply_pow2, g2, dim3(256), 0, st, x, scale, shift, res, mean, rstd, y, hwc4, C, act, slope,
+                       (const float2*)part, S, HW, eps);
+    return check_launch("instnorm_fwd");
+  }
+  hipLaunchKernelGGL(in_stats_final, dim3((N * C + 255) / 256), dim3(256), 0, st, x, (const float2*)part, mean, rstd, N, HW, C, S, eps);
   if (pow2_fast(C, HW)) {
     const int hwc4 = HW * C / 4;
     dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
-    hipLaunchKernelGGL(in_apply_pow2, g2, dim3(256), 0, st, x, scale, shift, res, mean, rstd, y, hwc4, C, act, slope);
+    hipLaunchKernelGGL(in_apply_pow2, g2, dim3(256), 0, st, x, scale, shift, res, mean, rstd, y, hwc4, C, act, slope,
+                       (const float2*)nullptr, 0, HW, eps);
   } else if ((C & 3) == 0) {
     unsigned blocks = (unsigned)std::min<long long>(ceil_div(total / 4, 256), 8192);
     hipLaunchKernelGGL(in_apply<true>, dim3(blocks), dim3(256), 0, st, x, scale, shift, res, mean, rstd, y, total, HW * C, C, act, slope);
@@ -758,13 +819,22 @@ extern "C" int srgan_instnorm_bwd(const float* x, const float* dy, const float* 
   dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
   if ((C & 3) == 0) hipLaunchKernelGGL(in_bwd_partial_v4, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
   else hipLaunchKernelGGL(in_bwd_partial, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
-  hipLaunchKernelGGL(in_bwd_final, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float2*)part, dshift, dscale, N * C, C, S);
   const long long total = (long long)N * HW * C;
   const float inv_hw = 1.f / (float)HW;
+  static const bool fuse_final = std::getenv("SRGAN_NORM_SEPARATE_FINAL") == nullptr;
+  if (pow2_fast(C, HW) && fuse_final) {
+    const int hwc4 = HW * C / 4;
+    dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
+    hipLaunchKernelGGL(in_bwd_apply_pow2, g2, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, hwc4, C, inv_hw, act,
+                       slope, (const float2*)part, S);
+    return check_launch("instnorm_bwd");
+  }
+  hipLaunchKernelGGL(in_bwd_final, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float2*)part, dshift, dscale, N * C, C, S);
   if (pow2_fast(C, HW)) {
     const int hwc4 = HW * C / 4;
     dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
-    hipLaunchKernelGGL(in_bwd_apply_pow2, g2, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, hwc4, C, inv_hw, act, slope);
+    hipLaunchKernelGGL(in_bwd_apply_pow2, g2, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, hwc4, C, inv_hw, act,
+                       slope, (const float2*)nullptr, 0);
   } else if ((C & 3) == 0) {
     unsigned blocks = (unsigned)std::min<long long>(ceil_div(total / 4, 256), 8192);
     hipLaunchKernelGGL(in_bwd_apply<true>, dim3(blocks), dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, total, HW * C, C, inv_hw, act, slope);
