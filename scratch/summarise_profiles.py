@@ -20,7 +20,7 @@ def prof_name(n):
     m = re.match(r"wino_wgrad_kernel<(\d)>", n)
     if m:
         return "wino_wgrad_kernel" if m.group(1) == "0" else "wino_wgrad_kernel<4x4s2>"
-    m = re.match(r"wino_kernel<(\d)>", n)
+    m = re.match(r"wino_kernel<(\d)(?:, (?:true|false))?>", n)
     if m:
         return "wino_kernel" if m.group(1) == "0" else "wino_kernel<4x4s2>"
     if n.startswith("rgbin_conv_kernel"):
