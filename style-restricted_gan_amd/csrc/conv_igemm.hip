@@ -1049,6 +1049,24 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, fl
   if (lane == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
+// at most four columns (the discriminator's PatchGAN and class heads: the only biased convolutions of a train step): one
+// workgroup, thread t sums rows t, t + 256, ... of every column, the 256 partial sums meet in LDS and are added in thread order
+// -- one launch instead of the partial + final pair (25 pairs per step)
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* __restrict__ a, float* __restrict__ out, int M, int C,
+                                                            int accumulate) {
+  __shared__ float sh[4][256];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int m = threadIdx.x; m < M; m += 256)
+    for (int c = 0; c < C; ++c) s[c] += a[(size_t)m * C + c];
+  for (int c = 0; c < C; ++c) sh[c][threadIdx.x] = s[c];
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t = 0.f;
+    for (int i = 0; i < 256; ++i) t += sh[threadIdx.x][i];
+    out[threadIdx.x] = accumulate ? out[threadIdx.x] + t : t;
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------------
 namespace {
 
@@ -2153,6 +2171,10 @@ static int finish_wgrad(const srgan_conv_desc* d, const WgradPlan& w, const floa
   (void)total;
   if (dbias) {
     const int M = d->N * d->Ho * d->Wo;
+    if (d->O <= 4 && M <= (1 << 16)) {
+      hipLaunchKernelGGL(colsum_narrow_kernel, dim3(1), dim3(256), 0, st, dy, dbias, M, d->O, g_wgrad_accumulate);
+      return check_launch("colsum_narrow_kernel");
+    }
     float* part = (float*)ws + (size_t)w.splits * w.Cdpad * w.NNpad;
     int nparts = (int)std::min<long long>(1024, ceil_div(M, 64));
     int rpb = (int)ceil_div(M, nparts);
