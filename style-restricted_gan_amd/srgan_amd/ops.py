@@ -485,8 +485,10 @@ _NO_WGRAD_DEFER = bool(_os.environ.get("SRGAN_NO_WGRAD_DEFER"))
 _WGRAD_ARENA_BYTES = int(_os.environ.get("SRGAN_WGRAD_ARENA_MB", "1024")) << 20
 
 
-def _wgrad_arena():
-    dev = torch.device("cuda", torch.cuda.current_device())
+def _wgrad_arena(device=None):
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     key = ("wgrad_arena", dev.index, torch.cuda.current_stream(dev).cuda_stream)
     a = _workspaces.get(key)
     if a is None:
@@ -495,8 +497,12 @@ def _wgrad_arena():
 
 
 class fused_param_grads:
-    def __init__(self, enabled=True):
+    """``device``: where the pass runs (default: the current device) -- the arena of the deferred slab sums lives there and the
+    sums run on that device's current stream."""
+
+    def __init__(self, enabled=True, device=None):
         self._enabled = enabled
+        self._device = device
 
     def __enter__(self):
         global _grad_sink, _defer_depth
@@ -504,8 +510,9 @@ class fused_param_grads:
         _grad_sink = {} if self._enabled else None
         self._defer = False
         if self._enabled and not _NO_WGRAD_DEFER and _defer_depth == 0:
-            a = _wgrad_arena()
-            _lib.check(_lib.load().srgan_wgrad_defer_begin(_ptr(a), a.numel(), _stream()), "wgrad_defer_begin")
+            a = _wgrad_arena(self._device)
+            st = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+            _lib.check(_lib.load().srgan_wgrad_defer_begin(_ptr(a), a.numel(), st), "wgrad_defer_begin")
             self._defer = True
             _defer_depth = 1
         return self

@@ -259,7 +259,7 @@ class SRGAN_training():
             errD_fake, _ = self._d_losses(self.target_image.detach(), 0., None, False)
             errD = errD_real + errD_class * self.lbd["class"] + errD_fake
         self._reduce_arm("D", self.optD)
-        with ops.fused_param_grads(not dp.hooks_need_live_grads()):
+        with ops.fused_param_grads(not dp.hooks_need_live_grads(), self.device):
             errD.backward()
         self._d_pending = self._reduce_start("D", self.optD) or True
         dp.launch_pending()                                         # recorded step: the all-reduces start here ...
@@ -368,7 +368,7 @@ class SRGAN_training():
             self._reduce_arm("E", self.optE)
             # the generator's weights are reached twice in this pass (reconstruction / identity graph and the kept target_image
             # graph): their weight-gradient kernels add the second contribution themselves (ops.fused_param_grads)
-            with ops.fused_param_grads(not dp.hooks_need_live_grads()):
+            with ops.fused_param_grads(not dp.hooks_need_live_grads(), self.device):
                 total_p1.backward(retain_graph=True)     # target_image's graph is needed again in phase 2
         # Data parallel: E's buckets go out first, G's behind them on the same communication stream; E's optimiser step, its
         # repack and phase 2's E(source) forward (which needs the new E, not the new G) then run UNDER G's all-reduce.  The two
@@ -426,7 +426,7 @@ class SRGAN_training():
                     errG_ex = errG_ex + errG_idt_reg * (L["idt_reg"] * (L["idt"] / L["cycle"]))
                     terms["errG_idt_reg"] = errG_idt_reg
             self._reduce_arm("G", self.optG)
-            with ops.fused_param_grads(not dp.hooks_need_live_grads()):
+            with ops.fused_param_grads(not dp.hooks_need_live_grads(), self.device):
                 errG_ex.backward()
         redG = self._reduce_start("G", self.optG)
         if redG is not None:
