@@ -114,9 +114,11 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(size, k, batch):
+def cpu_baseline(size, k, batch, timed_steps=2):
     """The CPU oracle (oracle/, a port of the reference's PyTorch-CPU path) on a bounded sample of the SAME workload: full-width
-    networks, the metric's batch size, k D-updates -- 1 warm-up + 2 timed steps."""
+    networks, the metric's batch size, k D-updates -- 1 warm-up step OF THE SAME SHAPE (it pays the oneDNN primitive creation of
+    every batch-32 / 64 / 128 convolution, the thread pool and the allocator) + 2 timed steps, the MEDIAN reported next to both
+    samples.  ~25 s per step on 16 cores of the GPU box's host: ~80 s in all."""
     from oracle import params as op, trainer as ot
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -125,39 +127,60 @@ def cpu_baseline(size, k, batch):
     PG, PD, PE = (op.fill(s, i) for i, s in enumerate(spec))
     torch.manual_seed(0)
     orc = ot.SRGANOracle(PG, PD, PE, LBD, k, np.eye(4), batch, "mu", 8)
-    orc_w = ot.SRGANOracle(PG, PD, PE, LBD, 1, np.eye(4), 4, "mu", 8)
-    x2, l2 = ot.synthetic_batch(4, size, 4, seed=2)
-    log(f"cpu baseline: warm-up on {cores} threads")
-    orc_w.train(x2, l2)                                   # warm-up (thread pool, allocator, oneDNN primitives): k=1, 4 images
-    log(f"cpu baseline: timed steps at batch {batch}")
-    steps, dt = 0, 0.0
-    while steps < 2 and (steps == 0 or dt < 15.0):        # bounded sample: ~10-30 s of CPU work on the GPU box's host cores
-        x, label = ot.synthetic_batch(batch, size, 4, seed=3 + steps)
+    samples = []
+    for step in range(1 + timed_steps):
+        x, label = ot.synthetic_batch(batch, size, 4, seed=2 + step)
+        log(f"cpu baseline: {'warm-up' if step == 0 else f'timed step {step}'} at batch {batch} on {cores} threads")
         t0 = time.perf_counter()
         orc.train(x, label)
-        dt += time.perf_counter() - t0
-        steps += 1
-        log(f"cpu baseline: step {steps} done, {dt:.1f} s so far")
-    return {"value": round(batch * steps / dt, 4), "unit": "images/sec", "cores": cores, "cpu_model": cpu_model(),
-            "kind": "port",
-            "sample": f"{steps} full train steps (k={k}, fp32, same networks / losses / batch size: {batch} images of "
-                      f"{size}x{size}) of the CPU oracle after a k=1 batch-4 warm-up; {dt:.1f} s on {cores} threads"}
+        dt = time.perf_counter() - t0
+        if step:
+            samples.append(dt)
+        else:
+            warm = dt
+    med = float(np.median(samples))
+    return {"value": round(batch / med, 4), "unit": "images/sec", "cores": cores, "cpu_model": cpu_model(),
+            "kind": "port", "seconds_per_step": [round(s, 2) for s in samples], "warmup_seconds": round(warm, 2),
+            "images_per_sec_samples": [round(batch / s, 4) for s in samples],
+            "sample": f"1 warm-up + {timed_steps} timed, median: full train steps (k={k}, fp32, same networks / losses / batch "
+                      f"size: {batch} images of {size}x{size}) of the CPU oracle, warm-up step of the same shape; "
+                      f"{sum(samples):.1f} s timed on {cores} threads"}
+
+
+def kernel_source_sha():
+    """sha256[:16] over the kernel sources (csrc/*.hip, *.h, *.cpp, Makefile) and the host files that choose the launches: what a
+    committed PMC summary must have been collected on for its bytes to describe THIS build (the GPU box has no .git)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pk = os.path.join(ROOT, "style-restricted_gan_amd")
+    files = sorted(glob.glob(os.path.join(pk, "csrc", "*.hip")) + glob.glob(os.path.join(pk, "csrc", "*.h")) +
+                   glob.glob(os.path.join(pk, "csrc", "*.cpp")) + [os.path.join(pk, "csrc", "Makefile")] +
+                   [os.path.join(pk, "srgan_amd", n) for n in ("ops.py", "model.py", "trainer.py")])
+    for p in files:
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel_name, dtype="f32"):
-    """HBM bytes per launch of `kernel_name` REPLAYED from the committed PMC summary (profiles/r*_pmc_traffic.json, or
-    r*_bf16_pmc_traffic.json for --dtype bf16; collected with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
-    same bench command) -- not measured in this run."""
+    """-> (bytes per launch or None, source file, current): HBM bytes per launch of `kernel_name` from the committed PMC summary
+    (profiles/r*_pmc_traffic.json, or r*_bf16_pmc_traffic.json for --dtype bf16; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes over this same bench command, scratch/collect_evidence.sh).  `current` is True only when the summary records the
+    kernel_source_sha of THIS tree: then it is this build's traffic; otherwise the line carries it as `traffic_replayed` and
+    `traffic` stays null."""
     import glob
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
                    if ("_bf16_" in os.path.basename(f)) == (dtype == "bf16"))
     if not files:
-        return None, None
+        return None, None, False
     try:
-        entry = json.load(open(files[-1]))["kernels"].get(kernel_name)
-        return (entry["hbm_bytes_per_launch"] if entry else None), os.path.relpath(files[-1], ROOT)
+        doc = json.load(open(files[-1]))
+        entry = doc["kernels"].get(kernel_name)
+        return ((entry["hbm_bytes_per_launch"] if entry else None), os.path.relpath(files[-1], ROOT),
+                doc.get("kernel_source_sha") == kernel_source_sha())
     except (OSError, ValueError, KeyError):
-        return None, None
+        return None, None, False
 
 
 GD_GFLOP_PER_IMAGE = {128: 60.54, 256: 243.86}        # (3 F_G - f_G) + (3 F_D - f_D), SURVEY.md 8d
@@ -301,8 +324,9 @@ def first_step_check(first, args, world):
     batch (tests/golden/bench_first_step.json, written by tests/golden/make_bench_first_step.py).  Only the configuration
     the fixture was generated for is compared; everything else must at least be finite."""
     vals = [float(v) for v in first]
-    if os.environ.get("SRGAN_BENCH_NO_CHECK"):       # timing experiments with deliberately wrong kernels (scratch/ only)
-        return {"hip": vals, "oracle": None, "check": "DISABLED (SRGAN_BENCH_NO_CHECK)"}
+    from srgan_amd import _lib
+    if _lib.ab("SRGAN_BENCH_NO_CHECK"):              # ablation builds with deliberately wrong kernels (make exp, scratch/ only)
+        return {"hip": vals, "oracle": None, "check": "DISABLED (SRGAN_BENCH_NO_CHECK next to an experiment build)"}
     if not all(np.isfinite(vals)):
         raise SystemExit(f"bench: non-finite losses in the first step: {vals}")
     if not os.path.exists(FIRST_STEP_FIXTURE):
@@ -373,10 +397,19 @@ def main():
     if world > 1:
         torch.set_num_threads(max(1, host_cores() // world))
     lib = _lib.load()
+    exit_code = 0
     if args.dtype == "bf16":
         from srgan_amd import ops as _ops
         _ops.set_compute_dtype("bf16")
     B = args.batch_per_gpu
+    # which physical device every rank drives (the driver checks that N ranks saw N devices)
+    me = (rank, str(device), torch.cuda.get_device_properties(device).name, getattr(torch.cuda.get_device_properties(device), "uuid", None))
+    me = (me[0], me[1], me[2], str(me[3]) if me[3] is not None else None)
+    devices = [me]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, me, group=dp.control_group())
+        devices = sorted(devices)
     sg = build_trainer(args.size, B * world, args.k, device, args.pretrained_e)
     torch.manual_seed(1000 + rank)           # per-rank noise stream after identical construction
 
@@ -499,7 +532,8 @@ def main():
         step_ms_mean = 1e3 * elapsed / args.steps
         for kk in kernels.values():
             kk.pop("_ms"), kk.pop("_fl")
-        traffic, traffic_src = pmc_traffic(name, args.dtype)
+        traffic, traffic_src, traffic_current = pmc_traffic(name, args.dtype)
+        switches = _lib.active_switches()
         gflop_img = (GFLOP_PER_IMAGE_FROZEN_E if args.pretrained_e else GFLOP_PER_IMAGE).get(args.size)
         out = {
             "metric": "images/sec G+D+E train step, CelebA 128x128 bs=32/GPU" if (args.size == 128 and B == 32) else
@@ -516,6 +550,11 @@ def main():
                                    (", E trunk frozen (BASELINE configs[2])" if args.pretrained_e else ", E trainable (BASELINE configs[1])"),
                        "global_batch": B * world, "unrolled_k": args.k, "parallelism": f"dp{world}",
                        "graph_fallback": graph_fallback,
+                       "backend": (dist.get_backend() if world > 1 else None),
+                       "ranks_seen": (dist.get_world_size() if world > 1 else 1), "devices": devices,
+                       "gradient_message_dtype": (dp.bucket_dtype() if world > 1 else None),
+                       "kernel_source_sha": kernel_source_sha(),
+                       "experiment_switches": switches,
                        "execution": ("eager launches (hipGraph recording FAILED on some rank: all ranks fell back)" if graph_fallback else
                                      "eager launches" if not graphed else "hipGraph replay of the captured step" if world == 1 else
                                      f"hipGraph segments replayed with the {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} "
@@ -526,10 +565,13 @@ def main():
                        "losses_last_step": [round(v, 4) for v in last]},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": round(executed, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(executed / peak, 4),
-                         "traffic": traffic,
+                         "traffic": traffic if traffic_current else None,
+                         "traffic_replayed": None if traffic_current else traffic,
                          "traffic_note": "no PMC entry for this kernel under profiles/" if traffic is None else
-                                         f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC) REPLAYED from {traffic_src}: "
-                                         "collected over this same command in separate --pmc passes, not measured in this run",
+                                         (f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC) from {traffic_src}, collected "
+                                          "over this same command in separate --pmc passes" +
+                                          (" ON THIS BUILD (the summary records this tree's kernel_source_sha)" if traffic_current else
+                                           " on an EARLIER build (kernel_source_sha differs): replayed, not this build's traffic")),
                          "achieved_note": "achieved / frac = MFMA FLOPs this kernel actually ISSUES (algorithmic conv FLOPs / "
                                           f"{div:g}) / HIP-event duration, against the dense matrix peak: the utilisation of the matrix pipe",
                          "algorithmic_tflops": round(algorithmic, 2), "algorithmic_over_peak": round(algorithmic / peak, 4),
@@ -556,9 +598,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, args.k, B)
         print(json.dumps(out))
+        if switches:
+            log(f"experiment build / switches active ({switches}): the line above is NOT a result of the product library")
+            exit_code = 3
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

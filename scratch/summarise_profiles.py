@@ -64,11 +64,21 @@ def counter(sub, name):
     return agg
 
 
+def evidence_sha():
+    """kernel_source_sha of the tree the evidence run executed (bench.py prints it in config): bench.py reports a PMC summary as
+    THIS build's traffic only when it matches the running tree's."""
+    p = os.path.join(ev, "bench_plain.json")
+    try:
+        return json.loads(open(p).read().strip().splitlines()[-1])["config"]["kernel_source_sha"]
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
 fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
 out = {"_doc": "Per-launch averages of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py "
-               "--steps 2 --warmup 1 --graph off --no-cpu-baseline --no-micro`; hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (KB*1024): on gfx950 "
+               "--steps 5 --warmup 1 --graph off --no-cpu-baseline --no-micro`; hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (KB*1024): on gfx950 "
                "FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact.",
-       "kernels": {}}
+       "kernel_source_sha": evidence_sha(), "kernels": {}}
 for k in sorted(fetch):
     f, w = sum(fetch[k]) / len(fetch[k]), sum(write[k]) / max(len(write[k]), 1)
     out["kernels"][k] = {"launches": len(fetch[k]), "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
@@ -79,10 +89,10 @@ json.dump(out, open(os.path.join(root, "profiles", pmc_tag + "_pmc_traffic.json"
 # 32x32x2 instruction); GRBM_GUI_ACTIVE is summed over the 8 XCDs, so GUI/8 is the kernel's length in shader cycles
 if glob.glob(os.path.join(ev, "mfma", "*", "*counter_collection.csv")):
     busy, gui = counter("mfma", "SQ_VALU_MFMA_BUSY_CYCLES"), counter("mfma", "GRBM_GUI_ACTIVE")
-    util = {"_doc": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over `python3 bench.py --steps 2 --warmup 1 "
+    util = {"_doc": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over `python3 bench.py --steps 5 --warmup 1 "
                     "--graph off --no-cpu-baseline --no-micro`; per kernel: sum over launches of MFMA busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8). "
                     "Launches shorter than ~0.3 ms over-count GUI cycles (MI355X_MICROARCH.md, DVFS), so small kernels read low.",
-            "kernels": {}}
+            "kernel_source_sha": evidence_sha(), "kernels": {}}
     for k in sorted(busy):
         b, g = sum(busy[k]), sum(gui[k])
         util["kernels"][k] = {"launches": len(busy[k]), "mfma_busy_cycles": int(b), "gui_active": int(g),

@@ -31,6 +31,23 @@ inline int check_launch(const char* what) {
     }                                       \
   } while (0)
 
+// Timing ablations (wrong results) and phase stamps are compile-time variants of the kernels: never in the product library.
+#if !defined(SRGAN_EXPERIMENTS) && (defined(WINO_EXP) || defined(RGBOUT_EXP) || defined(W43_DIAG))
+#error "WINO_EXP / RGBOUT_EXP / W43_DIAG are experiment builds: make exp EXPFLAGS=-DWINO_EXP=n (writes scratch/libsrgan_exp.so)"
+#endif
+
+// A/B switches of the measurement scripts under scratch/: only `make exp` (-DSRGAN_EXPERIMENTS, which writes
+// scratch/libsrgan_exp.so, loaded through SRGAN_HIP_LIB) reads them from the environment.  In the product library every switch is
+// a compile-time constant and its name is not in the binary (tests/test_abi_cpu.py checks the strings).
+#ifdef SRGAN_EXPERIMENTS
+#include <cstdlib>
+#define SRGAN_AB_SET(name) (std::getenv(name) != nullptr)
+#define SRGAN_AB_INT(name, dflt) (std::getenv(name) ? std::atoll(std::getenv(name)) : (long long)(dflt))
+#else
+#define SRGAN_AB_SET(name) false
+#define SRGAN_AB_INT(name, dflt) ((long long)(dflt))
+#endif
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }

@@ -601,7 +601,7 @@ int launch_c(const Halo16Params& p, bool in16, bool out16, long long grid, hipSt
 
 // the layer shapes the kernel is instantiated for: square channel counts 64 / 128 / 256, maps of whole 4 x 32 patches
 bool halo16_applicable(const srgan_conv_desc* d, int kind) {
-  static const bool off = std::getenv("SRGAN_NO_HALO16") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_HALO16");
   if (off || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != SRGAN_PAD_ZERO) return false;
   if (d->I != d->O || !(d->I == 64 || d->I == 128 || d->I == 256)) return false;
   if (d->Hi % 4 != 0 || d->Wi % 32 != 0 || d->Ho != d->Hi || d->Wo != d->Wi) return false;
@@ -632,7 +632,7 @@ int halo16_run(const srgan_conv_desc* d, int kind, const void* src, const void* 
 
 // ---- transposed 4x4 / stride-2 form: kind 1 of a strided layer d (its input gradient = a ConvTranspose2d forward) ----
 bool halo16t_applicable(const srgan_conv_desc* d) {
-  static const bool off = std::getenv("SRGAN_NO_HALO16T") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_HALO16T");
   if (off || d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 1 || d->pad_mode != SRGAN_PAD_ZERO) return false;
   if (!((d->O == 256 && d->I == 128) || (d->O == 128 && d->I == 64))) return false;
   if (d->Hi != 2 * d->Ho || d->Wi != 2 * d->Wo || d->Ho % 4 != 0 || d->Wo % 32 != 0) return false;
@@ -668,7 +668,7 @@ static void halo16_wgrad_plan(const srgan_conv_desc* d, Halo16WgradParams* p) {
 }
 
 bool halo16_wgrad_applicable(const srgan_conv_desc* d) {
-  static const bool off = std::getenv("SRGAN_NO_HALO16_WGRAD") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_HALO16_WGRAD");
   return !off && halo16_applicable(d, 0);
 }
 

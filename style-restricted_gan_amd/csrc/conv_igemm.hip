@@ -1073,7 +1073,7 @@ namespace {
 struct TileChoice { int BM, BN; };
 
 TileChoice choose_tile(long long M, int N) {
-  static const bool big = std::getenv("SRGAN_NO_BIG_TILE") == nullptr;
+  static const bool big = !SRGAN_AB_SET("SRGAN_NO_BIG_TILE");
   if (N <= 32) return {128, 32};
   if (N <= 64) return (big && ceil_div(M, 256) >= 256) ? TileChoice{256, 64} : TileChoice{128, 64};
   long long tiles = ceil_div(M, 128) * ceil_div(N, 128);
@@ -1129,8 +1129,8 @@ static TileChoice final_tile(const IgemmParams& p) {
 
 static SplitKPlan plan_splitk(const IgemmParams& p, int phases) {
   SplitKPlan s{1, 0, (long long)p.NB * p.Hd * p.Wd * p.Cd};
-  static const bool off = std::getenv("SRGAN_NO_SPLITK") != nullptr;
-  static const int target = std::getenv("SRGAN_SPLITK_TARGET") ? std::atoi(std::getenv("SRGAN_SPLITK_TARGET")) : 768;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_SPLITK");
+  static const int target = SRGAN_AB_INT("SRGAN_SPLITK_TARGET", 768);
   const TileChoice tc = final_tile(p);
   if (off || tc.BM == 256 || (p.Cd & 3) != 0 || s.dst_elems >= (1LL << 28)) return s;
   const long long wgs = ceil_div(p.M, tc.BM) * ceil_div(p.Cd, tc.BN) * phases;
@@ -1230,8 +1230,7 @@ static WgradVariant wgrad_variant(bool vec, bool rows) {
 }
 
 static bool wgrad_lookup(int BMc, int BNn, bool vec, bool rows, WgradVariant* k) {
-  if (BMc == 256 && BNn == 128) *k = wgrad_variant<256, 128, 4, 2>(vec, rows);
-  else if (BMc == 128 && BNn == 128) *k = wgrad_variant<128, 128, 2, 2>(vec, rows);
+  if (BMc == 128 && BNn == 128) *k = wgrad_variant<128, 128, 2, 2>(vec, rows);
   else if (BMc == 128 && BNn == 64) *k = wgrad_variant<128, 64, 2, 2>(vec, rows);
   else if (BMc == 128 && BNn == 32) *k = wgrad_variant<128, 32, 4, 1>(vec, rows);
   else if (BMc == 64 && BNn == 128) *k = wgrad_variant<64, 128, 2, 2>(vec, rows);
@@ -1274,10 +1273,8 @@ WgradPlan plan_wgrad(const srgan_conv_desc* d) {
   WgradPlan w;
   const long long M = (long long)d->N * d->Ho * d->Wo;
   const int NN = d->kh * d->kw * d->I;
-  // 8-wave 256x128 weight-gradient tiles: measured SLOWER in the train step (88 vs 98 TFLOP/s, A/B on one device),
-  // kept behind a switch for experiments
-  static const bool big = std::getenv("SRGAN_BIG_WGRAD") != nullptr;
-  w.BMc = d->O <= 32 ? 32 : (d->O <= 64 ? 64 : ((big && d->O % 256 == 0 && d->I % 128 == 0 && M >= 16384) ? 256 : 128));   // 8-wave tiles need long pixel ranges
+  // (8-wave 256x128 weight-gradient tiles were measured SLOWER in the train step: 88 vs 98 TFLOP/s, A/B on one device)
+  w.BMc = d->O <= 32 ? 32 : (d->O <= 64 ? 64 : 128);
   w.vec = (d->I % 32) == 0;
   if (w.vec) w.BNn = (d->I % 128 == 0) ? 128 : ((d->I % 64 == 0) ? 64 : 32);
   else w.BNn = 64;
@@ -1290,12 +1287,9 @@ WgradPlan plan_wgrad(const srgan_conv_desc* d) {
   w.NNpad = w.nn_tiles * w.BNn;
   const long long tiles = (long long)w.co_tiles * w.nn_tiles;
   const long long max_splits = std::max<long long>(1, ceil_div(M, 256));   // at least 8 K-tiles per split
-  static const long long wg_target = std::getenv("SRGAN_WGRAD_BLOCKS") ? std::atoll(std::getenv("SRGAN_WGRAD_BLOCKS")) : 512;
-  static const bool legacy = std::getenv("SRGAN_WGRAD_LEGACY_SPLIT") != nullptr;
+  static const long long wg_target = SRGAN_AB_INT("SRGAN_WGRAD_BLOCKS", 512);
   long long splits;
-  if (legacy) {
-    splits = ceil_div(w.BMc == 256 ? wg_target / 2 : wg_target, tiles);
-  } else {
+  {
     // about wg_target blocks, rounded to whole device rounds; among the candidate round counts take the best-filled
     const long long slots = wgrad_round_slots(w);
     const long long r0 = std::max<long long>(1, (wg_target + slots / 2) / slots);
@@ -1381,7 +1375,7 @@ enum FwdPath { PATH_IGEMM = 0, PATH_NARROW = 1, PATH_WAVE = 2, PATH_DENSE = 3, P
 // kept behind the packed weights).  1.3x faster than the VALU kernel of conv_narrow.hip on the 128x128 maps (230 vs 305 us at
 // batch 32; the N = 32 tile runs at 74 TFLOP/s executed -- a 256x32 tile with 64x32 wave tiles was tried and was slower).
 static bool rowconv_applicable(const srgan_conv_desc* d) {
-  static const bool off = std::getenv("SRGAN_NO_ROWCONV") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_ROWCONV");
   return !off && d->O == 3 && d->kh == 7 && d->kw == 7 && d->stride == 1 && d->pad_mode == SRGAN_PAD_ZERO && (d->I % BK) == 0 &&
          d->Wo >= 64 && d->Ho >= 8 && (long long)d->N * d->Ho * d->Wi * 21 < (1LL << 30);
 }
@@ -1567,7 +1561,7 @@ struct DgradGeom { IgemmParams p; int phases; bool reflect, wino, narrow, rgbin,
 // stride 2 into dx.  Returns false when the layer does not qualify.
 static bool narrow_s2_phase(const srgan_conv_desc* d, int pp, int qq, srgan_conv_desc* f, long long* w_off, int* pad_x,
                             size_t* packed_off) {
-  static const bool off = std::getenv("SRGAN_NO_NARROW_S2") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_NARROW_S2");
   if (off || d->stride != 2 || d->pad_mode != SRGAN_PAD_ZERO || d->I > 4 || d->O % 16 != 0 || d->kh != d->kw || d->kh < 2 ||
       d->kh > 8 || d->Hi < 2 || d->Wi < 2)
     return false;

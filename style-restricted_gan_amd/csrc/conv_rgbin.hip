@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512) void rgb_wgrad_kernel(RgbWgradParams p) {
 
 // kind 0: RGB input layer (I == 3, O == 64); kind 1: RGB output layer (I == 64, O == 3)
 int rgb_wgrad_kind(const srgan_conv_desc* d) {
-  static const bool off = std::getenv("SRGAN_NO_RGBIN") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_RGBIN");
   // (also in the bf16 compute mode: the RGB layers are documented to stay fp32 there, and these exact-fp32 MFMA kernels are 2-3x
   // faster than the scalar-gather GEMM / VALU kernels they would otherwise fall back to: 3.1 + 1.7 ms -> 1.4 + 1.0 ms per step)
   if (off) return -1;
@@ -296,7 +296,7 @@ int rgb_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, flo
 }
 
 bool rgbin_applicable(const srgan_conv_desc* d) {
-  static const bool off = std::getenv("SRGAN_NO_RGBIN") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_RGBIN");
   if (off) return false;
   return d->I == 3 && d->kh == 7 && d->kw == 7 && d->stride == 1 && d->pad_mode == SRGAN_PAD_ZERO && d->O % 64 == 0 &&
          d->Wo >= 32 && d->Ho >= 16 && (long long)d->N * d->Ho * d->Wo * d->O < (1LL << 31);

@@ -257,7 +257,7 @@ __global__ void rgbout_pack_kernel(const float* w, float* dst, long long sO, lon
 }  // namespace
 
 bool rgbout_applicable(const srgan_conv_desc* d) {
-  static const bool off = std::getenv("SRGAN_NO_RGBOUT") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_RGBOUT");
   if (off) return false;
   return d->O >= 1 && d->O <= 4 && d->kh == RO_K && d->kw == RO_K && d->stride == 1 && d->pad == RO_PAD && d->pad_mode == SRGAN_PAD_ZERO &&
          d->I % 16 == 0 && d->I >= 16 && d->I <= 4 * RO_MAXQ && d->Wo >= 64 && d->Ho >= 32 && d->Hi == d->Ho &&

@@ -785,7 +785,7 @@ static double conv_flops_of(const srgan_conv_desc* d) {
 // correlation onto the reflect-padded image (pad' = 2, output Hi+2p), folded by the caller.
 // variant 2: kind 0: the 4x4 stride-2 conv (MODE 1); kind 1: its input gradient / the transposed conv (MODE 2).
 static bool wino_disabled() {
-  static const bool off = std::getenv("SRGAN_NO_WINOGRAD") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_WINOGRAD");
   return off;
 }
 // Dispatch thresholds scale with this factor (default 1; 0 = take every geometrically valid layer).  Read on every call so
@@ -795,11 +795,11 @@ static double wino_threshold_scale() {
   return e ? std::atof(e) : 1.0;
 }
 static bool wino43_disabled() {
-  static const bool off = std::getenv("SRGAN_NO_WINOGRAD43") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_WINOGRAD43");
   return off;
 }
 static bool wino_s2_disabled() {
-  static const bool off = std::getenv("SRGAN_NO_WINOGRAD_S2") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_WINOGRAD_S2");
   return off;
 }
 
@@ -877,7 +877,7 @@ size_t wino_scratch_bytes(const srgan_conv_desc* d, int kind) {
 // Weight gradient of an F(4x4,3x3) layer from the V image its forward wrote (conv_wino43.hip): applicable when the forward runs
 // that path, Cin % 64 == 0, Cout % 32 == 0; split-K over 8-tile chunks so that ~256 workgroups run.
 bool wino43_wgrad_geometry(const srgan_conv_desc* d, Wino43WgradGeom* g) {
-  static const bool off = std::getenv("SRGAN_NO_WINOGRAD43_WGRAD") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_WINOGRAD43_WGRAD");
   if (off || wino_variant(d, 0) != 3 || d->I % 64 != 0 || d->O % 32 != 0) return false;
   const long long T = (long long)d->N * (d->Ho / 4) * (d->Wo / 4);
   const long long ntc = ceil_div(T, 64) * 8;
@@ -995,7 +995,7 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
 // ---- weight gradient host side ----
 // returns 0 (not applicable), 1 (3x3 stride-1) or 2 (4x4 stride-2)
 static int wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
-  static const bool off = std::getenv("SRGAN_NO_WINOGRAD_WGRAD") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_WINOGRAD_WGRAD");
   if (wino_disabled() || off || compute_bf16()) return 0;
   int variant = 0;
   if (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1) variant = 1;
@@ -1026,7 +1026,7 @@ static int wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
   // few tile positions (the discriminator's 32x32 / 16x16 maps at batch 64): the groups alone do not fill the device, so the
   // K range (groups x images) is cut along the batch as well: the (group splits, batch splits) pair with the most
   // workgroups within one device round wins, ties go to the longer K range per workgroup, then to the longer batch range
-  static const int min_chunks_b = std::getenv("SRGAN_WGRAD_BSPLIT_MIN_CHUNKS") ? std::atoi(std::getenv("SRGAN_WGRAD_BSPLIT_MIN_CHUNKS")) : 24;
+  static const int min_chunks_b = SRGAN_AB_INT("SRGAN_WGRAD_BSPLIT_MIN_CHUNKS", 24);
   if (variant == 2 && min_chunks_b > 0 && blocks < 192) {
     const int S = std::max(1, 256 / tiles);
     long long best_blocks = blocks, best_chunks = chunks;
@@ -1051,7 +1051,7 @@ static int wino_wgrad_geometry(const srgan_conv_desc* d, WinoWgradParams* p) {
   if (variant == 1) {
     if (blocks < 16 * ts || chunks < 4 * ts) return 0;      // too few workgroups / too short a K range: implicit GEMM instead
   } else {
-    static const int min_blocks = std::getenv("SRGAN_WGRAD_S2_MIN_BLOCKS") ? std::atoi(std::getenv("SRGAN_WGRAD_S2_MIN_BLOCKS")) : 192;
+    static const int min_blocks = SRGAN_AB_INT("SRGAN_WGRAD_S2_MIN_BLOCKS", 192);
     if (blocks < min_blocks * ts || chunks < (p->bsplits > 1 ? min_chunks_b : 48) * ts) return 0;    // measured: the discriminator's smallest maps stay faster on the implicit GEMM
   }
   return variant;
@@ -1078,8 +1078,7 @@ int wino_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, fl
   const int variant = wino_wgrad_geometry(d, &p);
   SRGAN_REQUIRE(variant != 0, "winograd wgrad: layer not applicable");
   p.x = x; p.dy = dy; p.slab = slab;
-  static const bool plain = std::getenv("SRGAN_WGRAD_PLAIN_ORDER") != nullptr;       // A/B switch: the round-2 order
-  p.xcd_splits = (!plain && p.splits % 8 == 0) ? 1 : 0;
+  p.xcd_splits = (p.splits % 8 == 0) ? 1 : 0;
   ProfToken tok = prof_begin(variant == 1 ? 15 : 17, conv_flops_of(d), st);   // algorithmic FLOPs, as above
   const dim3 grid((unsigned)(p.o_tiles * p.i_tiles * p.splits));
   if (variant == 1) hipLaunchKernelGGL(wino_wgrad_kernel<0>, grid, dim3(512), 0, st, p);

@@ -800,7 +800,7 @@ size_t wino43_scratch_floats(long long T, int C) { return (size_t)ceil_div(T, (l
 // `flops`: the layer's ALGORITHMIC FLOPs, booked on the multiply kernel; the input transform is HBM-bound and has its own slot
 int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops, hipStream_t st, bool v_ready) {
   // SRGAN_W43_ONLY=1 / 2 (timing experiments only): launch just the input transform / just the multiply kernel
-  static const int only = std::getenv("SRGAN_W43_ONLY") ? std::atoi(std::getenv("SRGAN_W43_ONLY")) : 0;
+  static const int only = SRGAN_AB_INT("SRGAN_W43_ONLY", 0);
   if (only != 2 && !v_ready) {      // v_ready: the caller's V image already holds B^T d B (in_fwd_slab_v_kernel wrote it)
     ProfToken tok = prof_begin(19, 0.0, st);
     hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)(p.m_tiles * (p.C / 32))), dim3(512), 0, st, p, vimg);
@@ -829,8 +829,7 @@ int wino43_wgrad_launch(const Wino43WgradGeom& g, const float* vimg, const float
   Wino43WgradParams p{};
   p.vimg = vimg; p.zimg = zimg; p.slab = slab; p.C = g.C; p.O = g.O; p.cchunks = g.C / 8; p.ntc = g.ntc;
   p.chunks_per_split = g.chunks_per_split; p.splits = g.splits; p.c_blocks = g.C / 64; p.o_blocks = g.O / 32;
-  static const bool major = std::getenv("SRGAN_W43_WGRAD_SPLIT_MAJOR") != nullptr;      // A/B switch: the round-2 order
-  p.split_minor = major ? 0 : 1;
+  p.split_minor = 1;
   ProfToken tok = prof_begin(22, flops, st);
   hipLaunchKernelGGL(wino43_wgrad_kernel, dim3((unsigned)(p.o_blocks * p.c_blocks * p.splits)), dim3(512), 0, st, p);
   prof_end(tok, st);

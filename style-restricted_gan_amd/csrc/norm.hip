@@ -710,14 +710,11 @@ int apply_grid(int hwc4, int N) {
   return (int)std::max<long long>(1, std::min(per_image, want));
 }
 
-int slab_remap() {
-  static const int on = std::getenv("SRGAN_NORM_PLAIN_GRID") == nullptr;
-  return on;
-}
+int slab_remap() { return 1; }
 
 // single-pass kernels: whole 32-channel groups, a slab of <= 1024 pixels, enough workgroups to cover the device
 bool slab_fast(int N, int HW, int C) {
-  static const bool off = std::getenv("SRGAN_NO_NORM_SLAB") != nullptr;
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_NORM_SLAB");
   return !off && (C % 32) == 0 && HW <= 1024 && (long long)N * (C / 32) >= 128;
 }
 
@@ -763,14 +760,12 @@ extern "C" int srgan_instnorm_fwd(const float* x, const float* scale, const floa
   }
   float2* part = reinterpret_cast<float2*>(ws);
   dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
-  static const bool exp_skip = std::getenv("SRGAN_EXP_SKIP_STATS") != nullptr;      // timing experiment (wrong results): no statistics pass
-  if (exp_skip) {      // one row per split: finite statistics from a negligible read
-    if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4, g, dim3(256), 0, st, x, part, HW, C, S, 1);
-    else hipLaunchKernelGGL(in_stats_partial, g, dim3(256), 0, st, x, part, HW, C, S, 1);
-  } else if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4, g, dim3(256), 0, st, x, part, HW, C, S, rps);
+  if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4, g, dim3(256), 0, st, x, part, HW, C, S, rps);
   else hipLaunchKernelGGL(in_stats_partial, g, dim3(256), 0, st, x, part, HW, C, S, rps);
   const long long total = (long long)N * HW * C;
-  static const bool fuse_final = std::getenv("SRGAN_NORM_SEPARATE_FINAL") == nullptr;
+  // the fused finish re-reads the shift sample x[n][pixel 0][c] in EVERY workgroup of the apply pass while workgroup 0 may
+  // already be storing y there: an in-place call (y == x, or the skip tensor == y) takes the separate finalize launch instead
+  const bool fuse_final = (const float*)y != x && (const float*)y != res;
   if (pow2_fast(C, HW) && fuse_final) {
     const int hwc4 = HW * C / 4;
     dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
@@ -821,8 +816,7 @@ extern "C" int srgan_instnorm_bwd(const float* x, const float* dy, const float* 
   else hipLaunchKernelGGL(in_bwd_partial, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
   const long long total = (long long)N * HW * C;
   const float inv_hw = 1.f / (float)HW;
-  static const bool fuse_final = std::getenv("SRGAN_NORM_SEPARATE_FINAL") == nullptr;
-  if (pow2_fast(C, HW) && fuse_final) {
+  if (pow2_fast(C, HW)) {      // (the backward's fused finish reads the partial sums only: in-place dx is an elementwise update)
     const int hwc4 = HW * C / 4;
     dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
     hipLaunchKernelGGL(in_bwd_apply_pow2, g2, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, hwc4, C, inv_hw, act,
@@ -830,12 +824,7 @@ extern "C" int srgan_instnorm_bwd(const float* x, const float* dy, const float* 
     return check_launch("instnorm_bwd");
   }
   hipLaunchKernelGGL(in_bwd_final, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float2*)part, dshift, dscale, N * C, C, S);
-  if (pow2_fast(C, HW)) {
-    const int hwc4 = HW * C / 4;
-    dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
-    hipLaunchKernelGGL(in_bwd_apply_pow2, g2, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, hwc4, C, inv_hw, act,
-                       slope, (const float2*)nullptr, 0);
-  } else if ((C & 3) == 0) {
+  if ((C & 3) == 0) {
     unsigned blocks = (unsigned)std::min<long long>(ceil_div(total / 4, 256), 8192);
     hipLaunchKernelGGL(in_bwd_apply<true>, dim3(blocks), dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, total, HW * C, C, inv_hw, act, slope);
   } else {

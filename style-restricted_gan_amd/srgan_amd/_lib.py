@@ -8,6 +8,23 @@ from ctypes import c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SRGAN_HIP_LIB") or os.path.join(_HERE, "libsrgan_hip.so")   # override: A/B kernel experiments
+# An experiment build (csrc/Makefile `make exp`, scratch/libsrgan_exp.so) is loaded: only then are the A/B switches of the
+# measurement scripts honoured, here (ab()) and in the library (SRGAN_AB_SET in csrc/common.h).  bench.py reports it.
+EXPERIMENTS = bool(os.environ.get("SRGAN_HIP_LIB"))
+
+
+def ab(name):
+    """An A/B switch of scratch/: the environment variable `name`, read only next to an experiment build of the library."""
+    return EXPERIMENTS and bool(os.environ.get(name))
+
+
+def active_switches():
+    """What makes this process differ from the product configuration (bench.py prints it and refuses to call the line a result)."""
+    out = {}
+    if EXPERIMENTS:
+        out["SRGAN_HIP_LIB"] = os.environ["SRGAN_HIP_LIB"]
+        out.update({k: v for k, v in os.environ.items() if k.startswith("SRGAN_") and k != "SRGAN_HIP_LIB"})
+    return out
 
 
 class ConvDesc(ctypes.Structure):

@@ -62,6 +62,8 @@ def init_from_env(backend=None):
         global _control
         _control = None
         control_group()
+        _gather_into_tensor.clear()
+        _probe_gather_into_tensor(device)
     return rk, ws, device
 
 
@@ -109,13 +111,34 @@ def set_recorder(rec):
     _recorder = rec
 
 
+_gather_into_tensor = {}      # backend name -> bool: does it implement all_gather_into_tensor (probed once, collectively)
+
+
+def _probe_gather_into_tensor(device):
+    """Feature-detect ``all_gather_into_tensor`` ONCE per backend, at a point every rank reaches together
+    (``init_from_env`` right after the group is made, else the first gather of a step).  Whether the call exists is a property
+    of the backend build, identical on every rank, so all ranks take the same branch; afterwards the chosen call's errors
+    propagate instead of being answered with a DIFFERENT collective on one rank."""
+    be = dist.get_backend()
+    if be not in _gather_into_tensor:
+        src = torch.zeros(1, device=device)
+        out = torch.zeros(dist.get_world_size(), device=device)
+        try:
+            dist.all_gather_into_tensor(out, src)
+            _gather_into_tensor[be] = True
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather(list(out.chunk(dist.get_world_size(), 0)), src)      # keep the ranks' collective sequences equal
+            _gather_into_tensor[be] = False
+    return _gather_into_tensor[be]
+
+
 def _all_gather_into(out, src):
     """Rank-ordered rows of every rank's ``src`` into ONE preallocated tensor (``all_gather_into_tensor``: RCCL writes the
     destination directly; a list of per-rank views may be staged through an internal flat buffer and copied out).  Backends
-    without the call get the list form on views of ``out`` -- same result."""
-    try:
+    without the call get the list form on views of ``out`` -- same result.  Errors of the chosen call propagate."""
+    if _probe_gather_into_tensor(src.device):
         dist.all_gather_into_tensor(out, src)
-    except (RuntimeError, NotImplementedError):
+    else:
         dist.all_gather(list(out.chunk(dist.get_world_size(), 0)), src)
 
 
@@ -145,17 +168,39 @@ def all_gather_rows(x):
     return _AllGatherRows.apply(x) if is_distributed() else x
 
 
-BUCKET_BYTES = 16 << 20   # per all-reduce message: several buckets per network, so the first ones run under the backward
+BUCKET_BYTES = 16 << 20   # per all-reduce message (fp32 bytes of its gradients): several buckets per network, so the first ones run under the backward
+
+_wire_dtype = None        # None: follow the compute mode (bf16 convolutions -> bf16 gradient messages)
+
+
+def set_bucket_dtype(name):
+    """What travels in a gradient all-reduce: "fp32", "bf16" or None = follow ``ops.get_compute_dtype()`` (default).  In the
+    bf16 mode (BASELINE configs[2]-[4]) the weight gradients are sums of bf16 products, so averaging them in bf16 on the wire
+    costs nothing the mode has not already spent and halves the ~180 MB a step moves over xGMI; the averaged
+    message is widened into the bucket's fp32 buffer on the communication stream and THAT is what ``p.grad`` is bound to --
+    Adam and the master weights never see a bf16 tensor."""
+    global _wire_dtype
+    if name not in (None, "fp32", "bf16"):
+        raise ValueError(f"set_bucket_dtype: {name!r}")
+    _wire_dtype = name
+
+
+def bucket_dtype():
+    if _wire_dtype is not None:
+        return _wire_dtype
+    from . import ops
+    return "bf16" if ops.get_compute_dtype() == "bf16" else "fp32"
 
 
 class _Bucket:
     """One all-reduce message: a PERSISTENT flat fp32 buffer and, per parameter, the view of it that becomes ``p.grad``."""
-    __slots__ = ("params", "flat", "views", "ready", "done", "launched", "count", "expected", "hit")
+    __slots__ = ("params", "flat", "views", "wire", "wire_views", "ready", "done", "launched", "count", "expected", "hit")
 
     def __init__(self, params):
         self.params = params
         self.flat = None               # allocated at first use (parameters may still move between devices before that)
         self.views = None
+        self.wire = self.wire_views = None   # bf16 message (bucket_dtype() == "bf16"); None: the fp32 buffer itself travels
         self.ready = self.done = None  # HIP events: compute -> comm (bucket flattened), comm -> compute (all-reduce finished)
         self.launched = False
         self.count = 0
@@ -164,16 +209,36 @@ class _Bucket:
 
     def materialise(self):
         p0 = self.params[0]
-        if self.flat is not None and self.flat.device == p0.device:
-            return
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=p0.device)
-        self.views, off = [], 0
-        for p in self.params:
-            n = p.numel()
-            self.views.append(self.flat[off:off + n].view(p.shape))      # dense, contiguous: what the fused Adam wants
-            off += n
-        if p0.is_cuda:
-            self.ready, self.done = torch.cuda.Event(), torch.cuda.Event()
+        if self.flat is None or self.flat.device != p0.device:
+            self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=p0.device)
+            self.views, off = [], 0
+            for p in self.params:
+                n = p.numel()
+                self.views.append(self.flat[off:off + n].view(p.shape))      # dense, contiguous: what the fused Adam wants
+                off += n
+            self.wire = self.wire_views = None
+            if p0.is_cuda:
+                self.ready, self.done = torch.cuda.Event(), torch.cuda.Event()
+        want16 = bucket_dtype() == "bf16"
+        if want16 and self.wire is None:
+            self.wire = torch.zeros(self.flat.numel(), dtype=torch.bfloat16, device=self.flat.device)
+            self.wire_views = [self.wire[v.storage_offset():v.storage_offset() + v.numel()].view(v.shape) for v in self.views]
+        elif not want16 and self.wire is not None:
+            self.wire = self.wire_views = None
+
+    def message(self):
+        """The tensor the all-reduce runs on."""
+        return self.wire if self.wire is not None else self.flat
+
+    def reduce_(self, avg):
+        """In-place average of the message across the ranks, then (bf16 message) widened into the fp32 buffer.  Runs on whatever
+        stream is current: the communication stream."""
+        msg = self.message()
+        dist.all_reduce(msg, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
+        if self.wire is not None:
+            self.flat.copy_(msg)
+        if not avg:
+            self.flat.mul_(1.0 / dist.get_world_size())
 
 
 class GradReducer:
@@ -264,13 +329,13 @@ class GradReducer:
             from . import ops
             ops.wait_compute_streams(bk.flat.device)
         srcs, dsts, holes = [], [], []
-        for p, v in zip(bk.params, bk.views):
+        for p, v in zip(bk.params, bk.wire_views if bk.wire is not None else bk.views):
             g = p.grad
             if g is None:
                 holes.append(v)
             elif g.data_ptr() != v.data_ptr():        # already the bucket's own slice (no zero_grad since the last pass)
                 srcs.append(g)
-                dsts.append(v)
+                dsts.append(v)                        # (a bf16 message: the multi-tensor copy rounds to nearest even)
         with torch.no_grad():
             if dsts:
                 torch._foreach_copy_(dsts, srcs)       # one multi-tensor launch lays the bucket out
@@ -286,13 +351,10 @@ class GradReducer:
             bk.ready.record(torch.cuda.current_stream(bk.flat.device))
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(bk.ready)
-                dist.all_reduce(bk.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
-                if not avg:
-                    bk.flat.mul_(1.0 / dist.get_world_size())
+                bk.reduce_(avg)
                 bk.done.record(self._comm_stream)
         else:
-            dist.all_reduce(bk.flat, op=dist.ReduceOp.SUM)
-            bk.flat.mul_(1.0 / dist.get_world_size())
+            bk.reduce_(False)
         bk.launched = True
         self._work.append(bk)
 
@@ -360,12 +422,10 @@ class _Comm:
 def _all_reduce_async(items):
     """In-place average of flat buckets, issued on the communication stream behind everything the compute stream has been
     given so far; returns at once -- the graph segments launched next run UNDER the collectives (``_wait_done`` joins)."""
-    ws = dist.get_world_size()
     bk0 = items[0][0]
     if not bk0.flat.is_cuda:
         for bk, avg in items:
-            dist.all_reduce(bk.flat, op=dist.ReduceOp.SUM)
-            bk.flat.mul_(1.0 / ws)
+            bk.reduce_(False)
         return
     dev = bk0.flat.device
     comm = comm_stream(dev)
@@ -373,9 +433,7 @@ def _all_reduce_async(items):
     with torch.cuda.stream(comm):
         comm.wait_event(bk0.ready)
         for bk, avg in items:
-            dist.all_reduce(bk.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
-            if not avg:
-                bk.flat.mul_(1.0 / ws)
+            bk.reduce_(avg)
             bk.done.record(comm)
 
 

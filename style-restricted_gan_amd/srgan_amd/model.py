@@ -18,7 +18,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, PAD_REFLECT, PAD_ZERO
 
 __all__ = ["CBINorm2d", "get_norm_layer", "SingleResidualBlock", "SingleGenerator",
@@ -102,7 +102,7 @@ class _AvgPool3s2(nn.Module):
 # its forward's stream and orders the streams with events) -- inside a captured train step the two scales become parallel
 # branches of the hipGraph.  Same kernels, same operands, same accumulation order of the two input gradients (the engine's,
 # by topological order): identical results.  ``SRGAN_NO_PARALLEL_SCALES=1`` keeps everything on one stream.
-_PARALLEL_SCALES = not os.environ.get("SRGAN_NO_PARALLEL_SCALES")
+_PARALLEL_SCALES = not _lib.ab("SRGAN_NO_PARALLEL_SCALES")
 _side_streams = {}
 
 
@@ -285,7 +285,7 @@ class SingleGenerator(nn.Module):
         self.up_norms = nn.ModuleList(norms)
 
     def forward(self, x, c):
-        if c.is_cuda and not os.environ.get("SRGAN_NO_CBIN_MULTI"):
+        if c.is_cuda and not _lib.ab("SRGAN_NO_CBIN_MULTI"):
             c = PrecomputedCon(c, list(self.down_cnorms) + [n for blk in self.resBlocks for n in (blk.cn1, blk.cn2)])
         for i in range(self.num_cls + 1):
             x = self.down_cnorms[i](self.down_convs[i](x), c, ACT_RELU)
@@ -309,7 +309,7 @@ def _d_trunk_layers(nch_in, nch, reduce, num_cls):
     return layers, dim_in
 
 
-_CHAIN_ACT_BWD = not os.environ.get("SRGAN_NO_CHAIN_ACT_BWD")
+_CHAIN_ACT_BWD = not _lib.ab("SRGAN_NO_CHAIN_ACT_BWD")
 
 
 def _run_trunk(seq, x):
@@ -482,7 +482,7 @@ def host_to_device(t, device):
     has drained (the GPU then idles while the next launches are being queued); a copy out of PyTorch's cached pinned
     allocator is asynchronous and the allocator keeps the staging block alive until the copy has run."""
     device = torch.device(device)
-    if device.type != "cuda" or t.device.type != "cpu" or os.environ.get("SRGAN_SYNC_H2D"):
+    if device.type != "cuda" or t.device.type != "cpu" or _lib.ab("SRGAN_SYNC_H2D"):
         return t.to(device)
     return t.pin_memory().to(device, non_blocking=True)
 

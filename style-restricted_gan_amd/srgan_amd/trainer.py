@@ -635,9 +635,19 @@ class _StepGraph:
         MIN all-reduce of the local answer on the host-side control group): a rank replaying index-ordered flat buckets beside
         a rank running the hook-ordered eager step -- or recording, with its extra agreement all-reduce -- would issue different
         collectives.  If any rank has to record, every rank records again; if any rank runs eagerly, all do."""
-        mode = self._local_mode(source_image, label)
+        failure = None
+        try:
+            mode = self._local_mode(source_image, label)
+        except NotImplementedError as e:
+            # (ADVICE r3) a rank that can no longer take graph mode must still join the agreement below -- raising before the
+            # collective would leave the other ranks blocked in it: vote "eager", let every rank leave the step together, then raise
+            failure, mode = e, 0
+            if not dp.is_distributed():
+                raise
         if dp.is_distributed():
             agreed = dp.all_min(mode)
+            if failure is not None:
+                raise failure
             if agreed < 2 and self.graph is not None:
                 if agreed == 1:
                     key = self.key

@@ -43,3 +43,20 @@ def test_product_refuses_cpu_tensors(built_lib):
     from srgan_amd import ops
     with pytest.raises(built_lib.SrganHipError, match="no CPU fallback"):
         ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))
+
+
+def test_no_experiment_switch_ships_in_the_product_library(built_lib):
+    """wrong-result timing switches (SRGAN_EXP_*), the compile-time ablations (WINO_EXP / RGBOUT_EXP /
+    W43_DIAG) and the A/B switches of scratch/ exist only in `make exp` builds (scratch/libsrgan_exp.so).  The product library
+    reads three environment variables, all test / debug hooks that change no result: listed here and in DESIGN.md."""
+    blob = open(built_lib.LIB_PATH, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"SRGAN_[A-Z0-9_]{3,}", blob))
+    assert not [n for n in names if n.startswith("SRGAN_EXP")], names
+    assert names <= {"SRGAN_WINOGRAD_THRESHOLD_SCALE", "SRGAN_PACK_ITEM_PATH", "SRGAN_DEBUG_REDUCE"}, names
+    assert not built_lib.EXPERIMENTS and not built_lib.ab("PATH")        # python-side A/B switches are off next to the product library
+    # an ablation flag without -DSRGAN_EXPERIMENTS does not compile (csrc/common.h)
+    import subprocess
+    src = os.path.join(ROOT, "style-restricted_gan_amd", "csrc")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "--offload-arch=gfx950", "-DWINO_EXP=5", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + src, "-E", "-x", "hip", os.path.join(src, "common.h"), "-o", os.devnull], capture_output=True, text=True)
+    assert r.returncode != 0 and "experiment builds" in r.stderr

@@ -173,6 +173,82 @@ def test_dp_world_size_4_gloo():
         assert err <= 1e-5 * scale, (rank, err, scale)
 
 
+def _worker8(rank, world, port, out):
+    """world_size 8: bucket order and sizes incl. the uneven last bucket, the averaged values of every
+    bucket, all_gather_rows in rank order -- and the bf16 message of the bf16 mode (set_bucket_dtype): the all-reduce runs on
+    a bf16 buffer, p.grad is bound to the widened fp32 buffer."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from srgan_amd import dp
+    dp.init_from_env("gloo")
+    assert dp.world_size() == 8
+    dp.BUCKET_BYTES = 256                                  # 64 floats per message
+    sizes = [40, 24, 64, 10, 30, 7]                        # reversed: [7, 30, 10] | [64] | [24, 40] -> 47, 64, 64 floats
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+    red = dp.GradReducer(params)
+    layout = [[p.numel() for p in bk.params] for bk in red._buckets_cache]
+    gen = torch.Generator().manual_seed(7)
+    base = [torch.randn(n, generator=gen) for n in sizes]  # the same on every rank
+    for p, b in zip(params, base):
+        p.grad = b * (rank + 1)
+    red.reduce()
+    err32 = max(float((p.grad - b * 4.5).abs().max()) for p, b in zip(params, base))      # mean of 1..8 = 4.5
+    bound32 = [p.grad.data_ptr() == red._buckets_cache[red._where[id(p)][0]].views[red._where[id(p)][1]].data_ptr() for p in params]
+    # rows in rank order
+    x = (torch.arange(4.0).view(2, 2) + 100 * rank).requires_grad_(True)
+    g = dp.all_gather_rows(x)
+    rows_ok = all(torch.equal(g[2 * r:2 * r + 2], torch.arange(4.0).view(2, 2) + 100 * r) for r in range(world))
+    (g * torch.arange(32.0).view(16, 2)).sum().backward()
+    rows_ok = rows_ok and torch.equal(x.grad, torch.arange(32.0).view(16, 2)[2 * rank:2 * rank + 2])
+    # bf16 messages
+    dp.set_bucket_dtype("bf16")
+    try:
+        for p, b in zip(params, base):
+            p.grad = b * (rank + 1)
+        red.reduce()
+        wire = [bk.wire.dtype for bk in red._buckets_cache]
+        grads_fp32 = all(p.grad.dtype == torch.float32 for p in params)
+        # every rank's contribution is rounded to bf16 once and the sum is kept in bf16 by the transport: 8 roundings of <= 2^-9
+        err16 = max(float(((p.grad - b * 4.5).abs() / (b.abs() * 4.5 + 1e-6)).max()) for p, b in zip(params, base))
+        same16 = [p.grad.clone() for p in params]
+    finally:
+        dp.set_bucket_dtype(None)
+    # back to fp32 messages: the bf16 buffers are dropped and the exact average returns
+    for p, b in zip(params, base):
+        p.grad = b * (rank + 1)
+    red.reduce()
+    err_back = max(float((p.grad - b * 4.5).abs().max()) for p, b in zip(params, base))
+    no_wire = all(bk.wire is None for bk in red._buckets_cache)
+    # all ranks hold identical averaged gradients in the bf16 mode too (what keeps the replicas identical)
+    flat16 = torch.cat([t.flatten() for t in same16])
+    gathered = [torch.zeros_like(flat16) for _ in range(world)]
+    dist.all_gather(gathered, flat16)
+    identical = all(torch.equal(gathered[0], t) for t in gathered)
+    out.put((rank, layout, err32, all(bound32), rows_ok, [str(w) for w in wire], grads_fp32, err16, err_back, no_wire, identical))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_world_size_8_gloo_buckets_gather_and_bf16_messages():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, out)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(8))
+    for rank, layout, err32, bound32, rows_ok, wire, grads_fp32, err16, err_back, no_wire, identical in res:
+        assert layout == [[7, 30, 10], [64], [24, 40]], layout          # reverse parameter order, 256-byte messages, uneven first
+        assert err32 <= 1e-5 and bound32 and rows_ok, (rank, err32, bound32, rows_ok)
+        assert wire == ["torch.bfloat16"] * 3 and grads_fp32
+        assert 0 < err16 <= 3e-2, (rank, err16)                         # bf16 on the wire: visible, and bounded
+        assert err_back <= 1e-5 and no_wire and identical, (rank, err_back, no_wire, identical)
+
+
 def test_single_process_is_a_no_op():
     from srgan_amd import dp
     assert not dp.is_distributed() and dp.world_size() == 1 and dp.rank() == 0

@@ -364,8 +364,7 @@ def test_residual_block_bf16_storage(ops, n, c):
     try:
         for mode in ("fused", "chain"):
             t = [v.clone().cuda().requires_grad_(True) for v in (x, s1, h1, s2, h2, w1, w2)]
-            if mode == "chain":
-                os.environ["SRGAN_NO_RESBLOCK_BF16"] = "1"
+            ops.RESBLOCK_BF16_STORAGE = mode != "chain"
             try:
                 with ops.pack_cache():
                     if mode == "fused":
@@ -379,7 +378,7 @@ def test_residual_block_bf16_storage(ops, n, c):
                         y = ops.instance_norm_act(y2, t[3], t[4], skip, ops.ACT_NONE)
                     y.backward(gy.cuda())
             finally:
-                os.environ.pop("SRGAN_NO_RESBLOCK_BF16", None)
+                ops.RESBLOCK_BF16_STORAGE = True
             res[mode] = [y.detach()] + [v.grad for v in t]
     finally:
         ops.set_compute_dtype("fp32")
