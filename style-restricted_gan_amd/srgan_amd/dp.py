@@ -64,6 +64,8 @@ def init_from_env(backend=None):
         control_group()
         _gather_into_tensor.clear()
         _probe_gather_into_tensor(device)
+    if os.environ.get("SRGAN_DP_BUCKET_DTYPE"):          # "fp32" / "bf16": see set_bucket_dtype (default: follow the compute mode)
+        set_bucket_dtype(os.environ["SRGAN_DP_BUCKET_DTYPE"])
     return rk, ws, device
 
 

@@ -209,22 +209,34 @@ def test_rccl_path_one_rank_equals_plain_step(graph):
         assert d <= 1e-6, (key, d)
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_config2_recipe_two_ranks_equal_one_process(graph):
+@pytest.mark.parametrize("graph,messages", [(False, "fp32"), (True, "fp32"), (True, "bf16")])
+def test_config2_recipe_two_ranks_equal_one_process(graph, messages):
     """BASELINE configs[2] in its stated form at tier-T widths: the pretrained-E recipe (encoder trunk outside optE) AND the bf16
     convolution mode AND two data-parallel ranks, against the single-process step of the same recipe.  graph=True: the ranks
-    record and replay graph segments (parameters that receive no gradient must stay without one in the recorded step too)."""
+    record and replay graph segments (parameters that receive no gradient must stay without one in the recorded step too).
+    messages: what travels in the gradient all-reduces -- "fp32" (SRGAN_DP_BUCKET_DTYPE=fp32) keeps the arithmetic of the
+    single-process step to 2e-5; "bf16" is the mode's default (dp.set_bucket_dtype): every rank's gradient is rounded to 8
+    mantissa bits before the sum, i.e. an ABSOLUTE error of 2^-9 of the per-rank gradient on the average -- where the ranks'
+    contributions cancel that exceeds the average itself, and the (eps = 1e-2, nearly linear) Adam step of such an element
+    differs by a fraction of lr.  Bounded per tensor: nothing beyond one lr per step, the bulk far below."""
     from srgan_amd import ops
     try:
         ref_losses, ref_state, ref_terms = _run(0, 1, recipe="config2")
     finally:
         ops.set_compute_dtype("fp32")
-    res = _spawn(2, lambda r, port, q: (r, 2, port, q, 0.0, "gloo", False, graph, "config2"), timeout=240)
+    os.environ["SRGAN_DP_BUCKET_DTYPE"] = messages
+    try:
+        res = _spawn(2, lambda r, port, q: (r, 2, port, q, 0.0, "gloo", False, graph, "config2"), timeout=240)
+    finally:
+        os.environ.pop("SRGAN_DP_BUCKET_DTYPE", None)
     dp_losses = (np.array(res[0][1]) + np.array(res[1][1])) / 2
     np.testing.assert_allclose(dp_losses, np.array(ref_losses), rtol=1e-3)
     for key, v in res[0][2].items():
-        d = float(np.abs(v - ref_state[key]).max())
-        assert d <= 2e-5, (key, d)
+        d = np.abs(v - ref_state[key])
+        if messages == "fp32":
+            assert float(d.max()) <= 2e-5, (key, float(d.max()))
+        else:
+            assert float(d.max()) <= STEPS * 1.1e-4 and float(np.median(d)) <= 1e-5, (key, float(d.max()), float(np.median(d)))
     trunk = [k for k in ref_state if k.startswith("E.layers")]
     assert trunk and all(np.array_equal(res[0][2][k], ref_state[k]) for k in trunk)      # the frozen-for-optE trunk did not move
 
@@ -237,7 +249,11 @@ def test_config3_recipe_four_ranks_equal_one_process():
         ref_losses, ref_state, ref_terms = _run(0, 1, recipe="config3")
     finally:
         ops.set_compute_dtype("fp32")
-    res = _spawn(4, lambda r, port, q: (r, 4, port, q, 0.0, "gloo", False, False, "config3"), timeout=300)
+    os.environ["SRGAN_DP_BUCKET_DTYPE"] = "fp32"      # the ARITHMETIC of four ranks (bf16 messages: the config2 test above)
+    try:
+        res = _spawn(4, lambda r, port, q: (r, 4, port, q, 0.0, "gloo", False, False, "config3"), timeout=300)
+    finally:
+        os.environ.pop("SRGAN_DP_BUCKET_DTYPE", None)
     dp_losses = sum(np.array(r[1]) for r in res) / 4
     np.testing.assert_allclose(dp_losses, np.array(ref_losses), rtol=1e-3)
     for key in ("errE_bKL", "errE_corr", "errE_hist"):          # global-batch statistics: identical on every rank
