@@ -4,6 +4,8 @@ _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.inser
 import torch
 from srgan_amd import ops, _lib
 lib = _lib.load()
+if os.environ.get("DT") == "bf16":
+    ops.set_compute_dtype("bf16")
 B = int(os.environ.get("B", "32"))
 REP = int(os.environ.get("REP", "10"))
 shapes = [  # name, Cin, H, Cout, k, s, p
@@ -11,7 +13,10 @@ shapes = [  # name, Cin, H, Cout, k, s, p
     ("G.down1 64->128 k4s2 @128", 64, 128, 128, 4, 2, 1),
     ("G.down2 128->256 k4s2 @64", 128, 64, 256, 4, 2, 1),
     ("D.c2 64->128 k4s2 @64", 64, 64, 128, 4, 2, 1),
+    ("D.c3 128->256 k4s2 @32", 128, 32, 256, 4, 2, 1),
     ("D.c4 256->512 k4s2 @16", 256, 16, 512, 4, 2, 1),
+    ("Er.l3a 512->512 k3 @7 reflect", 512, 7, 512, 3, 1, 1),
+    ("Er.l3b 512->1024 k3 @7 reflect", 512, 7, 1024, 3, 1, 1),
     ("E.l0 64->128 k3 @62", 64, 62, 128, 3, 1, 1),
     ("E.l2 256->512 k3 @15", 256, 15, 512, 3, 1, 1),
     ("Er.l0a 64->64 k3 @62 reflect", 64, 62, 64, 3, 1, 1),

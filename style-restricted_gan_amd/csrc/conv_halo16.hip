@@ -393,6 +393,172 @@ __global__ __launch_bounds__(256) void halo16_wgrad_kernel(Halo16WgradParams p) 
     for (int e = 0; e < 16; ++e) out[(size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * (9 * p.C) + t * p.C] = acc[t][e];
 }
 
+// ---- weight gradient of the 4x4 / stride-2 / pad-1 layers (round 4; reference pyfiles/model.py:212-215, 227-230, 302-309) ----
+//   dW[o][c][ky][kx] = sum_{n, oy, ox} dy[n][oy][ox][o] * x[n][2 oy + ky - 1][2 ox + kx - 1][c]
+// The staged GEMM (wgrad_kernel<..., BF>) gives every (o tile, tap pair) workgroup its own pass over dy and x: 8 passes over each
+// tensor for the generator's 64 -> 128 layer, ~1 GB per launch through L2 / the Infinity Cache -- it runs at the rate of that
+// stream (0.10 of the bf16 matrix peak), not of the matrix pipe.  Here a workgroup owns a 64 (o) x 64 (c) block of ALL SIXTEEN
+// taps over a range of 2 x 32 output-pixel patches, as halo16_wgrad_kernel does for the 3x3 layers:
+//   * per patch the 64-channel slice of the 6 x 66 pixel region of x that the patch's taps touch (rows 4 py - 1 .. 4 py + 4,
+//     columns 64 px - 1 .. 64 px + 64; zero outside the image) and of the 64 dy pixels is read ONCE as fp32 (buffer loads, range-
+//     checked), rounded to bf16 and parked in LDS as [pixel][64 channels + pad]: x is read O / 64 times and dy C / 64 times in all;
+//   * the reduce index of the MFMA is the pixel, so both operands come from the transposing read ds_read_b64_tr_b16 (a 16-lane
+//     group reads 4 pixels x 16 channels and receives them channel-major).  The x fragment of (tap, 16-pixel K step) is that read
+//     at region pixel (2 i + ky) * 66 + 2 j + kx: consecutive output pixels lie TWO region pixels apart, and the row stride of
+//     160 bytes puts the four pixels of a read 16 banks apart at that distance (2 x 160 B = 80 dwords = 16 mod 64), the second
+//     16-channel group 8 banks further: conflict-free without separating the four input phases in LDS;
+//   * 8 waves = (o half, c half, upper / lower two filter rows): 8 taps x 16 accumulator registers per lane; the 4 dy fragments
+//     of a patch are read once and reused by the eight taps; 32 MFMAs per wave and patch, the next patch's 16 loads per thread
+//     in flight under them (double-buffered LDS, one barrier per patch);
+//   * split-K over patch ranges into [split][O][16 C] slabs (tap-major columns, as every weight-gradient kernel), summed by the
+//     deterministic slab reduce of conv_igemm.hip.
+struct Halo16S2WgradParams {
+  const void* x;      // [NB][2 Ho][2 Wo][C] fp32, or bf16 (X16)
+  const void* dy;     // [NB][Ho][Wo][O] fp32, or bf16 (D16)
+  float* slab;        // [splits][O][16 C]
+  int NB, Ho, Wo, C, O, tiles_y, tiles_x, patches, per_split, splits, o_tiles, c_tiles;
+};
+
+constexpr int S2XS = 160;              // bytes per region pixel in LDS (64 bf16 channels + 32 pad)
+constexpr int S2D = 64 * GPS;
+
+// PW: patch width in output pixels (32, 16 or 8; the patch is 64 / PW rows high): the discriminator's 16 x 16 and 8 x 8 output maps
+// are covered by 4 x 16 and 8 x 8 patches (regions of 10 x 34 and 18 x 18 pixels).
+template <int PW, bool X16, bool D16>
+__global__ __launch_bounds__(512) void halo16s2_wgrad_kernel(Halo16S2WgradParams p) {
+  constexpr int PH = 64 / PW, RW = 2 * PW + 2, S2R = (2 * PH + 2) * RW, S2X = S2R * S2XS;
+  constexpr int XSZ = X16 ? 2 : 4, DSZ = D16 ? 2 : 4;
+  typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4;
+  __shared__ __attribute__((aligned(16))) unsigned char xs[2 * S2X];
+  __shared__ __attribute__((aligned(16))) unsigned char ds[2 * S2D];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wo = wave >> 2, wc = (wave >> 1) & 1, th = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int li = lane & 15, q4 = li >> 2, pq = li & 3, g1 = (lane >> 4) & 1;
+
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);      // the (o, c) blocks of one patch range share an XCD's L2
+  const int tiles = p.o_tiles * p.c_tiles;
+  const int split = bid / tiles, tile = bid - split * tiles;
+  const int ot = tile / p.c_tiles, ct = tile - ot * p.c_tiles;
+  const int p_begin = split * p.per_split, p_end = min(p_begin + p.per_split, p.patches);
+  const int Hi = 2 * p.Ho, Wi = 2 * p.Wo;
+
+  const auto rs_x = uniform_rsrc(p.x, (unsigned)((size_t)p.NB * Hi * Wi * p.C * XSZ));
+  const auto rs_d = uniform_rsrc(p.dy, (unsigned)((size_t)p.NB * p.Ho * p.Wo * p.O * DSZ));
+  constexpr unsigned kOutside = 0x80000000u;
+  const int hcg = tid & 7, hpl = tid >> 3;           // 8 channels of one of the 64 pixels of a pass
+  constexpr int XP = (S2R + 63) / 64;                // 7 passes over the region
+
+  f32x4 xl[XP], xh[XP], dl, dh;
+  auto issue = [&](int patch) __attribute__((always_inline)) {
+    int r = patch;
+    const int tx = r % p.tiles_x; r /= p.tiles_x;
+    const int ty = r % p.tiles_y;
+    const int nb = r / p.tiles_y;
+    const int Y0 = 2 * PH * ty - 1, X0 = 2 * PW * tx - 1;     // region origin in x
+#pragma unroll
+    for (int g = 0; g < XP; ++g) {
+      const int hp = g * 64 + hpl;
+      const int hr = hp / RW, hc = hp - hr * RW;
+      const int y = Y0 + hr, x = X0 + hc;
+      const bool ok = hp < S2R && y >= 0 && y < Hi && x >= 0 && x < Wi;
+      const unsigned off = ok ? (unsigned)((((nb * Hi + y) * Wi + x) * p.C + ct * 64 + hcg * 8) * XSZ) : kOutside;
+      xl[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+      if constexpr (!X16) xh[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+    }
+    {
+      const int oy = PH * ty + hpl / PW, ox = PW * tx + hpl % PW;         // pixel hpl of the patch
+      const unsigned off = (unsigned)((((nb * p.Ho + oy) * p.Wo + ox) * p.O + ot * 64 + hcg * 8) * DSZ);
+      dl = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 0, 0));
+      if constexpr (!D16) dh = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 16, 0));
+    }
+  };
+  auto pack8 = [](f32x4 lo, f32x4 hi) __attribute__((always_inline)) {
+    const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+    bf16x8 v;
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    return v;
+  };
+  auto park = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < XP; ++g) {
+      const int hp = g * 64 + hpl;
+      if (hp < S2R) {
+        if constexpr (X16) *reinterpret_cast<f32x4*>(&xs[buf * S2X + hp * S2XS + hcg * 16]) = xl[g];
+        else *reinterpret_cast<bf16x8*>(&xs[buf * S2X + hp * S2XS + hcg * 16]) = pack8(xl[g], xh[g]);
+      }
+    }
+    if constexpr (D16) *reinterpret_cast<f32x4*>(&ds[buf * S2D + hpl * GPS + hcg * 16]) = dl;
+    else *reinterpret_cast<bf16x8*>(&ds[buf * S2D + hpl * GPS + hcg * 16]) = pack8(dl, dh);
+  };
+
+  f32x16 acc[8];      // tap (ky, kx) = (2 th + (t >> 2), t & 3)
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  // lane part of a transposing fragment read: pixel 8 lh + q4 (and + 4) of the K step, channels 16 g1 + 4 pq .. + 3 of the wave's 32
+  const int d_lane = (8 * lh + q4) * GPS + (wo * 32 + 16 * g1 + 4 * pq) * 2;
+  // pixel 16 ks + 8 lh + q4 of the patch = (row, column) = (that / PW, that % PW): the lane's part of its region pixel
+  const int x_lane = (2 * th * RW + (PW >= 16 ? 2 * (8 * lh + q4) : 2 * lh * RW + 2 * q4)) * S2XS + (wc * 32 + 16 * g1 + 4 * pq) * 2;
+  auto dfrag = [&](const unsigned char* base) __attribute__((always_inline)) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(base));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(base + 4 * GPS));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto xfrag = [&](const unsigned char* base) __attribute__((always_inline)) {      // pixels two region pixels apart
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(base));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(base + 8 * S2XS));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  // region-pixel offset of (tap t of this wave's eight, K step ks): row 2 i + ky (the 2 th part rides in x_lane), column 2 j0 + kx
+  // with (i, j0) = patch position of the K step's first pixel (its lane part rides in x_lane as well)
+  auto x_off = [](int t, int ks) __attribute__((always_inline)) {
+    const int i = PW == 32 ? ks >> 1 : PW == 16 ? ks : 2 * ks, j0 = PW == 32 ? 16 * (ks & 1) : 0;
+    return ((2 * i + (t >> 2)) * RW + 2 * j0 + (t & 3)) * S2XS;
+  };
+
+  if (p_begin < p_end) {
+    issue(p_begin);
+    park(0);
+    __syncthreads();
+  }
+  for (int pt = p_begin; pt < p_end; ++pt) {
+    const int buf = (pt - p_begin) & 1;
+    if (pt + 1 < p_end) issue(pt + 1);
+    const unsigned char* D = ds + buf * S2D + d_lane;
+    const unsigned char* X = xs + buf * S2X + x_lane;
+    bf16x8 df[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) df[ks] = dfrag(D + 16 * ks * GPS);
+    bf16x8 xf[2];
+    xf[0] = xfrag(X + x_off(0, 0));
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int g = t * 4 + ks;
+        if (g + 1 < 32) xf[(g + 1) & 1] = xfrag(X + x_off((g + 1) >> 2, (g + 1) & 3));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[ks], xf[g & 1], acc[t], 0, 0, 0);
+      }
+    }
+    if (pt + 1 < p_end) park(buf ^ 1);
+    __syncthreads();
+  }
+
+  // slab[split][o][tap * C + c]: lane = c (128-byte lines), register e = o row (e % 4) + 8 (e / 4) + 4 lh
+  float* out = p.slab + ((size_t)split * p.O + ot * 64 + wo * 32) * (16 * p.C) + ct * 64 + wc * 32 + lr;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      out[(size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * (16 * p.C) + (size_t)(8 * th + t) * p.C] = acc[t][e];
+}
+
 // ---- transposed form of the 4x4 / stride-2 / pad-1 layers (input gradient of the generator's down convolutions and of the
 // discriminator trunk, forward of the generator's ConvTranspose2d layers; reference pyfiles/model.py:212-215,227-230,302-309) ----
 // Output pixel (2u + r, 2v + s) of phase (r, s) is a 2x2 stride-1 correlation of the SOURCE map:
@@ -667,12 +833,39 @@ static void halo16_wgrad_plan(const srgan_conv_desc* d, Halo16WgradParams* p) {
   p->splits = (p->patches + p->per_split - 1) / p->per_split;
 }
 
+// 4x4 / stride-2 / pad-1 layers with whole 64-channel blocks on both sides and output maps of whole 2 x 32 patches
+static bool halo16s2_wgrad_ok(const srgan_conv_desc* d) {
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_HALO16_S2_WGRAD");
+  if (off || d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 1 || d->pad_mode != SRGAN_PAD_ZERO) return false;
+  if (d->I % 64 != 0 || d->O % 64 != 0 || d->Hi != 2 * d->Ho || d->Wi != 2 * d->Wo) return false;
+  if (!((d->Wo % 32 == 0 && d->Ho % 2 == 0) || (d->Wo == 16 && d->Ho % 4 == 0) || (d->Wo == 8 && d->Ho % 8 == 0))) return false;
+  return (long long)d->N * d->Hi * d->Wi * d->I < (1LL << 29) && (long long)d->N * d->Ho * d->Wo * d->O < (1LL << 29);
+}
+
+static void halo16s2_wgrad_plan(const srgan_conv_desc* d, Halo16S2WgradParams* p) {
+  p->NB = d->N; p->Ho = d->Ho; p->Wo = d->Wo; p->C = d->I; p->O = d->O;
+  const int pw = d->Wo % 32 == 0 ? 32 : d->Wo;
+  p->tiles_y = d->Ho / (64 / pw); p->tiles_x = d->Wo / pw;
+  p->patches = d->N * p->tiles_y * p->tiles_x;
+  p->o_tiles = d->O / 64; p->c_tiles = d->I / 64;
+  const int tiles = p->o_tiles * p->c_tiles;
+  int splits = std::max(1, std::min(p->patches, 256 / tiles));      // one workgroup per CU (148 KB of LDS)
+  p->per_split = (p->patches + splits - 1) / splits;
+  p->splits = (p->patches + p->per_split - 1) / p->per_split;
+}
+
 bool halo16_wgrad_applicable(const srgan_conv_desc* d) {
   static const bool off = SRGAN_AB_SET("SRGAN_NO_HALO16_WGRAD");
-  return !off && halo16_applicable(d, 0);
+  return (!off && halo16_applicable(d, 0)) || halo16s2_wgrad_ok(d);
 }
 
 void halo16_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad) {
+  if (halo16s2_wgrad_ok(d)) {
+    Halo16S2WgradParams q{};
+    halo16s2_wgrad_plan(d, &q);
+    *splits = q.splits; *Cdpad = d->O; *NNpad = 16 * d->I;
+    return;
+  }
   Halo16WgradParams p{};
   halo16_wgrad_plan(d, &p);
   *splits = p.splits; *Cdpad = d->O; *NNpad = 9 * d->I;
@@ -681,6 +874,19 @@ void halo16_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* N
 int halo16_wgrad_run(const srgan_conv_desc* d, const void* x, const void* dy, float* slab, double flops, hipStream_t st, bool x16,
                      bool d16) {
   SRGAN_REQUIRE(halo16_wgrad_applicable(d), "halo16 wgrad: layer not applicable");
+  if (halo16s2_wgrad_ok(d)) {
+    SRGAN_REQUIRE(!x16 && !d16, "halo16 stride-2 wgrad: fp32 tensors only");
+    Halo16S2WgradParams q{};
+    halo16s2_wgrad_plan(d, &q);
+    q.x = x; q.dy = dy; q.slab = slab;
+    ProfToken tok = prof_begin(26, flops, st);
+    const dim3 grid((unsigned)(q.o_tiles * q.c_tiles * q.splits));
+    if (d->Wo % 32 == 0) hipLaunchKernelGGL((halo16s2_wgrad_kernel<32, false, false>), grid, dim3(512), 0, st, q);
+    else if (d->Wo == 16) hipLaunchKernelGGL((halo16s2_wgrad_kernel<16, false, false>), grid, dim3(512), 0, st, q);
+    else hipLaunchKernelGGL((halo16s2_wgrad_kernel<8, false, false>), grid, dim3(512), 0, st, q);
+    prof_end(tok, st);
+    return check_launch("halo16s2_wgrad_kernel");
+  }
   Halo16WgradParams p{};
   halo16_wgrad_plan(d, &p);
   p.x = x; p.dy = dy; p.slab = slab;
