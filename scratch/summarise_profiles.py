@@ -39,6 +39,10 @@ def prof_name(n):
         return "wino43_kernel"
     if "halo16t_kernel" in n:
         return "halo16t_kernel"
+    if "halo16s2_wgrad_kernel" in n:
+        return "halo16s2_wgrad_kernel"
+    if "halo16s_kernel" in n:
+        return "halo16s_kernel"
     if "halo16_wgrad_kernel" in n:
         return "halo16_wgrad_kernel"
     if "halo16_kernel" in n:

@@ -746,6 +746,218 @@ __global__ __launch_bounds__(256) void halo16t_kernel(Halo16TParams p) {
   }
 }
 
+// ---- strided form of the 4x4 / stride-2 / pad-1 layers (round 4): forward of the generator's down convolutions and of the
+// discriminator trunk, input gradient of the generator's ConvTranspose2d layers (reference pyfiles/model.py:212-215, 227-230,
+// 302-309) ----
+//   out[oy][ox][n] = sum_{ky, kx, c} x[2 oy + ky - 1][2 ox + kx - 1][c] * w[n][c][ky][kx]
+// The staged GEMM (igemm_kernel<256,128,BF>) pushes every input pixel through registers -> convert -> LDS once per tap that uses
+// it (4 of the 16) and streams fp32 filter tiles.  Here a workgroup owns a 4 x 32 output patch and all N output channels:
+//   * the 10 x 66 pixel region of x behind the patch (zero outside the image) is read ONCE per 64-channel half as fp32, rounded
+//     to bf16 and parked in LDS (95 KB).  Output pixels that are neighbours in a row read region pixels TWO apart, so the region
+//     is stored with its even and odd columns in separate planes, [row][column parity][33][64 channels + 8 pad]: the A fragment
+//     of (tap, K step) is then ONE ds_read_b128 per 32-pixel row at plane (kx & 1), column j + (kx >> 1) -- consecutive lanes
+//     144 bytes apart, conflict-free as in halo16_kernel;
+//   * K order (half, tap, chunk): the bf16 filter tiles [N][8192 / N reduce channels] (16 KB, 16 MFMAs per wave) stream
+//     global -> registers -> LDS through three buffers exactly as in halo16t_kernel; with C = 128 the second half of the region
+//     replaces the first between two tiles (exposed: 2 of 66 tile times);
+//   * 4 waves, each 2 rows x 32 pixels x N / 2 output channels; bias / activation in the epilogue, whole 128-byte lines per store.
+// These layers are short in K (16 or 64 filter tiles per patch): by ablation (make exp builds, profiles/LOG.md) a 94 us launch of
+// the 64 -> 128 layer at batch 32 spends 23 us reading regions, 21 us writing results and 13 us in the matrix pipe, one after the
+// other -- every CU holds one workgroup (143 KB of LDS) and all of them change phase together.  A persistent variant with loader
+// waves and a double-buffered 2 x 32 patch overlapped the phases but halved the work per fragment read and per barrier and came
+// out even (92 us); what would pay is bf16 activations in HBM (region straight into LDS, half the bytes).
+struct Halo16SParams {
+  const float* src;            // [NB][2 Ho][2 Wo][C]
+  const unsigned short* wp;    // packed bf16 filters [64-channel half][tap][chunk][N][8192 / N]
+  const float* bias;           // [N] or null
+  float* dst;                  // [NB][Ho][Wo][N]
+  int NB, Ho, Wo, tiles_y, tiles_x, act;
+  float slope;
+};
+
+template <int C, int BN>
+__global__ __launch_bounds__(256) void halo16s_kernel(Halo16SParams p) {
+  constexpr int PS = 64 * 2 + 16;              // bytes per region pixel (the resident 64-channel half)
+  constexpr int NH = C / 64;                   // halves
+  constexpr int HKT = 8192 / BN;               // reduce channels per filter tile
+  constexpr int NCH = 64 / HKT;                // tiles per tap of a half
+  constexpr int NKH = 16 * NCH;                // tiles per half
+  constexpr int NK = NH * NKH;
+  constexpr int KS = HKT / 16;                 // 16-deep K steps per tile
+  constexpr int TN = BN / 64;                  // 32-wide output-channel blocks per wave
+  constexpr int WTILE = 16384;
+  constexpr int PCS = HKT / 8;                 // 16-byte pieces per tile row
+  constexpr int SWS = PCS == 16 ? 0 : PCS == 8 ? 1 : 2;      // swizzle key = (row >> SWS) & (PCS - 1): one key per 256 bytes of rows
+  constexpr int RPX = 10 * 66;
+  static_assert((C == 64 && BN == 128) || (C == 128 && BN == 256), "instantiated for (C, N) = (64, 128) and (128, 256)");
+  static_assert(KS % 2 == 0 && NKH % 2 == 0, "fragment slots alternate per K step, two tiles per loop body");
+  __shared__ __attribute__((aligned(16))) unsigned char halo[RPX * PS];
+  __shared__ __attribute__((aligned(16))) unsigned char wt[3 * WTILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);      // neighbouring patches (shared region rows) on one XCD
+  int r0 = bid;
+  const int tx = r0 % p.tiles_x; r0 /= p.tiles_x;
+  const int ty = r0 % p.tiles_y;
+  const int nb = r0 / p.tiles_y;
+  const int Hi = 2 * p.Ho, Wi = 2 * p.Wo;
+  const int Y0 = 8 * ty - 1, X0 = 64 * tx - 1;          // region origin in x
+
+  const auto rs_x = uniform_rsrc(p.src, (unsigned)((size_t)p.NB * Hi * Wi * C * 4));
+  const auto rs_w = uniform_rsrc(p.wp, (unsigned)(NK * WTILE));
+
+  f32x4 wreg[4], wreg2[4];
+  auto load_w = [&](f32x4* dst, int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, tid * 16 + i * 4096, kt * WTILE, 0));
+  };
+  auto store_w = [&](const f32x4* src, int boff) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i;               // piece q: row q / PCS, piece q % PCS
+      const int n = q / PCS, pc = q % PCS;
+      *reinterpret_cast<f32x4*>(&wt[boff + n * (HKT * 2) + ((pc ^ ((n >> SWS) & (PCS - 1))) << 4)]) = src[i];
+    }
+  };
+  load_w(wreg, 0);
+  load_w(wreg2, 1);
+
+  // ---- one 64-channel half of the region: 21 passes of 32 pixels x 8 channels per thread, seven passes in flight ----
+  const int hcg = tid & 7, hpl = tid >> 3;
+  constexpr unsigned kOutside = 0x80000000u;
+  auto load_region = [&](int half) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      f32x4 lo[7], hi[7];
+#pragma unroll
+      for (int g = 0; g < 7; ++g) {
+        const int hp = (b * 7 + g) * 32 + hpl;
+        const int hr = hp / 66, hc = hp - hr * 66;
+        const int y = Y0 + hr, x = X0 + hc;
+        const bool ok = hp < RPX && y >= 0 && y < Hi && x >= 0 && x < Wi;
+        const unsigned off = ok ? (unsigned)((((nb * Hi + y) * Wi + x) * C + half * 64 + hcg * 8) * 4) : kOutside;
+        lo[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+        hi[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+      }
+#pragma unroll
+      for (int g = 0; g < 7; ++g) {
+        const int hp = (b * 7 + g) * 32 + hpl;
+        if (hp < RPX) {
+          const int hr = hp / 66, hc = hp - hr * 66;
+          const bf16x4 a = __builtin_convertvector(lo[g], bf16x4), c = __builtin_convertvector(hi[g], bf16x4);
+          bf16x8 v;
+          v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = c[0]; v[5] = c[1]; v[6] = c[2]; v[7] = c[3];
+          *reinterpret_cast<bf16x8*>(&halo[((hr * 2 + (hc & 1)) * 33 + (hc >> 1)) * PS + hcg * 16]) = v;
+        }
+      }
+    }
+  };
+  load_region(0);
+  store_w(wreg, 0);
+  store_w(wreg2, WTILE);
+  load_w(wreg, 2);
+  load_w(wreg2, 3);
+  __syncthreads();
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // lane's A address: output pixel (row 2 wm, column lr) at tap (0, 0) = region row 4 wm, plane 0, column lr; K half lh
+  const unsigned char* a_lane = halo + (wm * 8 * 33 + lr) * PS + lh * 16;
+  const int b_row = (wn * (BN / 2) + lr) * (HKT * 2), b_key = (lr >> SWS) & (PCS - 1);
+  auto b_off = [&](int s) __attribute__((always_inline)) { return b_row + (((2 * s + lh) ^ b_key) << 4); };
+
+  bf16x8 fa[2][2], fb[2][TN];
+  auto read_a = [&](int slot, const unsigned char* a, int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[slot][i] = *reinterpret_cast<const bf16x8*>(a + i * (4 * 33 * PS) + s * 32);
+  };
+  auto read_b = [&](int slot, int woff, int s) __attribute__((always_inline)) {
+    const unsigned char* B = wt + woff + b_off(s);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const bf16x8*>(B + j * 32 * (HKT * 2));
+  };
+  auto mma = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i], fb[slot][j], acc[i][j], 0, 0, 0);
+  };
+  // A address of tile (tap, chunk): region row + ky, plane kx & 1, column + (kx >> 1); chunk * HKT channels
+  auto a_of = [&](int tap, int ch) __attribute__((always_inline)) {
+    const int ky = tap >> 2, kx = tap & 3;
+    return a_lane + ((ky * 2 + (kx & 1)) * 33 + (kx >> 1)) * PS + ch * (HKT * 2);
+  };
+
+  int w_cur = 0, w_nxt = WTILE, w_nn = 2 * WTILE;
+  int half = 0, tap = 0, ch = 0;               // coordinates of tile kt
+  read_a(0, a_of(0, 0), 0);
+  read_b(0, w_cur, 0);
+  for (int kt = 0; kt < NK; kt += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = kt + u;
+      const unsigned char* a_cur = a_of(tap, ch);
+      int nch = ch + 1, ntap = tap, nhalf = half;
+      if (nch == NCH) { nch = 0; ntap = tap + 1; if (ntap == 16) { ntap = 0; nhalf = half + 1; } }
+      const unsigned char* a_nx = a_of(ntap, nch);
+      const bool reload = NH > 1 && nhalf != half && t + 1 < NK;      // the region changes before the next tile
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
+          read_a((s + 1) & 1, a_cur, s + 1);
+          read_b((s + 1) & 1, w_cur, s + 1);
+        } else {
+          if (t + 1 < NK) {
+            if (!reload) read_a(0, a_nx, 0);
+            read_b(0, w_nxt, 0);
+          }
+          if (t + 2 < NK) store_w(u == 0 ? wreg : wreg2, w_nn);
+          if (t + 4 < NK) load_w(u == 0 ? wreg : wreg2, t + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(s & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      if (reload) {                            // (wave-uniform) every wave is done with the old half
+        load_region(nhalf);
+        __syncthreads();
+        read_a(0, a_nx, 0);
+      }
+      const int tw = w_cur; w_cur = w_nxt; w_nxt = w_nn; w_nn = tw;
+      half = nhalf; tap = ntap; ch = nch;
+    }
+  }
+
+  // ---- epilogue: lane = output channel; register e of acc[i][j] = pixel column (e % 4) + 8 (e / 4) + 4 lh of output row
+  // 4 ty + 2 wm + i (16-byte stores through an LDS transpose were measured: no gain -- the write phase is bound by memory) ----
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const size_t row = ((size_t)(nb * p.Ho + 4 * ty + 2 * wm + i) * p.Wo + 32 * tx) * BN;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = wn * (BN / 2) + j * 32 + lr;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        p.dst[row + (size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * BN + n] = apply_act(acc[i][j][e] + bv, p.act, p.slope);
+    }
+  }
+}
+
 template <int C>
 int launch_c(const Halo16Params& p, bool in16, bool out16, long long grid, hipStream_t st) {
   const dim3 g((unsigned)grid), b(256);
@@ -819,6 +1031,32 @@ int halo16t_run(const srgan_conv_desc* d, const float* dy, const void* packed, f
   else hipLaunchKernelGGL((halo16t_kernel<128, 64>), dim3((unsigned)grid), dim3(256), 0, st, p);
   prof_end(tok, st);
   return check_launch("halo16t_kernel");
+}
+
+// ---- strided 4x4 / stride-2 form: kind 0 of the layer (variant 6 of conv_wino.hip's slot) ----
+bool halo16s_applicable(const srgan_conv_desc* d) {
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_HALO16S");
+  if (off || d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 1 || d->pad_mode != SRGAN_PAD_ZERO) return false;
+  if (!((d->I == 64 && d->O == 128) || (d->I == 128 && d->O == 256))) return false;
+  if (d->Hi != 2 * d->Ho || d->Wi != 2 * d->Wo || d->Ho % 4 != 0 || d->Wo % 32 != 0) return false;
+  return (long long)d->N * d->Hi * d->Wi * d->I < (1LL << 29) && (long long)d->N * d->Ho * d->Wo * d->O < (1LL << 30);
+}
+
+size_t halo16s_packed_bytes(const srgan_conv_desc* d) { return (size_t)16 * d->I * d->O * 2; }
+
+int halo16s_run(const srgan_conv_desc* d, const float* x, const void* packed, const float* bias, float* y, int act, float slope,
+                double flops, hipStream_t st) {
+  SRGAN_REQUIRE(halo16s_applicable(d), "halo16s: layer not applicable");
+  Halo16SParams p{};
+  p.src = x; p.wp = reinterpret_cast<const unsigned short*>(packed); p.bias = bias; p.dst = y;
+  p.NB = d->N; p.Ho = d->Ho; p.Wo = d->Wo; p.tiles_y = d->Ho / 4; p.tiles_x = d->Wo / 32; p.act = act; p.slope = slope;
+  const long long grid = (long long)p.NB * p.tiles_y * p.tiles_x;
+  SRGAN_REQUIRE(grid > 0 && grid < (1LL << 31), "halo16s: grid");
+  ProfToken tok = prof_begin(29, flops, st);
+  if (d->I == 64) hipLaunchKernelGGL((halo16s_kernel<64, 128>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((halo16s_kernel<128, 256>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  prof_end(tok, st);
+  return check_launch("halo16s_kernel");
 }
 
 // ---- weight gradient host side (hooked into conv_wino.hip's weight-gradient slot in bf16 mode) ----

@@ -44,8 +44,8 @@ static const char* const kProfNames[] = {
     "wgrad_kernel<gen>", "wgrad_kernel<vec>", "igemm_kernel<256,128,4,2,gen>", "igemm_kernel<256,128,4,2,vec>",
     "igemm_kernel<256,64,4,2,gen>", "igemm_kernel<256,64,4,2,vec>", "wino_kernel", "wino_wgrad_kernel", "wino_kernel<4x4s2>", "wino_wgrad_kernel<4x4s2>",
     "wino43_kernel", "wino43_input_kernel", "rgbin_conv_kernel", "rgb_wgrad_kernel", "wino43_wgrad_kernel", "wino43_dy_kernel",
-    "halo16_kernel", "halo16_wgrad_kernel", "halo16s2_wgrad_kernel", "halo16t_kernel", "rgbout_conv_kernel"};
-constexpr int kProfKernels = 29;
+    "halo16_kernel", "halo16_wgrad_kernel", "halo16s2_wgrad_kernel", "halo16t_kernel", "rgbout_conv_kernel", "halo16s_kernel"};
+constexpr int kProfKernels = 30;
 
 struct ProfScope {
   bool on;

@@ -810,7 +810,8 @@ static bool wino_s2_disabled() {
 static int wino_variant(const srgan_conv_desc* d, int kind) {
   if (compute_bf16()) {                                            // bf16 mode: the transforms would eat the 8-bit mantissa
     if (halo16_applicable(d, kind)) return 4;
-    return kind == 1 && halo16t_applicable(d) ? 5 : 0;              // 5: transposed 4x4 / stride-2 form (conv_halo16.hip)
+    if (kind == 1 && halo16t_applicable(d)) return 5;               // 5: transposed 4x4 / stride-2 form (conv_halo16.hip)
+    return kind == 0 && halo16s_applicable(d) ? 6 : 0;              // 6: strided 4x4 / stride-2 form
   }
   if (wino_disabled()) return 0;
 
@@ -853,8 +854,8 @@ static void wino_dims(const srgan_conv_desc* d, int kind, int* C, int* N, int* n
   const int v = wino_variant(d, kind);
   *C = kind == 0 ? d->I : d->O;
   *N = kind == 0 ? d->O : d->I;
-  *n_tiles = (v == 4 || v == 5) ? 1 : v == 3 ? *N / 32 : (int)ceil_div(*N, WNB);
-  *nchunk = (v == 4 || v == 5) ? *C / 32 : (v == 2 && kind == 0 ? 4 : 1) * (*C / WC);      // MODE 1 reduces over (input phase, channel)
+  *n_tiles = (v >= 4) ? 1 : v == 3 ? *N / 32 : (int)ceil_div(*N, WNB);
+  *nchunk = (v >= 4) ? *C / 32 : (v == 2 && kind == 0 ? 4 : 1) * (*C / WC);      // MODE 1 reduces over (input phase, channel)
   *phases = (v == 2 && kind == 1) ? 4 : 1;                  // (variant 5 keeps its four phases inside one packed image)                  // MODE 2: one filter image per output phase
 }
 
@@ -862,6 +863,7 @@ size_t wino_packed_bytes(const srgan_conv_desc* d, int kind) {
   int C, N, n_tiles, nchunk, phases;
   wino_dims(d, kind, &C, &N, &n_tiles, &nchunk, &phases);
   if (wino_variant(d, kind) == 4) return halo16_packed_bytes(d);
+  if (wino_variant(d, kind) == 6) return halo16s_packed_bytes(d);
   if (wino_variant(d, kind) == 5) return halo16t_packed_bytes(d);
   if (wino_variant(d, kind) == 3) return (size_t)n_tiles * nchunk * (36 * 256) * sizeof(float);
   return (size_t)phases * n_tiles * nchunk * 8192 * sizeof(float);
@@ -932,6 +934,10 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
   wino_dims(d, kind, &C, &N, &p.n_tiles, &p.nchunk, &phases);
   const int variant = wino_variant(d, kind);
   SRGAN_REQUIRE(variant != 0, "winograd: layer not applicable");
+  if (variant == 6) {
+    SRGAN_REQUIRE(!v_ready && !res && !mask, "halo16s: no prepared image, skip tensor or mask on this path");
+    return halo16s_run(d, src, packed, bias, dst, act, slope, conv_flops_of(d), st);
+  }
   if (variant == 5) {
     SRGAN_REQUIRE(!v_ready && !bias && act == SRGAN_ACT_NONE, "halo16t: plain transposed product only");
     return halo16t_run(d, src, packed, dst, conv_flops_of(d), st);

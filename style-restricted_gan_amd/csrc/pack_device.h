@@ -95,7 +95,7 @@ struct WinoPackParams {
 
 constexpr int WP_WNB = 64, WP_WC = 8;
 __device__ __host__ __forceinline__ long long wino_pack_total(const WinoPackParams& p) {
-  if (p.variant == 5) return (long long)p.N * (p.C / 8);                           // one item = 8 reduce channels of one output channel, 16 taps
+  if (p.variant == 5 || p.variant == 6) return (long long)p.N * (p.C / 8);         // one item = 8 reduce channels of one output channel, 16 taps
   if (p.variant == 4) return (long long)p.nchunk * p.N * 4;                      // one item = 8 reduce channels of one cout, 9 taps
   if (p.variant == 3) return (long long)p.n_tiles * 32 * p.nchunk * 2;          // one item = 4 channels of one cout
   return (long long)p.n_tiles * WP_WNB * p.nchunk * WP_WC * p.phases;
@@ -285,8 +285,39 @@ __device__ __forceinline__ void halo16t_pack_item(const WinoPackParams& p, long 
     }
 }
 
+// variant 6 (conv_halo16.hip, strided 4x4 / stride-2 form, kind 0 of w[O][I][4][4]): bf16
+// [64-channel half][tap (ky, kx)][chunk of the half][N = O][HK = 8192 / N reduce channels c],  B[n][k] = w[n][k][ky][kx].
+// One item = (n, 8 reduce channels) for all 16 taps: 512 contiguous source bytes with dense OIHW weights.
+__device__ __forceinline__ void halo16s_pack_item(const WinoPackParams& p, long long idx) {
+  const int hk = 8192 / p.N, pcs = hk / 8, nchk = 64 / hk;
+  long long r = idx;
+  const int part = (int)(r % pcs); r /= pcs;
+  const int n = (int)(r % p.N);
+  const int chunkg = (int)(r / p.N);                    // chunk of hk channels over all of C
+  const int half = chunkg / nchk, chunk = chunkg - half * nchk;
+  float v[8][16];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = chunkg * hk + part * 8 + j;
+    const float* src = p.w + n * p.sO + k * p.sI;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[j][t] = src[(t >> 2) * p.sH + (t & 3) * p.sW];
+  }
+  unsigned short* dst = reinterpret_cast<unsigned short*>(p.dst);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const f32x4 lo = {v[0][t], v[1][t], v[2][t], v[3][t]}, hi = {v[4][t], v[5][t], v[6][t], v[7][t]};
+    const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+    bf16x8 o;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+    const int kt = (half * 16 + t) * nchk + chunk;
+    *reinterpret_cast<bf16x8*>(dst + ((size_t)kt * p.N + n) * hk + part * 8) = o;
+  }
+}
+
 __device__ __forceinline__ void wino_pack_item(const WinoPackParams& p, long long idx) {
   constexpr int WNB = WP_WNB, WC = WP_WC;
+  if (p.variant == 6) { halo16s_pack_item(p, idx); return; }
   if (p.variant == 5) { halo16t_pack_item(p, idx); return; }
   if (p.variant == 4) { halo16_pack_item(p, idx); return; }
   if (p.variant == 3) { wino43_pack_item(p, idx); return; }
