@@ -186,6 +186,15 @@ def pmc_traffic(kernel_name, dtype="f32"):
 GD_GFLOP_PER_IMAGE = {128: 60.54, 256: 243.86}        # (3 F_G - f_G) + (3 F_D - f_D), SURVEY.md 8d
 
 
+HBM_PEAK_TBS = 8.0                                                   # HBM3E spec (6.3 TB/s measured for a float4 copy), MI355X_MICROARCH.md
+HBM_KERNELS = ("in_stats_partial", "in_apply", "in_bwd_partial", "in_bwd_apply", "in_fwd_slab", "in_bwd_slab")
+
+
+def is_hbm_kernel(name):
+    """Kernels whose launch brackets carry ALGORITHMIC BYTES instead of FLOPs (csrc/norm.hip: the instance-norm passes)."""
+    return name in HBM_KERNELS
+
+
 def executed_divisor(name):
     """Algorithmic conv FLOPs / MFMA FLOPs actually issued: Winograd F(4x4,3x3) multiplies 36 values per 16 outputs x 9 taps
     (4x fewer), F(2x2,3x3) / F(3x3,2x2) 16 per 36 (2.25x fewer, before the waste of ragged edge tiles); 1 for the direct forms."""
@@ -240,7 +249,7 @@ def micro_gd_run(size, batch, dtype, steps, warmup, device):
     for kid in range(lib.srgan_prof_num_kernels()):
         ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
         _lib.check(lib.srgan_prof_collect(kid, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_collect")
-        if n.value:
+        if n.value and not is_hbm_kernel(lib.srgan_prof_kernel_name(kid).decode()):
             issued += fl.value / executed_divisor(lib.srgan_prof_kernel_name(kid).decode()) / 2
             counted += fl.value / 2
             gemm_ms += ms.value / 2
@@ -495,6 +504,7 @@ def main():
 
     # per-kernel totals of the HIP-event brackets
     kernels = {}
+    hbm = {}
     best = None
     for kid in range(lib.srgan_prof_num_kernels()):
         ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
@@ -502,6 +512,11 @@ def main():
         if n.value == 0:
             continue
         name = lib.srgan_prof_kernel_name(kid).decode()
+        if is_hbm_kernel(name):
+            hbm[name] = {"launches": n.value, "total_ms": round(ms.value, 3), "avg_us": round(1e3 * ms.value / n.value, 2),
+                         "algorithmic_mb_per_launch": round(fl.value / n.value / 1e6, 2),
+                         "achieved_tb_s": round(fl.value / (ms.value * 1e-3) / 1e12, 3), "_ms": ms.value, "_bytes": fl.value}
+            continue
         div = executed_divisor(name)
         kernels[name] = {"launches": n.value, "total_ms": round(ms.value, 3), "avg_us": round(1e3 * ms.value / n.value, 2),
                          "algorithmic_tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
@@ -590,6 +605,23 @@ def main():
                                           "the timed region (HIP events on the launch stream, rank 0)",
                          "all_gemm_kernels": kernels},
         }
+        if hbm:
+            # the largest HBM-bound kernel of the step: algorithmic bytes per launch / duration / 8 TB/s
+            top = max(hbm, key=lambda k_: hbm[k_]["_ms"])
+            tot_ms = sum(v["_ms"] for v in hbm.values())
+            tot_b = sum(v["_bytes"] for v in hbm.values())
+            for v in hbm.values():
+                v.pop("_ms"), v.pop("_bytes")
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": top, "achieved": round(1e3 * hbm[top]["achieved_tb_s"], 1), "peak": 1e3 * HBM_PEAK_TBS,
+                                   "unit": "GB/s", "frac": round(hbm[top]["achieved_tb_s"] / HBM_PEAK_TBS, 4),
+                                   "launches": hbm[top]["launches"], "avg_launch_us": hbm[top]["avg_us"],
+                                   "algorithmic_mb_per_launch": hbm[top]["algorithmic_mb_per_launch"],
+                                   "instance_norm_passes": {"ms_per_step": round(tot_ms / prof_steps, 3),
+                                                            "achieved_tb_s": round(tot_b / (tot_ms * 1e-3) / 1e12, 3),
+                                                            "note": "all bracketed instance-norm passes (two-pass and slab kernels of csrc/norm.hip; the "
+                                                                    "fused norm + Winograd-transform kernels of the trunk are not bracketed): tensor bytes "
+                                                                    "each pass must move / summed duration"},
+                                   "measured_over": out["roofline"]["measured_over"], "kernels": hbm}
         if world == 1 and not args.no_micro and args.size in GD_GFLOP_PER_IMAGE:
             log("micro benchmark: G+D forward-backward")
             del sg

@@ -793,22 +793,29 @@ extern "C" int srgan_instnorm_fwd(const float* x, const float* scale, const floa
   int S, rps;
   plan_split(N, HW, C, S, rps);
   SRGAN_REQUIRE(ws && ws_bytes >= (size_t)N * S * C * sizeof(float2), "instnorm_fwd: workspace too small");
+  const double tbytes = (double)N * HW * C * sizeof(float);      // bench.py's roofline_hbm: bytes the passes must move
   if (slab_fast(N, HW, C)) {
     const dim3 gs((unsigned)(C / 32), (unsigned)N);
     const int rows = (HW + 63) / 64;
 #define SRGAN_FWD_SLAB(R) hipLaunchKernelGGL(in_fwd_slab<R>, gs, dim3(512), 0, st, x, scale, shift, res, y, mean, rstd, HW, C, eps, act, slope, slab_remap())
+    ProfToken tok = prof_begin(34, (res ? 3.0 : 2.0) * tbytes, st);
     if (rows <= 1) SRGAN_FWD_SLAB(1);
     else if (rows <= 2) SRGAN_FWD_SLAB(2);
     else if (rows <= 4) SRGAN_FWD_SLAB(4);
     else if (rows <= 8) SRGAN_FWD_SLAB(8);
     else SRGAN_FWD_SLAB(16);
 #undef SRGAN_FWD_SLAB
+    prof_end(tok, st);
     return check_launch("instnorm_fwd (slab)");
   }
   float2* part = reinterpret_cast<float2*>(ws);
   dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
-  if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4, g, dim3(256), 0, st, x, part, HW, C, S, rps);
-  else hipLaunchKernelGGL(in_stats_partial, g, dim3(256), 0, st, x, part, HW, C, S, rps);
+  {
+    ProfToken tok = prof_begin(30, tbytes, st);
+    if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4, g, dim3(256), 0, st, x, part, HW, C, S, rps);
+    else hipLaunchKernelGGL(in_stats_partial, g, dim3(256), 0, st, x, part, HW, C, S, rps);
+    prof_end(tok, st);
+  }
   const long long total = (long long)N * HW * C;
   // the fused finish re-reads the shift sample x[n][pixel 0][c] in EVERY workgroup of the apply pass while workgroup 0 may
   // already be storing y there: an in-place call (y == x, or the skip tensor == y) takes the separate finalize launch instead
@@ -816,8 +823,10 @@ extern "C" int srgan_instnorm_fwd(const float* x, const float* scale, const floa
   if (pow2_fast(C, HW) && fuse_final) {
     const int hwc4 = HW * C / 4;
     dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
+    ProfToken tok = prof_begin(31, (res ? 3.0 : 2.0) * tbytes, st);
     hipLaunchKernelGGL(in_apply_pow2, g2, dim3(256), 0, st, x, scale, shift, res, mean, rstd, y, hwc4, C, act, slope,
                        (const float2*)part, S, HW, eps);
+    prof_end(tok, st);
     return check_launch("instnorm_fwd");
   }
   hipLaunchKernelGGL(in_stats_final, dim3((N * C + 255) / 256), dim3(256), 0, st, x, (const float2*)part, mean, rstd, N, HW, C, S, eps);
@@ -845,29 +854,38 @@ extern "C" int srgan_instnorm_bwd(const float* x, const float* dy, const float* 
   int S, rps;
   plan_split(N, HW, C, S, rps);
   SRGAN_REQUIRE(ws && ws_bytes >= (size_t)N * S * C * sizeof(float2), "instnorm_bwd: workspace too small");
+  const double tbytes = (double)N * HW * C * sizeof(float);
   if (slab_fast(N, HW, C)) {
     const dim3 gs((unsigned)(C / 16), (unsigned)N);
     const int rows = (HW + 63) / 64;
 #define SRGAN_BWD_SLAB(R) hipLaunchKernelGGL(in_bwd_slab<R>, gs, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dx, dscale, dshift, HW, C, act, slope, slab_remap())
+    ProfToken tok = prof_begin(35, 3.0 * tbytes, st);
     if (rows <= 1) SRGAN_BWD_SLAB(1);
     else if (rows <= 2) SRGAN_BWD_SLAB(2);
     else if (rows <= 4) SRGAN_BWD_SLAB(4);
     else if (rows <= 8) SRGAN_BWD_SLAB(8);
     else SRGAN_BWD_SLAB(16);
 #undef SRGAN_BWD_SLAB
+    prof_end(tok, st);
     return check_launch("instnorm_bwd (slab)");
   }
   float2* part = reinterpret_cast<float2*>(ws);
   dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
-  if ((C & 3) == 0) hipLaunchKernelGGL(in_bwd_partial_v4, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
-  else hipLaunchKernelGGL(in_bwd_partial, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
+  {
+    ProfToken tok = prof_begin(32, 2.0 * tbytes, st);
+    if ((C & 3) == 0) hipLaunchKernelGGL(in_bwd_partial_v4, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
+    else hipLaunchKernelGGL(in_bwd_partial, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
+    prof_end(tok, st);
+  }
   const long long total = (long long)N * HW * C;
   const float inv_hw = 1.f / (float)HW;
   if (pow2_fast(C, HW)) {      // (the backward's fused finish reads the partial sums only: in-place dx is an elementwise update)
     const int hwc4 = HW * C / 4;
     dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
+    ProfToken tok = prof_begin(33, 3.0 * tbytes, st);
     hipLaunchKernelGGL(in_bwd_apply_pow2, g2, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, hwc4, C, inv_hw, act,
                        slope, (const float2*)part, S);
+    prof_end(tok, st);
     return check_launch("instnorm_bwd");
   }
   hipLaunchKernelGGL(in_bwd_final, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float2*)part, dshift, dscale, N * C, C, S);
