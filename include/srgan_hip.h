@@ -230,13 +230,19 @@ int srgan_linear_bwd(const float* x, const float* W, const float* dy, float* dx,
  * srgan_halo16_conv: kind 0 forward, kind 1 input gradient (+ `res`, fp32, added to an fp32 result).  srgan_halo16_wgrad: dw
  * (fp32, through the descriptor's weight strides); bf16 x requires bf16 dy.  ws: srgan_conv2d_workspace(d) bytes. */
 int srgan_halo16_applicable(const srgan_conv_desc* d);
+/* Round 4: the same two entry points also serve the 4x4 / stride-2 / pad-1 layers whose three directions run on the
+ * LDS-resident-patch kernels in the bf16 mode -- (Cin, Cout) = (64, 128) / (128, 256), output maps of whole 4 x 32 patches: the
+ * generator's down convolutions (pyfiles/model.py:212-215) and, through their transposed form, its up convolutions (:227-230).
+ * kind 0 = strided form (x -> y, or a ConvTranspose2d's input gradient), kind 1 = transposed form (dy -> dx, or a ConvTranspose2d
+ * forward); no `res`.  srgan_halo16_wgrad on these layers: bf16 x with fp32 or bf16 dy, or both fp32. */
+int srgan_halo16s2_applicable(const srgan_conv_desc* d);
 int srgan_halo16_conv(const srgan_conv_desc* d, int kind, const void* src, int src_bf16, const void* packed, const float* res,
                       void* dst, int dst_bf16, void* stream);
 int srgan_halo16_wgrad(const srgan_conv_desc* d, const void* x, int x_bf16, const void* dy, int dy_bf16, float* dw, void* ws,
                        size_t ws_bytes, void* stream);
 /* Single-pass instance norm (+ per-sample scale / shift, activation, optional fp32 skip tensor) of maps with <= 1024 pixels with
  * bf16 tensors on either side; statistics, sums, scale / shift gradients in fp32.  Backward: x = the normalised tensor's INPUT
- * (bf16), dy fp32 or bf16, dx bf16.  srgan_instnorm_slab_applicable: the shape is served (C % 32 == 0, HW <= 1024, enough slabs). */
+ * (fp32 or bf16), dy fp32 or bf16, dx of x's type.  srgan_instnorm_slab_applicable: the shape is served (C % 32 == 0, HW <= 1024, enough slabs). */
 int srgan_instnorm_slab_applicable(int N, int HW, int C);
 int srgan_instnorm_slab_fwd_io(const void* x, int x_bf16, const float* scale, const float* shift, const float* res, void* y,
                                int y_bf16, float* mean, float* rstd, int N, int HW, int C, float eps, int act, float slope,
@@ -244,6 +250,17 @@ int srgan_instnorm_slab_fwd_io(const void* x, int x_bf16, const float* scale, co
 int srgan_instnorm_slab_bwd_io(const void* x, int x_bf16, const void* dy, int dy_bf16, const float* scale, const float* shift,
                                const float* mean, const float* rstd, void* dx, int dx_bf16, float* dscale, float* dshift, int N,
                                int HW, int C, int act, float slope, void* stream);
+/* Instance norm (+ affine, activation) with fp32 or bf16 tensors on either side, for the shapes the slab kernels or the fast
+ * two-pass kernels serve (srgan_instnorm_io_applicable: HW <= 1024 with C % 32 == 0, or C | 1024 with C % 4 == 0): the norms
+ * between the generator's down / up convolutions when the bf16 mode keeps those activations in 16 bits (pyfiles/model.py:54-67,
+ * 228, 231, 245-246).  Statistics, scale / shift and their gradients are fp32.  Backward: dx has x's type.  ws:
+ * srgan_instnorm_workspace(N, HW, C) bytes. */
+int srgan_instnorm_io_applicable(int N, int HW, int C);
+int srgan_instnorm_fwd_io(const void* x, int x_bf16, const float* scale, const float* shift, void* y, int y_bf16, float* mean,
+                          float* rstd, int N, int HW, int C, float eps, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int srgan_instnorm_bwd_io(const void* x, int x_bf16, const void* dy, int dy_bf16, const float* scale, const float* shift,
+                          const float* mean, const float* rstd, void* dx, int dx_bf16, float* dscale, float* dshift, int N, int HW,
+                          int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);
 
 /* NCHW <-> NHWC repack at the module boundary. */
 int srgan_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);

@@ -150,11 +150,12 @@ int halo16_run(const srgan_conv_desc* d, int kind, const void* src, const void* 
                void* dst, int act, float slope, double flops, hipStream_t st, bool in16 = false, bool out16 = false);
 bool halo16t_applicable(const srgan_conv_desc* d);        // kind 1 of a 4x4 / stride-2 layer (transposed form)
 size_t halo16t_packed_bytes(const srgan_conv_desc* d);
-int halo16t_run(const srgan_conv_desc* d, const float* dy, const void* packed, float* dx, double flops, hipStream_t st);
+int halo16t_run(const srgan_conv_desc* d, const void* dy, const void* packed, void* dx, double flops, hipStream_t st,
+                bool in16 = false, bool out16 = false);
 bool halo16s_applicable(const srgan_conv_desc* d);        // kind 0 of a 4x4 / stride-2 layer (strided form, variant 6)
 size_t halo16s_packed_bytes(const srgan_conv_desc* d);
-int halo16s_run(const srgan_conv_desc* d, const float* x, const void* packed, const float* bias, float* y, int act, float slope,
-                double flops, hipStream_t st);
+int halo16s_run(const srgan_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, int act, float slope,
+                double flops, hipStream_t st, bool in16 = false, bool out16 = false);
 bool halo16_wgrad_applicable(const srgan_conv_desc* d);
 void halo16_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad);
 int halo16_wgrad_run(const srgan_conv_desc* d, const void* x, const void* dy, float* slab, double flops, hipStream_t st,

@@ -570,14 +570,15 @@ __global__ __launch_bounds__(512) void halo16s2_wgrad_kernel(Halo16S2WgradParams
 // channels (64 at BN = 128, 128 at BN = 64), i.e. 16 MFMAs per wave and tile as above; swizzle key of a row = its index
 // shifted so that the 16 rows of a ds_read_b128 lane group hit 16 different 16-byte columns.
 struct Halo16TParams {
-  const float* src;            // [NB][Hs][Ws][C]
+  const void* src;             // [NB][Hs][Ws][C] fp32, or bf16 (IN16)
   const unsigned short* wp;    // packed bf16 filters [phase][tap][chunk][BN][HK]
-  float* dst;                  // [NB][2 Hs][2 Ws][N]
+  void* dst;                   // [NB][2 Hs][2 Ws][N] fp32, or bf16 (OUT16)
   int NB, Hs, Ws, tiles_y, tiles_x;
 };
 
-template <int C, int BN>
+template <int C, int BN, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(256) void halo16t_kernel(Halo16TParams p) {
+  constexpr int ISZ = IN16 ? 2 : 4;            // bytes per source element
   constexpr int PS = C * 2 + 16;               // bytes per halo pixel
   constexpr int HKT = 8192 / BN;               // reduce channels per tile
   constexpr int NCH = C / HKT;                 // chunks per tap
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(256) void halo16t_kernel(Halo16TParams p) {
   const int nb = r0 / p.tiles_y;
   const int Y0 = ty * 4, X0 = tx * 32;
 
-  const auto rs_x = uniform_rsrc(p.src, (unsigned)((size_t)p.NB * p.Hs * p.Ws * C * 4));
+  const auto rs_x = uniform_rsrc(p.src, (unsigned)((size_t)p.NB * p.Hs * p.Ws * C * ISZ));
   const auto rs_w = uniform_rsrc(p.wp, (unsigned)(NK * WTILE));
 
   f32x4 wreg[4], wreg2[4];
@@ -639,18 +640,23 @@ __global__ __launch_bounds__(256) void halo16t_kernel(Halo16TParams p) {
         const int hr = hp / 34, hc = hp - hr * 34;
         const int y = Y0 - 1 + hr, x = X0 - 1 + hc;
         const bool ok = hp < HPX && y >= 0 && y < p.Hs && x >= 0 && x < p.Ws;
-        const unsigned off = ok ? (unsigned)((((nb * p.Hs + y) * p.Ws + x) * C + quarter * 64 + hcg * 8) * 4) : kOutside;
+        const unsigned off = ok ? (unsigned)((((nb * p.Hs + y) * p.Ws + x) * C + quarter * 64 + hcg * 8) * ISZ) : kOutside;
         lo[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
-        hi[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+        if constexpr (!IN16) hi[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+        else hi[g] = lo[g];
       }
 #pragma unroll
       for (int g = 0; g < 7; ++g) {
         const int hp = g * 32 + hpl;
         if (hp < HPX) {
-          const bf16x4 a = __builtin_convertvector(lo[g], bf16x4), b = __builtin_convertvector(hi[g], bf16x4);
-          bf16x8 v;
-          v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-          *reinterpret_cast<bf16x8*>(&halo[hp * PS + quarter * 128 + hcg * 16]) = v;
+          if constexpr (IN16) {
+            *reinterpret_cast<f32x4*>(&halo[hp * PS + quarter * 128 + hcg * 16]) = lo[g];
+          } else {
+            const bf16x4 a = __builtin_convertvector(lo[g], bf16x4), b = __builtin_convertvector(hi[g], bf16x4);
+            bf16x8 v;
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+            *reinterpret_cast<bf16x8*>(&halo[hp * PS + quarter * 128 + hcg * 16]) = v;
+          }
         }
       }
     }
@@ -705,7 +711,11 @@ __global__ __launch_bounds__(256) void halo16t_kernel(Halo16TParams p) {
       for (int j = 0; j < TN; ++j) {
         const int n = wn * (BN / 2) + j * 32 + lr;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) p.dst[row + (size_t)(2 * ((e & 3) + 8 * (e >> 2) + 4 * lh)) * BN + n] = acc[i][j][e];
+        for (int e = 0; e < 16; ++e) {
+          const size_t o = row + (size_t)(2 * ((e & 3) + 8 * (e >> 2) + 4 * lh)) * BN + n;
+          if constexpr (OUT16) static_cast<__bf16*>(p.dst)[o] = (__bf16)acc[i][j][e];
+          else static_cast<float*>(p.dst)[o] = acc[i][j][e];
+        }
       }
     }
   };
@@ -767,16 +777,19 @@ __global__ __launch_bounds__(256) void halo16t_kernel(Halo16TParams p) {
 // waves and a double-buffered 2 x 32 patch overlapped the phases but halved the work per fragment read and per barrier and came
 // out even (92 us); what would pay is bf16 activations in HBM (region straight into LDS, half the bytes).
 struct Halo16SParams {
-  const float* src;            // [NB][2 Ho][2 Wo][C]
+  const void* src;             // [NB][2 Ho][2 Wo][C] fp32, or bf16 (IN16)
   const unsigned short* wp;    // packed bf16 filters [64-channel half][tap][chunk][N][8192 / N]
   const float* bias;           // [N] or null
-  float* dst;                  // [NB][Ho][Wo][N]
+  void* dst;                   // [NB][Ho][Wo][N] fp32, or bf16 (OUT16)
   int NB, Ho, Wo, tiles_y, tiles_x, act;
   float slope;
 };
 
-template <int C, int BN>
+// IN16 / OUT16: the source / destination tensor is bf16 in HBM (round 4: the activations between the generator's down / up
+// convolutions and their norms, ops.py): the region then needs one 16-byte load per 8 channels and no conversion.
+template <int C, int BN, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(256) void halo16s_kernel(Halo16SParams p) {
+  constexpr int ISZ = IN16 ? 2 : 4;            // bytes per source element
   constexpr int PS = 64 * 2 + 16;              // bytes per region pixel (the resident 64-channel half)
   constexpr int NH = C / 64;                   // halves
   constexpr int HKT = 8192 / BN;               // reduce channels per filter tile
@@ -808,7 +821,7 @@ __global__ __launch_bounds__(256) void halo16s_kernel(Halo16SParams p) {
   const int Hi = 2 * p.Ho, Wi = 2 * p.Wo;
   const int Y0 = 8 * ty - 1, X0 = 64 * tx - 1;          // region origin in x
 
-  const auto rs_x = uniform_rsrc(p.src, (unsigned)((size_t)p.NB * Hi * Wi * C * 4));
+  const auto rs_x = uniform_rsrc(p.src, (unsigned)((size_t)p.NB * Hi * Wi * C * ISZ));
   const auto rs_w = uniform_rsrc(p.wp, (unsigned)(NK * WTILE));
 
   f32x4 wreg[4], wreg2[4];
@@ -841,19 +854,25 @@ __global__ __launch_bounds__(256) void halo16s_kernel(Halo16SParams p) {
         const int hr = hp / 66, hc = hp - hr * 66;
         const int y = Y0 + hr, x = X0 + hc;
         const bool ok = hp < RPX && y >= 0 && y < Hi && x >= 0 && x < Wi;
-        const unsigned off = ok ? (unsigned)((((nb * Hi + y) * Wi + x) * C + half * 64 + hcg * 8) * 4) : kOutside;
+        const unsigned off = ok ? (unsigned)((((nb * Hi + y) * Wi + x) * C + half * 64 + hcg * 8) * ISZ) : kOutside;
         lo[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
-        hi[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+        if constexpr (!IN16) hi[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+        else hi[g] = lo[g];
       }
 #pragma unroll
       for (int g = 0; g < 7; ++g) {
         const int hp = (b * 7 + g) * 32 + hpl;
         if (hp < RPX) {
           const int hr = hp / 66, hc = hp - hr * 66;
-          const bf16x4 a = __builtin_convertvector(lo[g], bf16x4), c = __builtin_convertvector(hi[g], bf16x4);
-          bf16x8 v;
-          v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = c[0]; v[5] = c[1]; v[6] = c[2]; v[7] = c[3];
-          *reinterpret_cast<bf16x8*>(&halo[((hr * 2 + (hc & 1)) * 33 + (hc >> 1)) * PS + hcg * 16]) = v;
+          unsigned char* dst = &halo[((hr * 2 + (hc & 1)) * 33 + (hc >> 1)) * PS + hcg * 16];
+          if constexpr (IN16) {                  // lo already holds the 8 bf16 channels
+            *reinterpret_cast<f32x4*>(dst) = lo[g];
+          } else {
+            const bf16x4 a = __builtin_convertvector(lo[g], bf16x4), c = __builtin_convertvector(hi[g], bf16x4);
+            bf16x8 v;
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = c[0]; v[5] = c[1]; v[6] = c[2]; v[7] = c[3];
+            *reinterpret_cast<bf16x8*>(dst) = v;
+          }
         }
       }
     }
@@ -952,8 +971,12 @@ __global__ __launch_bounds__(256) void halo16s_kernel(Halo16SParams p) {
       const int n = wn * (BN / 2) + j * 32 + lr;
       const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        p.dst[row + (size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * BN + n] = apply_act(acc[i][j][e] + bv, p.act, p.slope);
+      for (int e = 0; e < 16; ++e) {
+        const float v = apply_act(acc[i][j][e] + bv, p.act, p.slope);
+        const size_t o = row + (size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * BN + n;
+        if constexpr (OUT16) static_cast<__bf16*>(p.dst)[o] = (__bf16)v;
+        else static_cast<float*>(p.dst)[o] = v;
+      }
     }
   }
 }
@@ -1019,7 +1042,8 @@ bool halo16t_applicable(const srgan_conv_desc* d) {
 
 size_t halo16t_packed_bytes(const srgan_conv_desc* d) { return (size_t)16 * d->I * d->O * 2; }
 
-int halo16t_run(const srgan_conv_desc* d, const float* dy, const void* packed, float* dx, double flops, hipStream_t st) {
+int halo16t_run(const srgan_conv_desc* d, const void* dy, const void* packed, void* dx, double flops, hipStream_t st, bool in16,
+                bool out16) {
   SRGAN_REQUIRE(halo16t_applicable(d), "halo16t: layer not applicable");
   Halo16TParams p{};
   p.src = dy; p.wp = reinterpret_cast<const unsigned short*>(packed); p.dst = dx;
@@ -1027,8 +1051,16 @@ int halo16t_run(const srgan_conv_desc* d, const float* dy, const void* packed, f
   const long long grid = (long long)p.NB * p.tiles_y * p.tiles_x;
   SRGAN_REQUIRE(grid > 0 && grid < (1LL << 31), "halo16t: grid");
   ProfToken tok = prof_begin(27, flops, st);
-  if (d->O == 256) hipLaunchKernelGGL((halo16t_kernel<256, 128>), dim3((unsigned)grid), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((halo16t_kernel<128, 64>), dim3((unsigned)grid), dim3(256), 0, st, p);
+#define SRGAN_H16T(C_, N_)                                                                                            \
+  do {                                                                                                                \
+    if (in16 && out16) hipLaunchKernelGGL((halo16t_kernel<C_, N_, true, true>), dim3((unsigned)grid), dim3(256), 0, st, p);        \
+    else if (in16) hipLaunchKernelGGL((halo16t_kernel<C_, N_, true, false>), dim3((unsigned)grid), dim3(256), 0, st, p);          \
+    else if (out16) hipLaunchKernelGGL((halo16t_kernel<C_, N_, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p);         \
+    else hipLaunchKernelGGL((halo16t_kernel<C_, N_, false, false>), dim3((unsigned)grid), dim3(256), 0, st, p);                   \
+  } while (0)
+  if (d->O == 256) SRGAN_H16T(256, 128);
+  else SRGAN_H16T(128, 64);
+#undef SRGAN_H16T
   prof_end(tok, st);
   return check_launch("halo16t_kernel");
 }
@@ -1044,8 +1076,8 @@ bool halo16s_applicable(const srgan_conv_desc* d) {
 
 size_t halo16s_packed_bytes(const srgan_conv_desc* d) { return (size_t)16 * d->I * d->O * 2; }
 
-int halo16s_run(const srgan_conv_desc* d, const float* x, const void* packed, const float* bias, float* y, int act, float slope,
-                double flops, hipStream_t st) {
+int halo16s_run(const srgan_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, int act, float slope,
+                double flops, hipStream_t st, bool in16, bool out16) {
   SRGAN_REQUIRE(halo16s_applicable(d), "halo16s: layer not applicable");
   Halo16SParams p{};
   p.src = x; p.wp = reinterpret_cast<const unsigned short*>(packed); p.bias = bias; p.dst = y;
@@ -1053,8 +1085,16 @@ int halo16s_run(const srgan_conv_desc* d, const float* x, const void* packed, co
   const long long grid = (long long)p.NB * p.tiles_y * p.tiles_x;
   SRGAN_REQUIRE(grid > 0 && grid < (1LL << 31), "halo16s: grid");
   ProfToken tok = prof_begin(29, flops, st);
-  if (d->I == 64) hipLaunchKernelGGL((halo16s_kernel<64, 128>), dim3((unsigned)grid), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((halo16s_kernel<128, 256>), dim3((unsigned)grid), dim3(256), 0, st, p);
+#define SRGAN_H16S(C_, N_)                                                                                            \
+  do {                                                                                                                \
+    if (in16 && out16) hipLaunchKernelGGL((halo16s_kernel<C_, N_, true, true>), dim3((unsigned)grid), dim3(256), 0, st, p);        \
+    else if (in16) hipLaunchKernelGGL((halo16s_kernel<C_, N_, true, false>), dim3((unsigned)grid), dim3(256), 0, st, p);          \
+    else if (out16) hipLaunchKernelGGL((halo16s_kernel<C_, N_, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p);         \
+    else hipLaunchKernelGGL((halo16s_kernel<C_, N_, false, false>), dim3((unsigned)grid), dim3(256), 0, st, p);                   \
+  } while (0)
+  if (d->I == 64) SRGAN_H16S(64, 128);
+  else SRGAN_H16S(128, 256);
+#undef SRGAN_H16S
   prof_end(tok, st);
   return check_launch("halo16s_kernel");
 }
@@ -1113,15 +1153,22 @@ int halo16_wgrad_run(const srgan_conv_desc* d, const void* x, const void* dy, fl
                      bool d16) {
   SRGAN_REQUIRE(halo16_wgrad_applicable(d), "halo16 wgrad: layer not applicable");
   if (halo16s2_wgrad_ok(d)) {
-    SRGAN_REQUIRE(!x16 && !d16, "halo16 stride-2 wgrad: fp32 tensors only");
+    SRGAN_REQUIRE(x16 || !d16, "halo16 stride-2 wgrad: bf16 dy with fp32 x is not instantiated");
     Halo16S2WgradParams q{};
     halo16s2_wgrad_plan(d, &q);
     q.x = x; q.dy = dy; q.slab = slab;
     ProfToken tok = prof_begin(26, flops, st);
     const dim3 grid((unsigned)(q.o_tiles * q.c_tiles * q.splits));
-    if (d->Wo % 32 == 0) hipLaunchKernelGGL((halo16s2_wgrad_kernel<32, false, false>), grid, dim3(512), 0, st, q);
-    else if (d->Wo == 16) hipLaunchKernelGGL((halo16s2_wgrad_kernel<16, false, false>), grid, dim3(512), 0, st, q);
-    else hipLaunchKernelGGL((halo16s2_wgrad_kernel<8, false, false>), grid, dim3(512), 0, st, q);
+#define SRGAN_S2W(PW_)                                                                                             \
+  do {                                                                                                                \
+    if (x16 && d16) hipLaunchKernelGGL((halo16s2_wgrad_kernel<PW_, true, true>), grid, dim3(512), 0, st, q);          \
+    else if (x16) hipLaunchKernelGGL((halo16s2_wgrad_kernel<PW_, true, false>), grid, dim3(512), 0, st, q);           \
+    else hipLaunchKernelGGL((halo16s2_wgrad_kernel<PW_, false, false>), grid, dim3(512), 0, st, q);                  \
+  } while (0)
+    if (d->Wo % 32 == 0) SRGAN_S2W(32);
+    else if (d->Wo == 16) SRGAN_S2W(16);
+    else SRGAN_S2W(8);
+#undef SRGAN_S2W
     prof_end(tok, st);
     return check_launch("halo16s2_wgrad_kernel");
   }

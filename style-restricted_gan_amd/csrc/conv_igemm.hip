@@ -2022,12 +2022,26 @@ extern "C" int srgan_halo16_applicable(const srgan_conv_desc* d) {
   return compute_bf16() && halo16_applicable(d, 0) && halo16_wgrad_applicable(d) && wino_applicable(d, 0) && wino_applicable(d, 1) ? 1 : 0;
 }
 
+// 4x4 / stride-2 / pad-1 layers whose forward (halo16s_kernel), input gradient (halo16t_kernel) and weight gradient
+// (halo16s2_wgrad_kernel) all run on the LDS-resident-patch kernels in the bf16 mode: these take and write bf16 tensors
+// (srgan_halo16_conv / srgan_halo16_wgrad with the *_bf16 flags) -- the generator's down / up convolutions.
+extern "C" int srgan_halo16s2_applicable(const srgan_conv_desc* d) {
+  if (validate(d) != 0) return 0;
+  return compute_bf16() && halo16s_applicable(d) && halo16t_applicable(d) && halo16_wgrad_applicable(d) && wino_applicable(d, 0) &&
+         wino_applicable(d, 1) ? 1 : 0;
+}
+
 extern "C" int srgan_halo16_conv(const srgan_conv_desc* d, int kind, const void* src, int src_bf16, const void* packed,
                                  const float* res, void* dst, int dst_bf16, void* stream) {
   if (int e = validate(d)) return e;
   SRGAN_REQUIRE(src && packed && dst, "halo16_conv: null pointer");
   SRGAN_REQUIRE(kind == 0 || kind == 1, "halo16_conv: kind must be 0 (forward) or 1 (input gradient)");
-  SRGAN_REQUIRE(srgan_halo16_applicable(d), "halo16_conv: layer / compute mode not applicable (srgan_halo16_applicable)");
+  if (srgan_halo16s2_applicable(d)) {
+    SRGAN_REQUIRE(!res, "halo16_conv: no skip tensor on the stride-2 layers");
+    if (kind == 0) return halo16s_run(d, src, packed, nullptr, dst, SRGAN_ACT_NONE, 0.f, conv_flops(d), as_stream(stream), src_bf16 != 0, dst_bf16 != 0);
+    return halo16t_run(d, src, packed, dst, conv_flops(d), as_stream(stream), src_bf16 != 0, dst_bf16 != 0);
+  }
+  SRGAN_REQUIRE(srgan_halo16_applicable(d), "halo16_conv: layer / compute mode not applicable (srgan_halo16_applicable / srgan_halo16s2_applicable)");
   return halo16_run(d, kind, src, packed, nullptr, res, dst, SRGAN_ACT_NONE, 0.f, conv_flops(d), as_stream(stream), src_bf16 != 0,
                     dst_bf16 != 0);
 }
@@ -2036,7 +2050,8 @@ extern "C" int srgan_halo16_wgrad(const srgan_conv_desc* d, const void* x, int x
                                   void* ws, size_t ws_bytes, void* stream) {
   if (int e = validate(d)) return e;
   SRGAN_REQUIRE(x && dy && dw && ws, "halo16_wgrad: null pointer");
-  SRGAN_REQUIRE(srgan_halo16_applicable(d), "halo16_wgrad: layer / compute mode not applicable (srgan_halo16_applicable)");
+  SRGAN_REQUIRE(srgan_halo16_applicable(d) || srgan_halo16s2_applicable(d),
+                "halo16_wgrad: layer / compute mode not applicable (srgan_halo16_applicable / srgan_halo16s2_applicable)");
   SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "halo16_wgrad: workspace too small (srgan_conv2d_workspace)");
   hipStream_t st = as_stream(stream);
   if (int e = defer_take(d, &ws, &ws_bytes, st)) return e;

@@ -15,6 +15,19 @@ namespace srgan {
 constexpr int NORM_CH = 32;    // channels per block
 constexpr int NORM_ROWS = 8;   // row groups per block (256 threads)
 
+// 4 consecutive channels of an fp32 or bf16 tensor <-> f32x4 (bf16 tensors: the activations the bf16 mode keeps in 16 bits, ops.py)
+template <bool B16>
+__device__ __forceinline__ f32x4 ld4(const void* base, size_t idx) {
+  if constexpr (B16) return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(base) + idx), f32x4);
+  else return *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + idx);
+}
+template <bool B16>
+__device__ __forceinline__ void st4(void* base, size_t idx, f32x4 v) {
+  if constexpr (B16) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(base) + idx) = __builtin_convertvector(v, bf16x4);
+  else *reinterpret_cast<f32x4*>(static_cast<float*>(base) + idx) = v;
+}
+
+
 // partial[(n*S + s)*C + c] = {sum(x - x0), sum((x - x0)^2)} over the split's rows, x0 = x[n][0][c]
 __global__ __launch_bounds__(256) void in_stats_partial(const float* __restrict__ x, float2* __restrict__ part,
                                                         int HW, int C, int S, int rows_per_split) {
@@ -44,7 +57,8 @@ __global__ __launch_bounds__(256) void in_stats_partial(const float* __restrict_
 }
 
 // float4 variants (C % 4 == 0): 8 lanes cover the block's 32 channels, 32 row lanes stride over the rows
-__global__ __launch_bounds__(256) void in_stats_partial_v4(const float* __restrict__ x, float2* __restrict__ part,
+template <bool X16 = false>
+__global__ __launch_bounds__(256) void in_stats_partial_v4(const void* __restrict__ x, float2* __restrict__ part,
                                                            int HW, int C, int S, int rows_per_split) {
   const int q = threadIdx.x & 7, ty = threadIdx.x >> 3;
   const int c = blockIdx.x * NORM_CH + q * 4;
@@ -52,17 +66,17 @@ __global__ __launch_bounds__(256) void in_stats_partial_v4(const float* __restri
   __shared__ f32x4 sh[2][32][8];
   f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
   if (c < C) {
-    const float* xp = x + (size_t)n * HW * C + c;
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp);
+    const size_t xb = (size_t)n * HW * C + c;
+    const f32x4 x0 = ld4<X16>(x, xb);
     const int r0 = s * rows_per_split, r1 = min(HW, r0 + rows_per_split);
     int r = r0 + ty;
     // four rows in flight per thread (round 4): with one dependent load per iteration a CU had ~32 KB outstanding and the pass ran
     // at 4.2 TB/s; the sums keep the row order r, r + 32, ... (same values as the plain loop)
     for (; r + 96 < r1; r += 128) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(xp + (size_t)r * C);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(xp + (size_t)(r + 32) * C);
-      const f32x4 v2 = *reinterpret_cast<const f32x4*>(xp + (size_t)(r + 64) * C);
-      const f32x4 v3 = *reinterpret_cast<const f32x4*>(xp + (size_t)(r + 96) * C);
+      const f32x4 v0 = ld4<X16>(x, xb + (size_t)r * C);
+      const f32x4 v1 = ld4<X16>(x, xb + (size_t)(r + 32) * C);
+      const f32x4 v2 = ld4<X16>(x, xb + (size_t)(r + 64) * C);
+      const f32x4 v3 = ld4<X16>(x, xb + (size_t)(r + 96) * C);
       const f32x4 w0 = v0 - x0, w1 = v1 - x0, w2 = v2 - x0, w3 = v3 - x0;
       a += w0; b += w0 * w0;
       a += w1; b += w1 * w1;
@@ -70,7 +84,7 @@ __global__ __launch_bounds__(256) void in_stats_partial_v4(const float* __restri
       a += w3; b += w3 * w3;
     }
     for (; r < r1; r += 32) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (size_t)r * C) - x0;
+      const f32x4 v = ld4<X16>(x, xb + (size_t)r * C) - x0;
       a += v;
       b += v * v;
     }
@@ -88,7 +102,8 @@ __global__ __launch_bounds__(256) void in_stats_partial_v4(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void in_bwd_partial_v4(const float* __restrict__ x, const float* __restrict__ dy,
+template <bool X16 = false, bool G16 = false>
+__global__ __launch_bounds__(256) void in_bwd_partial_v4(const void* __restrict__ x, const void* __restrict__ dy,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          float2* __restrict__ part, int HW, int C, int S, int rows_per_split,
@@ -119,15 +134,15 @@ __global__ __launch_bounds__(256) void in_bwd_partial_v4(const float* __restrict
     int r = r0 + ty;
     for (; r + 96 < r1; r += 128) {      // four rows of both tensors in flight (see in_stats_partial_v4); row order kept
       const size_t o = base + (size_t)r * C;
-      const f32x4 x0v = *reinterpret_cast<const f32x4*>(x + o), g0 = *reinterpret_cast<const f32x4*>(dy + o);
-      const f32x4 x1v = *reinterpret_cast<const f32x4*>(x + o + (size_t)32 * C), g1 = *reinterpret_cast<const f32x4*>(dy + o + (size_t)32 * C);
-      const f32x4 x2v = *reinterpret_cast<const f32x4*>(x + o + (size_t)64 * C), g2 = *reinterpret_cast<const f32x4*>(dy + o + (size_t)64 * C);
-      const f32x4 x3v = *reinterpret_cast<const f32x4*>(x + o + (size_t)96 * C), g3 = *reinterpret_cast<const f32x4*>(dy + o + (size_t)96 * C);
+      const f32x4 x0v = ld4<X16>(x, o), g0 = ld4<G16>(dy, o);
+      const f32x4 x1v = ld4<X16>(x, o + (size_t)32 * C), g1 = ld4<G16>(dy, o + (size_t)32 * C);
+      const f32x4 x2v = ld4<X16>(x, o + (size_t)64 * C), g2 = ld4<G16>(dy, o + (size_t)64 * C);
+      const f32x4 x3v = ld4<X16>(x, o + (size_t)96 * C), g3 = ld4<G16>(dy, o + (size_t)96 * C);
       term(x0v, g0); term(x1v, g1); term(x2v, g2); term(x3v, g3);
     }
     for (; r < r1; r += 32) {
       const size_t o = base + (size_t)r * C;
-      term(*reinterpret_cast<const f32x4*>(x + o), *reinterpret_cast<const f32x4*>(dy + o));
+      term(ld4<X16>(x, o), ld4<G16>(dy, o));
     }
   }
   sh[0][ty][q] = a;
@@ -218,10 +233,11 @@ __global__ void in_apply(const float* __restrict__ x, const float* __restrict__ 
 // `part` != null (round 3): the statistics arrive as the S partial pairs of in_stats_partial and every thread finishes its own
 // four channels (a few KB from L2) -- the 5.6 us in_stats_final launch between the two passes is gone; workgroup x = 0 of an
 // image stores mean / rstd for the backward pass.
-__global__ __launch_bounds__(256) void in_apply_pow2(const float* __restrict__ x, const float* __restrict__ scale,
+template <bool X16 = false, bool Y16 = false>
+__global__ __launch_bounds__(256) void in_apply_pow2(const void* __restrict__ x, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, const float* __restrict__ res,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
-                                                     float* __restrict__ y, int HWC4, int C, int act, float slope,
+                                                     void* __restrict__ y, int HWC4, int C, int act, float slope,
                                                      const float2* __restrict__ part, int S, int HW, float eps) {
   const int n = blockIdx.y;
   const int c = (threadIdx.x * 4) % C;
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(256) void in_apply_pow2(const float* __restrict__ x
   if (part) {
     f32x4 a, b;
     sum_partials4(part, n, S, C, c, &a, &b);
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + (size_t)n * HWC4 * 4 + c);
+    const f32x4 x0 = ld4<X16>(x, (size_t)n * HWC4 * 4 + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float m1, r1;
@@ -252,9 +268,9 @@ __global__ __launch_bounds__(256) void in_apply_pow2(const float* __restrict__ x
     sf = *reinterpret_cast<const f32x4*>(shift + nc);
   }
   const size_t base = (size_t)n * HWC4;
-  const f32x4* xp = reinterpret_cast<const f32x4*>(x) + base;
   const f32x4* rp = res ? reinterpret_cast<const f32x4*>(res) + base : nullptr;
-  f32x4* yp = reinterpret_cast<f32x4*>(y) + base;
+  auto xat = [&](int j) __attribute__((always_inline)) { return ld4<X16>(x, (base + j) * 4); };
+  auto yput = [&](int j, f32x4 v) __attribute__((always_inline)) { st4<Y16>(y, (base + j) * 4, v); };
   auto one = [&](f32x4 xv, f32x4 rv) __attribute__((always_inline)) {
     f32x4 v = ((xv - mu) * rs) * sc + sf;         // same expression as the backward's mask recomputation
 #pragma unroll
@@ -265,22 +281,23 @@ __global__ __launch_bounds__(256) void in_apply_pow2(const float* __restrict__ x
   int j = blockIdx.x * 256 + threadIdx.x;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   for (; j + 3 * step < HWC4; j += 4 * step) {     // four float4 of each tensor in flight per thread (round 4)
-    const f32x4 x0v = xp[j], x1v = xp[j + step], x2v = xp[j + 2 * step], x3v = xp[j + 3 * step];
+    const f32x4 x0v = xat(j), x1v = xat(j + step), x2v = xat(j + 2 * step), x3v = xat(j + 3 * step);
     f32x4 r0 = zero, r1 = zero, r2 = zero, r3 = zero;
     if (rp) { r0 = rp[j]; r1 = rp[j + step]; r2 = rp[j + 2 * step]; r3 = rp[j + 3 * step]; }
-    yp[j] = one(x0v, r0);
-    yp[j + step] = one(x1v, r1);
-    yp[j + 2 * step] = one(x2v, r2);
-    yp[j + 3 * step] = one(x3v, r3);
+    yput(j, one(x0v, r0));
+    yput(j + step, one(x1v, r1));
+    yput(j + 2 * step, one(x2v, r2));
+    yput(j + 3 * step, one(x3v, r3));
   }
-  for (; j < HWC4; j += step) yp[j] = one(xp[j], rp ? rp[j] : zero);
+  for (; j < HWC4; j += step) yput(j, one(xat(j), rp ? rp[j] : zero));
 }
 
-__global__ __launch_bounds__(256) void in_bwd_apply_pow2(const float* __restrict__ x, const float* __restrict__ dy,
+template <bool X16 = false, bool G16 = false, bool D16 = false>
+__global__ __launch_bounds__(256) void in_bwd_apply_pow2(const void* __restrict__ x, const void* __restrict__ dy,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          float* __restrict__ dshift, float* __restrict__ dscale,
-                                                         float* __restrict__ dx, int HWC4, int C, float inv_hw, int act,
+                                                         void* __restrict__ dx, int HWC4, int C, float inv_hw, int act,
                                                          float slope, const float2* __restrict__ part, int S) {
   const int n = blockIdx.y;
   const int c = (threadIdx.x * 4) % C;
@@ -307,9 +324,9 @@ __global__ __launch_bounds__(256) void in_bwd_apply_pow2(const float* __restrict
   const f32x4 mgx = dsc * inv_hw;
   const f32x4 k = rs * sc;
   const size_t base = (size_t)n * HWC4;
-  const f32x4* xp = reinterpret_cast<const f32x4*>(x) + base;
-  const f32x4* gp = reinterpret_cast<const f32x4*>(dy) + base;
-  f32x4* op = reinterpret_cast<f32x4*>(dx) + base;
+  auto xat = [&](int j) __attribute__((always_inline)) { return ld4<X16>(x, (base + j) * 4); };
+  auto gat = [&](int j) __attribute__((always_inline)) { return ld4<G16>(dy, (base + j) * 4); };
+  auto oput = [&](int j, f32x4 v) __attribute__((always_inline)) { st4<D16>(dx, (base + j) * 4, v); };
   auto one = [&](f32x4 xv, f32x4 g) __attribute__((always_inline)) {
     const f32x4 xh = (xv - mu) * rs;
     const f32x4 z = xh * sc + sf;
@@ -320,14 +337,14 @@ __global__ __launch_bounds__(256) void in_bwd_apply_pow2(const float* __restrict
   const int step = gridDim.x * 256;
   int j = blockIdx.x * 256 + threadIdx.x;
   for (; j + 3 * step < HWC4; j += 4 * step) {     // four float4 of both tensors in flight per thread (round 4)
-    const f32x4 x0v = xp[j], x1v = xp[j + step], x2v = xp[j + 2 * step], x3v = xp[j + 3 * step];
-    const f32x4 g0 = gp[j], g1 = gp[j + step], g2 = gp[j + 2 * step], g3 = gp[j + 3 * step];
-    op[j] = one(x0v, g0);
-    op[j + step] = one(x1v, g1);
-    op[j + 2 * step] = one(x2v, g2);
-    op[j + 3 * step] = one(x3v, g3);
+    const f32x4 x0v = xat(j), x1v = xat(j + step), x2v = xat(j + 2 * step), x3v = xat(j + 3 * step);
+    const f32x4 g0 = gat(j), g1 = gat(j + step), g2 = gat(j + 2 * step), g3 = gat(j + 3 * step);
+    oput(j, one(x0v, g0));
+    oput(j + step, one(x1v, g1));
+    oput(j + 2 * step, one(x2v, g2));
+    oput(j + 3 * step, one(x3v, g3));
   }
-  for (; j < HWC4; j += step) op[j] = one(xp[j], gp[j]);
+  for (; j < HWC4; j += step) oput(j, one(xat(j), gat(j)));
 }
 
 // backward partial: {sum g, sum g*xh}, g = dy * act'(xh*scale+shift)
@@ -624,18 +641,6 @@ __device__ __forceinline__ void slab_coords(int nslab, int N, int remap, int& sl
   }
 }
 
-// 4 consecutive channels of an fp32 or bf16 tensor <-> f32x4 (bf16 tensors: the intermediates of ops._ResBlockBf16Fn)
-template <bool B16>
-__device__ __forceinline__ f32x4 ld4(const void* base, size_t idx) {
-  if constexpr (B16) return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(base) + idx), f32x4);
-  else return *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + idx);
-}
-template <bool B16>
-__device__ __forceinline__ void st4(void* base, size_t idx, f32x4 v) {
-  if constexpr (B16) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(base) + idx) = __builtin_convertvector(v, bf16x4);
-  else *reinterpret_cast<f32x4*>(static_cast<float*>(base) + idx) = v;
-}
-
 // forward: 512 threads over HW x 32 channels (8 lanes per pixel: whole 128-byte lines; 16-channel slabs with 256 threads were
 // measured slower here, 45.6 vs 34.7 us on the 32x32x256 trunk, while they help the backward below)
 template <int R, bool X16 = false, bool Y16 = false>
@@ -812,7 +817,7 @@ extern "C" int srgan_instnorm_fwd(const float* x, const float* scale, const floa
   dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
   {
     ProfToken tok = prof_begin(30, tbytes, st);
-    if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4, g, dim3(256), 0, st, x, part, HW, C, S, rps);
+    if ((C & 3) == 0) hipLaunchKernelGGL(in_stats_partial_v4<false>, g, dim3(256), 0, st, (const void*)x, part, HW, C, S, rps);
     else hipLaunchKernelGGL(in_stats_partial, g, dim3(256), 0, st, x, part, HW, C, S, rps);
     prof_end(tok, st);
   }
@@ -824,7 +829,7 @@ extern "C" int srgan_instnorm_fwd(const float* x, const float* scale, const floa
     const int hwc4 = HW * C / 4;
     dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
     ProfToken tok = prof_begin(31, (res ? 3.0 : 2.0) * tbytes, st);
-    hipLaunchKernelGGL(in_apply_pow2, g2, dim3(256), 0, st, x, scale, shift, res, mean, rstd, y, hwc4, C, act, slope,
+    hipLaunchKernelGGL((in_apply_pow2<false, false>), g2, dim3(256), 0, st, (const void*)x, scale, shift, res, mean, rstd, (void*)y, hwc4, C, act, slope,
                        (const float2*)part, S, HW, eps);
     prof_end(tok, st);
     return check_launch("instnorm_fwd");
@@ -833,7 +838,7 @@ extern "C" int srgan_instnorm_fwd(const float* x, const float* scale, const floa
   if (pow2_fast(C, HW)) {
     const int hwc4 = HW * C / 4;
     dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
-    hipLaunchKernelGGL(in_apply_pow2, g2, dim3(256), 0, st, x, scale, shift, res, mean, rstd, y, hwc4, C, act, slope,
+    hipLaunchKernelGGL((in_apply_pow2<false, false>), g2, dim3(256), 0, st, (const void*)x, scale, shift, res, mean, rstd, (void*)y, hwc4, C, act, slope,
                        (const float2*)nullptr, 0, HW, eps);
   } else if ((C & 3) == 0) {
     unsigned blocks = (unsigned)std::min<long long>(ceil_div(total / 4, 256), 8192);
@@ -873,7 +878,7 @@ extern "C" int srgan_instnorm_bwd(const float* x, const float* dy, const float* 
   dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
   {
     ProfToken tok = prof_begin(32, 2.0 * tbytes, st);
-    if ((C & 3) == 0) hipLaunchKernelGGL(in_bwd_partial_v4, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
+    if ((C & 3) == 0) hipLaunchKernelGGL((in_bwd_partial_v4<false, false>), g, dim3(256), 0, st, (const void*)x, (const void*)dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
     else hipLaunchKernelGGL(in_bwd_partial, g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope);
     prof_end(tok, st);
   }
@@ -883,7 +888,7 @@ extern "C" int srgan_instnorm_bwd(const float* x, const float* dy, const float* 
     const int hwc4 = HW * C / 4;
     dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
     ProfToken tok = prof_begin(33, 3.0 * tbytes, st);
-    hipLaunchKernelGGL(in_bwd_apply_pow2, g2, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, hwc4, C, inv_hw, act,
+    hipLaunchKernelGGL((in_bwd_apply_pow2<false, false, false>), g2, dim3(256), 0, st, (const void*)x, (const void*)dy, scale, shift, mean, rstd, dshift, dscale, (void*)dx, hwc4, C, inv_hw, act,
                        slope, (const float2*)part, S);
     prof_end(tok, st);
     return check_launch("instnorm_bwd");
@@ -936,24 +941,109 @@ extern "C" int srgan_instnorm_slab_bwd_io(const void* x, int x_bf16, const void*
   SRGAN_REQUIRE(x && dy && mean && rstd && dx && dscale && dshift, "instnorm_slab_bwd_io: null pointer");
   SRGAN_REQUIRE((scale == nullptr) == (shift == nullptr), "instnorm_slab_bwd_io: scale and shift go together");
   SRGAN_REQUIRE(slab_fast(N, HW, C), "instnorm_slab_bwd_io: shape not served by the slab kernels (srgan_instnorm_slab_applicable)");
-  SRGAN_REQUIRE(x_bf16 && dx_bf16, "instnorm_slab_bwd_io: instantiated for a bf16 conv output and a bf16 result (dy fp32 or bf16)");
+  SRGAN_REQUIRE((x_bf16 != 0) == (dx_bf16 != 0), "instnorm_slab_bwd_io: the input gradient has the input's type");
   hipStream_t st = as_stream(stream);
   const dim3 gs((unsigned)(C / 16), (unsigned)N);
   const int rows = (HW + 63) / 64;
-#define SRGAN_BWD_IO(R, G) hipLaunchKernelGGL((in_bwd_slab<R, true, G, true>), gs, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dx, dscale, dshift, HW, C, act, slope, slab_remap())
-#define SRGAN_BWD_IO_R(G)                  \
-  do {                                     \
-    if (rows <= 1) SRGAN_BWD_IO(1, G);     \
-    else if (rows <= 2) SRGAN_BWD_IO(2, G);\
-    else if (rows <= 4) SRGAN_BWD_IO(4, G);\
-    else if (rows <= 8) SRGAN_BWD_IO(8, G);\
-    else SRGAN_BWD_IO(16, G);              \
+#define SRGAN_BWD_IO(R, X, G) hipLaunchKernelGGL((in_bwd_slab<R, X, G, X>), gs, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dx, dscale, dshift, HW, C, act, slope, slab_remap())
+#define SRGAN_BWD_IO_R(X, G)                  \
+  do {                                        \
+    if (rows <= 1) SRGAN_BWD_IO(1, X, G);     \
+    else if (rows <= 2) SRGAN_BWD_IO(2, X, G);\
+    else if (rows <= 4) SRGAN_BWD_IO(4, X, G);\
+    else if (rows <= 8) SRGAN_BWD_IO(8, X, G);\
+    else SRGAN_BWD_IO(16, X, G);              \
   } while (0)
-  if (dy_bf16) SRGAN_BWD_IO_R(true);
-  else SRGAN_BWD_IO_R(false);
+  if (x_bf16 && dy_bf16) SRGAN_BWD_IO_R(true, true);
+  else if (x_bf16) SRGAN_BWD_IO_R(true, false);
+  else if (dy_bf16) SRGAN_BWD_IO_R(false, true);
+  else SRGAN_BWD_IO_R(false, false);
 #undef SRGAN_BWD_IO_R
 #undef SRGAN_BWD_IO
   return check_launch("instnorm_slab_bwd_io");
+}
+
+// ---- instance norm with 16-bit tensors on either side (round 4: bf16 activation storage outside the residual trunk) ----
+// Served shapes: the slab kernels' (maps of <= 1024 pixels) and the fast two-pass kernels' (C | 1024, C % 4 == 0); statistics,
+// scale / shift and the parameter-gradient sums stay fp32.  Reference: pyfiles/model.py:54-67, 178 (as srgan_instnorm_fwd / _bwd).
+extern "C" int srgan_instnorm_io_applicable(int N, int HW, int C) {
+  return (N > 0 && HW > 0 && C > 0 && (slab_fast(N, HW, C) || ((C & 3) == 0 && pow2_fast(C, HW)))) ? 1 : 0;
+}
+
+extern "C" int srgan_instnorm_fwd_io(const void* x, int x_bf16, const float* scale, const float* shift, void* y, int y_bf16,
+                                     float* mean, float* rstd, int N, int HW, int C, float eps, int act, float slope, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  SRGAN_REQUIRE(x && y && mean && rstd, "instnorm_fwd_io: null pointer");
+  SRGAN_REQUIRE(srgan_instnorm_io_applicable(N, HW, C), "instnorm_fwd_io: shape not served (srgan_instnorm_io_applicable)");
+  SRGAN_REQUIRE(x != y, "instnorm_fwd_io: in-place calls are not supported");
+  if (slab_fast(N, HW, C)) return srgan_instnorm_slab_fwd_io(x, x_bf16, scale, shift, nullptr, y, y_bf16, mean, rstd, N, HW, C, eps, act, slope, stream);
+  SRGAN_REQUIRE((scale == nullptr) == (shift == nullptr), "instnorm_fwd_io: scale and shift go together");
+  hipStream_t st = as_stream(stream);
+  int S, rps;
+  plan_split(N, HW, C, S, rps);
+  SRGAN_REQUIRE(ws && ws_bytes >= (size_t)N * S * C * sizeof(float2), "instnorm_fwd_io: workspace too small (srgan_instnorm_workspace)");
+  const double ebytes = (double)N * HW * C;
+  float2* part = reinterpret_cast<float2*>(ws);
+  dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
+  {
+    ProfToken tok = prof_begin(30, ebytes * (x_bf16 ? 2 : 4), st);
+    if (x_bf16) hipLaunchKernelGGL(in_stats_partial_v4<true>, g, dim3(256), 0, st, x, part, HW, C, S, rps);
+    else hipLaunchKernelGGL(in_stats_partial_v4<false>, g, dim3(256), 0, st, x, part, HW, C, S, rps);
+    prof_end(tok, st);
+  }
+  const int hwc4 = HW * C / 4;
+  dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
+  ProfToken tok = prof_begin(31, ebytes * ((x_bf16 ? 2 : 4) + (y_bf16 ? 2 : 4)), st);
+#define SRGAN_APPLY_IO(A, B) hipLaunchKernelGGL((in_apply_pow2<A, B>), g2, dim3(256), 0, st, x, scale, shift, (const float*)nullptr, mean, rstd, y, hwc4, C, act, slope, (const float2*)part, S, HW, eps)
+  if (x_bf16 && y_bf16) SRGAN_APPLY_IO(true, true);
+  else if (x_bf16) SRGAN_APPLY_IO(true, false);
+  else if (y_bf16) SRGAN_APPLY_IO(false, true);
+  else SRGAN_APPLY_IO(false, false);
+#undef SRGAN_APPLY_IO
+  prof_end(tok, st);
+  return check_launch("instnorm_fwd_io");
+}
+
+extern "C" int srgan_instnorm_bwd_io(const void* x, int x_bf16, const void* dy, int dy_bf16, const float* scale, const float* shift,
+                                     const float* mean, const float* rstd, void* dx, int dx_bf16, float* dscale, float* dshift, int N,
+                                     int HW, int C, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
+  SRGAN_REQUIRE(x && dy && mean && rstd && dx && dscale && dshift, "instnorm_bwd_io: null pointer");
+  SRGAN_REQUIRE(srgan_instnorm_io_applicable(N, HW, C), "instnorm_bwd_io: shape not served (srgan_instnorm_io_applicable)");
+  SRGAN_REQUIRE((x_bf16 != 0) == (dx_bf16 != 0), "instnorm_bwd_io: the input gradient has the input's type");
+  if (slab_fast(N, HW, C)) {
+    return srgan_instnorm_slab_bwd_io(x, x_bf16, dy, dy_bf16, scale, shift, mean, rstd, dx, dx_bf16, dscale, dshift, N, HW, C, act, slope, stream);
+  }
+  SRGAN_REQUIRE((scale == nullptr) == (shift == nullptr), "instnorm_bwd_io: scale and shift go together");
+  hipStream_t st = as_stream(stream);
+  int S, rps;
+  plan_split(N, HW, C, S, rps);
+  SRGAN_REQUIRE(ws && ws_bytes >= (size_t)N * S * C * sizeof(float2), "instnorm_bwd_io: workspace too small (srgan_instnorm_workspace)");
+  const double ebytes = (double)N * HW * C;
+  const int xb = x_bf16 ? 2 : 4, gb = dy_bf16 ? 2 : 4;
+  float2* part = reinterpret_cast<float2*>(ws);
+  dim3 g((C + NORM_CH - 1) / NORM_CH, S, N);
+  {
+    ProfToken tok = prof_begin(32, ebytes * (xb + gb), st);
+#define SRGAN_BPART_IO(A, B) hipLaunchKernelGGL((in_bwd_partial_v4<A, B>), g, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, HW, C, S, rps, act, slope)
+    if (x_bf16 && dy_bf16) SRGAN_BPART_IO(true, true);
+    else if (x_bf16) SRGAN_BPART_IO(true, false);
+    else if (dy_bf16) SRGAN_BPART_IO(false, true);
+    else SRGAN_BPART_IO(false, false);
+#undef SRGAN_BPART_IO
+    prof_end(tok, st);
+  }
+  const int hwc4 = HW * C / 4;
+  const float inv_hw = 1.f / (float)HW;
+  dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
+  ProfToken tok = prof_begin(33, ebytes * (2 * xb + gb), st);
+#define SRGAN_BAPPLY_IO(A, B) hipLaunchKernelGGL((in_bwd_apply_pow2<A, B, A>), g2, dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dshift, dscale, dx, hwc4, C, inv_hw, act, slope, (const float2*)part, S)
+  if (x_bf16 && dy_bf16) SRGAN_BAPPLY_IO(true, true);
+  else if (x_bf16) SRGAN_BAPPLY_IO(true, false);
+  else if (dy_bf16) SRGAN_BAPPLY_IO(false, true);
+  else SRGAN_BAPPLY_IO(false, false);
+#undef SRGAN_BAPPLY_IO
+  prof_end(tok, st);
+  return check_launch("instnorm_bwd_io");
 }
 
 extern "C" int srgan_cbin_affine_fwd(const float* c, const float* W, const float* b, const float* gamma,

@@ -36,14 +36,30 @@ E_SLOPE = 0.2    # nn.LeakyReLU(0.2) in the encoders               (model.py:357
 class _Conv2d(nn.Conv2d):
     """nn.Conv2d parameters; forward = implicit-GEMM MFMA kernel (optionally fused LeakyReLU)."""
 
-    def forward(self, x, act=ACT_NONE, slope=0.0, in_slope=None, act_bwd_by_consumer=False):
+    def forward(self, x, act=ACT_NONE, slope=0.0, in_slope=None, act_bwd_by_consumer=False, io16=None):
+        """io16 (bf16 mode, ops.s2_io_applicable layers only): None = ordinary fp32 tensors; True / False = the input may be a
+        bf16 tensor and the output is written as bf16 / fp32 (the generator's down path, ops.py "bf16 activation storage")."""
+        if io16 is not None:
+            return ops.conv2d_s2_io(x, self.weight, io16)
         mode = PAD_REFLECT if self.padding_mode == "reflect" else PAD_ZERO
         return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], mode, act, slope, in_slope, act_bwd_by_consumer)
 
+    def s2_io_applicable(self, x):
+        n, ci, hi, wi = x.shape
+        return (self.bias is None and self.kernel_size == (4, 4) and self.stride == (2, 2) and self.padding == (1, 1)
+                and self.padding_mode == "zeros" and ops.s2_io_applicable(n, ci, hi, wi, self.out_channels, self.weight, False))
+
 
 class _ConvTranspose2d(nn.ConvTranspose2d):
-    def forward(self, x):
+    def forward(self, x, io16=None):
+        if io16 is not None:
+            return ops.conv_transpose2d_io(x, self.weight, io16)
         return ops.conv_transpose2d(x, self.weight, self.stride[0], self.padding[0])
+
+    def s2_io_applicable(self, x):
+        n, ci, hi, wi = x.shape
+        return (self.bias is None and self.kernel_size == (4, 4) and self.stride == (2, 2) and self.padding == (1, 1)
+                and self.output_padding == (0, 0) and ops.s2_io_applicable(n, ci, hi, wi, self.out_channels, self.weight, True))
 
 
 class _Linear(nn.Linear):
@@ -86,7 +102,9 @@ class _InstanceNorm2d(nn.Module):
             raise NotImplementedError("InstanceNorm2d(affine=True) is not used by the reference")
         self.num_features = num_features
 
-    def forward(self, x, act=ACT_NONE, slope=0.0):
+    def forward(self, x, act=ACT_NONE, slope=0.0, out_bf16=False):
+        if out_bf16 or x.dtype == torch.bfloat16:
+            return ops.instance_norm_act_io(x, None, None, act, slope, 1e-5, out_bf16)
         return ops.instance_norm_act(x, None, None, None, act, slope)
 
 
@@ -175,10 +193,15 @@ class CBINorm2d(nn.Module):
         if input.dim() != 4:
             raise ValueError('expected 4D input (got {}D input)'.format(input.dim()))
 
-    def forward(self, input, ConInfor, act=ACT_NONE, slope=0.0, res=None):
-        """(IN(x) + tanh(Linear(c))) * weight + bias, with optional fused activation / residual."""
+    def forward(self, input, ConInfor, act=ACT_NONE, slope=0.0, res=None, out_bf16=False):
+        """(IN(x) + tanh(Linear(c))) * weight + bias, with optional fused activation / residual.  out_bf16 / a bf16 input: the
+        bf16 mode's 16-bit activation storage (no residual there)."""
         self._check_input_dim(input)
         scale, shift = self.scale_shift(ConInfor, input.device)
+        if out_bf16 or input.dtype == torch.bfloat16:
+            if res is not None:
+                raise ValueError("CBINorm2d: no residual on the 16-bit storage path")
+            return ops.instance_norm_act_io(input, scale, shift, act, slope, self.eps, out_bf16)
         return ops.instance_norm_act(input, scale, shift, res, act, slope, self.eps)
 
     def scale_shift(self, ConInfor, device):
@@ -287,11 +310,35 @@ class SingleGenerator(nn.Module):
     def forward(self, x, c):
         if c.is_cuda and not _lib.ab("SRGAN_NO_CBIN_MULTI"):
             c = PrecomputedCon(c, list(self.down_cnorms) + [n for blk in self.resBlocks for n in (blk.cn1, blk.cn2)])
+        # bf16 mode: the tensors between the stride-2 convolutions and their norms are kept in bf16 where the patch kernels and the
+        # 16-bit norm kernels serve the shapes (ops.py, "bf16 activation storage"); everything else -- and every other mode --
+        # takes the ordinary fp32 path.  io[i]: down conv i (i >= 1) takes and writes bf16.
+        n, _, h, w = x.shape
+        io = [False] * (self.num_cls + 2)
+        if x.is_cuda and ops.get_compute_dtype() == "bf16":
+            hh, ww = h, w
+            for i in range(1, self.num_cls + 1):
+                cv = self.down_convs[i]
+                probe = torch.empty((n, cv.in_channels, hh, ww), device="meta")
+                io[i] = (cv.s2_io_applicable(probe) and ops.norm_io_applicable(n, cv.in_channels, hh, ww)
+                         and ops.norm_io_applicable(n, cv.out_channels, hh // 2, ww // 2))
+                hh, ww = hh // 2, ww // 2
         for i in range(self.num_cls + 1):
-            x = self.down_cnorms[i](self.down_convs[i](x), c, ACT_RELU)
+            y = self.down_convs[i](x, io16=True) if io[i] else self.down_convs[i](x)
+            x = self.down_cnorms[i](y, c, ACT_RELU, out_bf16=io[i + 1])
         x = self.resBlocks([x, c])[0]
+        n, _, h, w = x.shape
+        iot = [False] * (self.num_cls + 1)
+        if x.is_cuda and ops.get_compute_dtype() == "bf16":
+            hh, ww = h, w
+            for i in range(self.num_cls):
+                cv = self.up_convs[i]
+                probe = torch.empty((n, cv.in_channels, hh, ww), device="meta")
+                iot[i] = cv.s2_io_applicable(probe) and ops.norm_io_applicable(n, cv.out_channels, 2 * hh, 2 * ww)
+                hh, ww = 2 * hh, 2 * ww
         for i in range(self.num_cls):
-            x = self.up_norms[i](self.up_convs[i](x), ACT_RELU)
+            y = self.up_convs[i](x, io16=True) if iot[i] else self.up_convs[i](x)
+            x = self.up_norms[i](y, ACT_RELU, out_bf16=iot[i + 1])
         return ops.tanh(self.up_convs[-1](x))
 
 

@@ -93,8 +93,8 @@ def upload_small(blob, device, out=None):
     return out
 
 
-def nhwc_empty(n, c, h, w, device):
-    return torch.empty((n, h, w, c), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+def nhwc_empty(n, c, h, w, device, dtype=torch.float32):
+    return torch.empty((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
 
 
 def is_nhwc_dense(t):
@@ -105,9 +105,13 @@ def to_nhwc(t):
     """Return an NHWC-dense tensor with the same logical NCHW shape/values (HIP repack kernel)."""
     if t.dim() != 4:
         raise ValueError('expected 4D input (got {}D input)'.format(t.dim()))
+    if t.dtype == torch.bfloat16 and t.is_cuda and is_nhwc_dense(t):      # a 16-bit activation of the bf16 mode (already dense)
+        return t
     _require_gpu(t, "to_nhwc")
     if is_nhwc_dense(t):
         return t
+    if t.dtype != torch.float32:
+        raise _lib.SrganHipError(f"to_nhwc: a {t.dtype} tensor must already be NHWC-dense (the repack kernel is fp32)")
     t = t.contiguous()
     n, c, h, w = t.shape
     out = nhwc_empty(n, c, h, w, t.device)
@@ -1024,6 +1028,173 @@ class _ResBlockBf16Fn(Function):
             dx = torch.empty_like(g)
             _lib.check(lib.srgan_halo16_conv(ctypes.byref(d1), 1, _ptr(dy1), 1, _ptr(hit1.buf), _ptr(g), _ptr(dx), 0, st), "halo16_conv")
         return dx, ds1, dh1, ds2, dh2, dw1, dw2, None
+
+
+# ---- bf16 activation storage outside the residual trunk (round 4) -------------------------------------------------------
+# In the bf16 mode the generator's down / up path keeps the tensors BETWEEN its stride-2 convolutions and their norms in bf16
+# (pyfiles/model.py:212-215, 227-231, 245-246):
+#     norm0 out (fp32 -> bf16) -> down1 (bf16 -> bf16) -> norm1 (bf16 -> bf16) -> down2 (bf16 -> bf16) -> norm2 (bf16 -> fp32) -> trunk
+#     trunk out (fp32) -> up0 (fp32 -> bf16) -> norm (bf16 -> bf16) -> up1 (bf16 -> bf16) -> norm (bf16 -> fp32) -> RGB head
+# The convolutions round their operands to bf16 anyway, so a bf16 norm OUTPUT changes no product; a bf16 conv OUTPUT is what
+# torch.autocast stores (its statistics are then taken from the rounded values, as in the residual-block node above).  The
+# gradients take the types of the tensors they belong to.  Served by the LDS-resident-patch kernels (csrc/conv_halo16.hip:
+# halo16s / halo16t / halo16s2_wgrad with IN16 / OUT16) and the instance-norm kernels with 16-bit I/O (srgan_instnorm_fwd_io /
+# _bwd_io): half the bytes in the norm passes, region loads without conversion in the convolutions.
+STORAGE_BF16 = True               # tests switch it off to compare against the fp32-tensor chain
+
+
+def _is16(t):
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def s2_io_applicable(n, ci, hi, wi, co, weight, transposed):
+    """True when a 4x4 / stride-2 / pad-1 Conv2d (ci -> co, hi x wi -> half) -- or, transposed=True, the ConvTranspose2d
+    (ci -> co, hi x wi -> double) -- can take / write bf16 tensors: bf16 mode, packed-weight scope, all three directions on the
+    patch kernels."""
+    if not (STORAGE_BF16 and _pack_cache_on and get_compute_dtype() == "bf16" and weight.is_cuda):
+        return False
+    if tuple(weight.shape[2:]) != (4, 4):
+        return False
+    if transposed:          # conv C of _ConvTranspose2dFn: input = y-space [n, co, 2 hi, 2 wi], output = x-space
+        desc = _conv_desc(n, 2 * hi, 2 * wi, co, hi, wi, ci, 4, 4, 2, 1, PAD_ZERO, weight)
+    else:
+        if hi % 2 or wi % 2:
+            return False
+        desc = _conv_desc(n, hi, wi, ci, hi // 2, wi // 2, co, 4, 4, 2, 1, PAD_ZERO, weight)
+    return bool(_lib.load().srgan_halo16s2_applicable(ctypes.byref(desc)))
+
+
+def norm_io_applicable(n, c, h, w):
+    return bool(STORAGE_BF16 and get_compute_dtype() == "bf16" and _lib.load().srgan_instnorm_io_applicable(n, h * w, c))
+
+
+def _s2_wgrad(desc, weight, xin, dy, needs):
+    """dW of conv C (desc) from xin (C's input side) and dy (C's output side), either fp32 or bf16; through the gradient sink."""
+    if not needs:
+        return None
+    slots = _sink_slots(weight)
+    (dw,), acc = slots if slots is not None else ([torch.empty(weight.shape, dtype=torch.float32, device=weight.device)], False)
+    dd = ConvDesc.from_buffer_copy(desc)
+    dd.sO, dd.sI, dd.sH, dd.sW = dw.stride()
+    ws, nb = _conv_ws(dd, xin.device)
+    with _wgrad_accumulate(acc, slots is not None):
+        _lib.check(_lib.load().srgan_halo16_wgrad(ctypes.byref(dd), _ptr(xin), _is16(xin), _ptr(dy), _is16(dy), _ptr(dw), _ptr(ws), nb,
+                                                   _stream()), "halo16_wgrad")
+    return None if slots is not None else dw
+
+
+class _ConvS2IoFn(Function):
+    """4x4 / stride-2 / pad-1 Conv2d without bias in the bf16 mode, input fp32 or bf16, output bf16 or fp32 (see above)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, out_bf16):
+        x = to_nhwc(x)
+        n, i, hi, wi = x.shape
+        o = weight.shape[0]
+        desc = _conv_desc(n, hi, wi, i, hi // 2, wi // 2, o, 4, 4, 2, 1, PAD_ZERO, weight)
+        hit, _ = _packed(desc, weight, 0, ACT_NONE)
+        y = nhwc_empty(n, o, hi // 2, wi // 2, x.device, torch.bfloat16 if out_bf16 else torch.float32)
+        _lib.check(_lib.load().srgan_halo16_conv(ctypes.byref(desc), 0, _ptr(x), _is16(x), _ptr(hit.buf), None, _ptr(y), _is16(y),
+                                                 _stream()), "halo16_conv")
+        ctx.desc, ctx.weight = desc, weight
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = to_nhwc(gy)
+        weight = ctx.weight
+        dx = None
+        if ctx.needs_input_grad[0]:
+            hit, _ = _packed(ctx.desc, weight, 1, ACT_NONE)
+            dx = torch.empty_like(x)
+            _lib.check(_lib.load().srgan_halo16_conv(ctypes.byref(ctx.desc), 1, _ptr(gy), _is16(gy), _ptr(hit.buf), None, _ptr(dx),
+                                                     _is16(dx), _stream()), "halo16_conv")
+        dw = _s2_wgrad(ctx.desc, weight, x, gy, ctx.needs_input_grad[1])
+        return dx, dw, None
+
+
+class _ConvT2IoFn(Function):
+    """4x4 / stride-2 / pad-1 ConvTranspose2d in the bf16 mode with fp32 or bf16 tensors on either side: the transposed form of
+    the conv C whose weight is w viewed as [O = Cin][I = Cout] (as _ConvTranspose2dFn)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, out_bf16):
+        x = to_nhwc(x)
+        n, ci, hi, wi = x.shape
+        co = weight.shape[1]
+        desc = _conv_desc(n, 2 * hi, 2 * wi, co, hi, wi, ci, 4, 4, 2, 1, PAD_ZERO, weight)
+        hit, _ = _packed(desc, weight, 1, ACT_NONE)
+        y = nhwc_empty(n, co, 2 * hi, 2 * wi, x.device, torch.bfloat16 if out_bf16 else torch.float32)
+        _lib.check(_lib.load().srgan_halo16_conv(ctypes.byref(desc), 1, _ptr(x), _is16(x), _ptr(hit.buf), None, _ptr(y), _is16(y),
+                                                 _stream()), "halo16_conv")
+        ctx.desc, ctx.weight = desc, weight
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = to_nhwc(gy)
+        weight = ctx.weight
+        dx = None
+        if ctx.needs_input_grad[0]:
+            hit, _ = _packed(ctx.desc, weight, 0, ACT_NONE)
+            dx = torch.empty_like(x)
+            _lib.check(_lib.load().srgan_halo16_conv(ctypes.byref(ctx.desc), 0, _ptr(gy), _is16(gy), _ptr(hit.buf), None, _ptr(dx),
+                                                     _is16(dx), _stream()), "halo16_conv")
+        dw = _s2_wgrad(ctx.desc, weight, gy, x, ctx.needs_input_grad[1])      # C's input side is y-space
+        return dx, dw, None
+
+
+class _InstNormIoFn(Function):
+    """instance_norm_act with an fp32 or bf16 input and a bf16 or fp32 output (no residual); dx has x's type."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, act, slope, eps, out_bf16):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        lib = _lib.load()
+        y = nhwc_empty(n, c, h, w, x.device, torch.bfloat16 if out_bf16 else torch.float32)
+        mean = torch.empty(n * c, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        nb = lib.srgan_instnorm_workspace(n, h * w, c)
+        ws = workspace(x.device, nb)
+        _lib.check(lib.srgan_instnorm_fwd_io(_ptr(x), _is16(x), _ptr(scale), _ptr(shift), _ptr(y), _is16(y), _ptr(mean), _ptr(rstd),
+                                             n, h * w, c, float(eps), act, float(slope), _ptr(ws), nb, _stream()), "instnorm_fwd_io")
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(x, scale, shift, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, scale, shift, mean, rstd = ctx.saved_tensors
+        gy = to_nhwc(gy)
+        n, c, h, w = x.shape
+        lib = _lib.load()
+        dx = torch.empty_like(x)
+        dscale = torch.empty(n, c, dtype=torch.float32, device=x.device)
+        dshift = torch.empty_like(dscale)
+        nb = lib.srgan_instnorm_workspace(n, h * w, c)
+        ws = workspace(x.device, nb)
+        _lib.check(lib.srgan_instnorm_bwd_io(_ptr(x), _is16(x), _ptr(gy), _is16(gy), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
+                                             _ptr(dx), _is16(dx), _ptr(dscale), _ptr(dshift), n, h * w, c, ctx.act, float(ctx.slope),
+                                             _ptr(ws), nb, _stream()), "instnorm_bwd_io")
+        has_aff = scale is not None
+        return dx, dscale if has_aff else None, dshift if has_aff else None, None, None, None, None
+
+
+def conv2d_s2_io(x, weight, out_bf16):
+    return _ConvS2IoFn.apply(x, weight, bool(out_bf16))
+
+
+def conv_transpose2d_io(x, weight, out_bf16):
+    return _ConvT2IoFn.apply(x, weight, bool(out_bf16))
+
+
+def instance_norm_act_io(x, scale, shift, act=ACT_NONE, slope=0.0, eps=1e-5, out_bf16=False):
+    return _InstNormIoFn.apply(x, scale, shift, act, slope, eps, bool(out_bf16))
 
 
 RESBLOCK_BF16_STORAGE = True      # tests/test_ops_gpu.py switches the bf16-storage node off to compare it with the unfused chain

@@ -1043,3 +1043,53 @@ def test_leaky_relu_backward_in_the_consumers_input_gradient(ops, n, c0, c1, c2,
         close(got, want, 3e-5)
     for a, b in zip(res[True], res[False]):
         close(a, b, 1e-6)
+
+
+def test_generator_bf16_activation_storage_vs_fp32_tensors(ops):
+    """Round 4: in the bf16 mode the tensors between the generator's stride-2 convolutions and their norms live in HBM as bf16
+    (ops.py "bf16 activation storage": halo16s / halo16t / halo16s2_wgrad kernels with 16-bit I/O, instance norm with 16-bit
+    I/O).  A full-width generator on a 16 x 128 image (so that every down / up layer is served: 8 x 64 and 4 x 32 maps) runs
+    forward + backward with the storage on and off; both are bf16-mode results, so they are held to each other and, for scale,
+    to the fp32-tensor chain's own distance from the exact-fp32 mode."""
+    from srgan_amd import model
+    torch.manual_seed(0)
+    G = model.SingleGenerator(3, 64, 2, 2, 1, "instance", num_con=12).cuda()
+    x = (torch.rand(2, 3, 16, 128) * 2 - 1).cuda()
+    c = torch.cat([torch.eye(4)[torch.tensor([1, 3])], torch.randn(2, 8)], 1).cuda()
+    gy = rnd(2, 3, 16, 128, seed=5).cuda()
+    params = [p for p in G.parameters()]
+
+    def run(mode, storage):
+        ops.set_compute_dtype(mode)
+        ops.STORAGE_BF16 = storage
+        try:
+            for p in params:
+                p.grad = None
+            with ops.pack_cache():
+                if mode == "bf16":
+                    probe = torch.empty((2, 64, 16, 128), device="meta")
+                    assert G.down_convs[1].s2_io_applicable(probe) == storage      # the path under test is really taken
+                y = G(x, c)
+                (y * gy).sum().backward()
+            return y.detach().clone(), [p.grad.detach().clone() for p in params]
+        finally:
+            ops.STORAGE_BF16 = True
+            ops.set_compute_dtype("fp32")
+            ops.invalidate_packed()
+
+    y32, g32 = run("fp32", True)
+    yc, gc = run("bf16", False)          # bf16 products, fp32 tensors
+    ys, gs = run("bf16", True)           # bf16 products, bf16 tensors between conv and norm
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-12))
+
+    assert rel(ys, y32) <= 1.5 * rel(yc, y32) + 2e-3, (rel(ys, y32), rel(yc, y32))
+    assert rel(ys, y32) <= 2e-2
+    worst = 0.0
+    for (name, _), a, b, r in zip(G.named_parameters(), gs, gc, g32):
+        e_s, e_c = rel(a, r), rel(b, r)
+        worst = max(worst, e_s)
+        # ReLU-mask flips of bf16-rounded pre-activations dominate both bf16 paths (cf. test_residual_block_bf16_storage)
+        assert e_s <= 1.6 * e_c + 1e-2, (name, e_s, e_c)
+    assert worst <= 0.15, worst
