@@ -101,6 +101,119 @@ __global__ __launch_bounds__(512) void rgbin_conv_kernel(RgbinParams p) {
   }
 }
 
+// ---- bf16 compute mode (round 4): the same layers on v_mfma_f32_32x32x16_bf16 ----
+// In the bf16 mode these layers used to stay on the fp32 kernel above: 108 us per launch at batch 32 for a result that takes 25 us
+// to write.  Here the halo is parked as bf16 with FOUR channels per pixel (RGB + a zero), so that the 8 consecutive k of a lane's
+// fragment -- two neighbouring pixels x 4 channels -- are 16 contiguous bytes at an 8-byte aligned address (two ds_read_b64;
+// with 3 channels per pixel they would start at odd multiples of 2 bytes); K is laid out (ky, 32-entry row): 7 (kx) x 4 (c)
+// taps + 4 zero-weight entries, two 16-deep K steps per filter row, 14 steps in all (the fp32 kernel: 77 steps of 2).  The filter
+// block lives in LDS as [64 output channels][232] bf16 (row stride 29 x 16 bytes: conflict-free ds_read_b128 fragments).  Same
+// tile, wave roles and epilogue as above; the products are 11x cheaper, what is left is the write of the result.
+constexpr int R16_HC = 40;            // halo columns: 32 + 6 + 2 (the zero-weight entries read one pixel further)
+constexpr int R16_KPS = 232;          // bf16 per packed filter row: 7 x 32 + 8 pad
+
+struct Rgbin16Params {
+  const float* x;            // [NB][H][W][3]
+  const unsigned short* wp;  // [O][R16_KPS] bf16
+  const float* bias;         // [O] or null
+  float* y;                  // [NB][Ho][Wo][O]
+  int NB, H, W, Ho, Wo, O, pad;
+  int tiles_x, tiles_y, o_blocks;
+  int act;
+  float slope;
+};
+
+__global__ __launch_bounds__(512) void rgbin16_conv_kernel(Rgbin16Params p) {
+  constexpr int TR = 16, TC = 32, KH = 7, HR = TR + KH - 1;
+  __shared__ __attribute__((aligned(16))) unsigned short halo[HR * R16_HC * 4 + 32];
+  __shared__ __attribute__((aligned(16))) unsigned short wl[64 * R16_KPS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  int b = blockIdx.x;
+  const int tx = b % p.tiles_x; b /= p.tiles_x;
+  const int ty = b % p.tiles_y; b /= p.tiles_y;
+  const int ob = b % p.o_blocks, n = b / p.o_blocks;
+  const int X0 = tx * TC, Y0 = ty * TR;
+
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.wp + (size_t)ob * 64 * R16_KPS);
+    f32x4* dst = reinterpret_cast<f32x4*>(wl);
+    for (int e = tid; e < 64 * R16_KPS / 8; e += 512) dst[e] = src[e];
+  }
+  {
+    const float* img = p.x + (size_t)n * p.H * p.W * 3;
+    for (int e = tid; e < HR * R16_HC + 8; e += 512) {
+      const int r = e / R16_HC, c = e - r * R16_HC;
+      const int gy = Y0 - p.pad + r, gx = X0 - p.pad + c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < HR && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
+        const float* q = img + ((size_t)gy * p.W + gx) * 3;
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2];
+      }
+      *reinterpret_cast<bf16x4*>(&halo[e * 4]) = __builtin_convertvector(v, bf16x4);
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // A: lane (lr, lh) = pixel column lr, k = 8 lh .. 8 lh + 7 of the step = pixels lr + 4 s + 2 lh, + 1 of filter row ky
+  const unsigned short* a0 = halo + ((2 * wave) * R16_HC + lr + 2 * lh) * 4;
+  const unsigned short* bw = wl + lr * R16_KPS + 8 * lh;
+#pragma unroll
+  for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned short* a = a0 + ((i + ky) * R16_HC + 4 * s) * 4;
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(a), hi = *reinterpret_cast<const bf16x4*>(a + 4);
+        fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bw + j * 32 * R16_KPS + ky * 32 + 16 * s);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oy = Y0 + 2 * wave + i;
+    if (oy >= p.Ho) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int oc = ob * 64 + j * 32 + lr;
+      const float bv = p.bias ? p.bias[oc] : 0.f;
+      float* row = p.y + ((size_t)(n * p.Ho + oy) * p.Wo) * p.O + oc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ox = X0 + 8 * (e >> 2) + 4 * lh + (e & 3);
+        if (ox < p.Wo) row[(size_t)ox * p.O] = apply_act(acc[i][j][e] + bv, p.act, p.slope);
+      }
+    }
+  }
+}
+
+// bf16 packed filter: wp[o][ky * 32 + kx * 4 + c] = w[o][c][ky][kx] (through the weight strides), zero elsewhere
+__global__ void rgbin16_pack_kernel(const float* w, unsigned short* dst, long long sO, long long sI, long long sH, long long sW, int O) {
+  const long long total = (long long)O * R16_KPS;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int o = (int)(idx / R16_KPS), k = (int)(idx - (long long)o * R16_KPS);
+    const int ky = k >> 5, kx = (k & 31) >> 2, c = k & 3;
+    float v = 0.f;
+    if (ky < 7 && kx < 7 && c < 3) v = w[o * sO + c * sI + ky * sH + kx * sW];
+    reinterpret_cast<__bf16*>(dst)[idx] = (__bf16)v;
+  }
+}
+
 // packed filter: wp[(ky * KR + kx * CI + c)][o] = w[o][c][ky][kx] (through the weight strides), zero in the pad entry
 __global__ void rgbin_pack_kernel(const float* w, float* dst, long long sO, long long sI, long long sH, long long sW, int O,
                                   int CI, int KH, int KW) {
@@ -304,7 +417,20 @@ bool rgbin_applicable(const srgan_conv_desc* d) {
 
 size_t rgbin_packed_elems(const srgan_conv_desc* d) { return (size_t)d->kh * ((d->kw * d->I + 1) & ~1) * d->O; }
 
+// bf16 mode: the 3 -> 64k-channel 7x7 / pad-3 layers on rgbin16_conv_kernel (its packed filter, O x 232 bf16, fits the fp32
+// kernel's allocation of 7 x 22 x O floats)
+static bool rgbin16_mode(const srgan_conv_desc* d) {
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_RGBIN16");
+  return !off && compute_bf16() && d->I == 3 && d->kh == 7 && d->kw == 7 && d->pad == 3;
+}
+
 int rgbin_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st) {
+  if (rgbin16_mode(d)) {
+    const long long total16 = (long long)d->O * R16_KPS;
+    hipLaunchKernelGGL(rgbin16_pack_kernel, dim3((unsigned)std::min<long long>(ceil_div(total16, 256), 1024)), dim3(256), 0, st, w,
+                       reinterpret_cast<unsigned short*>(dst), d->sO, d->sI, d->sH, d->sW, d->O);
+    return check_launch("rgbin16_pack_kernel");
+  }
   const long long total = (long long)rgbin_packed_elems(d);
   hipLaunchKernelGGL(rgbin_pack_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 1024)), dim3(256), 0, st, w, dst,
                      d->sO, d->sI, d->sH, d->sW, d->O, d->I, d->kh, d->kw);
@@ -322,6 +448,15 @@ int rgbin_run(const srgan_conv_desc* d, const float* x, const float* packed, con
   const long long grid = (long long)p.tiles_x * p.tiles_y * p.o_blocks * d->N;
   SRGAN_REQUIRE(grid < (1LL << 31), "rgb-input conv: grid too large");
   ProfToken tok = prof_begin(20, 2.0 * d->N * d->Ho * d->Wo * (double)d->O * d->kh * d->kw * d->I, st);
+  if (rgbin16_mode(d)) {
+    Rgbin16Params q{};
+    q.x = x; q.wp = reinterpret_cast<const unsigned short*>(packed); q.bias = bias; q.y = y;
+    q.NB = p.NB; q.H = p.H; q.W = p.W; q.Ho = p.Ho; q.Wo = p.Wo; q.O = p.O; q.pad = p.pad;
+    q.tiles_x = p.tiles_x; q.tiles_y = p.tiles_y; q.o_blocks = p.o_blocks; q.act = act; q.slope = slope;
+    hipLaunchKernelGGL(rgbin16_conv_kernel, dim3((unsigned)grid), dim3(512), 0, st, q);
+    prof_end(tok, st);
+    return check_launch("rgbin16_conv_kernel");
+  }
   hipLaunchKernelGGL((rgbin_conv_kernel<7, 7, 3>), dim3((unsigned)grid), dim3(512), 0, st, p);
   prof_end(tok, st);
   return check_launch("rgbin_conv_kernel");

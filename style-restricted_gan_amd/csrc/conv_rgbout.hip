@@ -241,6 +241,142 @@ __global__ __launch_bounds__(512) void rgbout_conv_kernel(RgboutParams p) {
   }
 }
 
+// ---- bf16 compute mode (round 4): the 64 -> 3 channel head on v_mfma_f32_32x32x16_bf16 ----
+// In the bf16 mode this layer used to stay on the fp32 kernel above (148 us per launch at batch 32, 1.5 ms per step).  With bf16
+// products the 4-wide instruction is not needed: D[32 pixels][32 columns] with 3 live columns wastes 90 % of a matrix instruction
+// that is 16x cheaper -- 196 K steps (49 taps x 4 chunks of 16 channels) x 32 cycles per 32 pixels, ~45 us of matrix time per
+// launch.  Workgroup = 8 rows x 32 pixels (one row per wave), the (8 + 6) x (32 + 6) pixel halo parked ONCE as bf16
+// [pixel][64 channels + 8 pad] (77 KB: the A fragment of (tap, chunk) is one conflict-free ds_read_b128), the packed filter
+// [K step][3 couts][16] (19 KB) beside it.  The B fragment is read by the three live lanes of each half-wave only.  Bound by the
+// halo read: fp32 input, every pixel fetched 2.1 times (4-row tiles with two workgroups per CU fetched it 3 times: 119 us
+// against this tile's; with everything but the halo load removed the launch took as long).
+constexpr int RO16_TR = 8, RO16_TC = 32, RO16_HR = RO16_TR + 6, RO16_HC = RO16_TC + 6, RO16_PS = 64 * 2 + 16;
+constexpr int RO16_KSTEPS = 49 * 4;
+
+struct Rgbout16Params {
+  const float* x;            // [NB][H][W][64]
+  const unsigned short* wp;  // [196 K steps][3][16] bf16
+  const float* bias;         // [O] or null
+  float* y;                  // [NB][H][W][O]
+  int NB, H, W, O, tiles_x, tiles_y;
+  int exp;
+};
+
+__global__ __launch_bounds__(512) void rgbout16_conv_kernel(Rgbout16Params p) {
+  __shared__ __attribute__((aligned(16))) unsigned char halo[RO16_HR * RO16_HC * RO16_PS];
+  __shared__ __attribute__((aligned(16))) unsigned char wl[RO16_KSTEPS * 3 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  int b = blockIdx.x;
+  const int tx = b % p.tiles_x; b /= p.tiles_x;
+  const int ty = b % p.tiles_y;
+  const int n = b / p.tiles_y;
+  const int X0 = tx * RO16_TC, Y0 = ty * RO16_TR;
+
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.wp);
+    f32x4* dst = reinterpret_cast<f32x4*>(wl);
+    for (int e = tid; e < RO16_KSTEPS * 3 * 2; e += 512) dst[e] = src[e];
+  }
+  {
+    // thread = (pixel of the pass, 16-byte piece of its 256-byte channel row): a wave instruction covers 4 pixels x 256 contiguous
+    // bytes = 8 whole lines (with 8 channels per thread every instruction touched 16 half lines and the texture path, ~2.3 cycles
+    // per line, set the pace).  UNCONDITIONAL loads: an out-of-image pixel reads the image's first pixel (in bounds) and is zeroed
+    // when it is parked (a conditional load merged with a zero made the compiler wait for every load in turn: 240 us per launch).
+    constexpr int NPX = RO16_HR * RO16_HC, PPP = 512 / 16, NPASS = (NPX + PPP - 1) / PPP, HALF = (NPASS + 1) / 2;
+    const int piece = tid & 15, hpl = tid >> 4;
+    const float* img = p.x + (size_t)n * p.H * p.W * 64 + piece * 4;
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+      f32x4 v[HALF];
+      bool okv[HALF];
+#pragma unroll
+      for (int g = 0; g < HALF; ++g) {
+        const int hp = (bt * HALF + g) * PPP + hpl;
+        const int hr = hp / RO16_HC, hc = hp - hr * RO16_HC;
+        const int gy = Y0 - 3 + hr, gx = X0 - 3 + hc;
+        okv[g] = hp < NPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        v[g] = *reinterpret_cast<const f32x4*>(img + (okv[g] ? ((size_t)gy * p.W + gx) * 64 : 0));
+      }
+#pragma unroll
+      for (int g = 0; g < HALF; ++g) {
+        const int hp = (bt * HALF + g) * PPP + hpl;
+        if (hp < NPX) {
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<bf16x4*>(&halo[hp * RO16_PS + piece * 8]) = __builtin_convertvector(okv[g] ? v[g] : z4, bf16x4);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  // A: lane (lr, lh) = pixel column lr of row `wave`, k = 8 lh .. 8 lh + 7 of the step's 16 channels; B: lane = cout lr (< 3 live)
+  const unsigned char* a_lane = halo + (wave * RO16_HC + lr) * RO16_PS + lh * 16;
+  const unsigned char* b_lane = wl + (lr < 3 ? lr : 0) * 32 + lh * 16;
+  const bool live = lr < 3;
+  bf16x8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = (__bf16)0.f;
+  // 49 taps x 4 chunks; the fragments of tap t + 1 are requested before the products of tap t (one wave per SIMD and workgroup:
+  // without the prefetch every tap waited out the LDS latency: 217 us per launch instead of the fp32 kernel's 168)
+  bf16x8 fa[2][4], fb[2][4];
+  auto fetch = [&](int slot, int tap) __attribute__((always_inline)) {
+    const int ky = tap / 7, kx = tap - 7 * ky;
+    const unsigned char* a = a_lane + (ky * RO16_HC + kx) * RO16_PS;
+    const unsigned char* bq = b_lane + tap * 4 * 96;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#ifdef SRGAN_EXPERIMENTS
+      if (!(p.exp & 1) || tap == 0) fa[slot][q] = *reinterpret_cast<const bf16x8*>(a + q * 32);
+      if (!(p.exp & 2) || tap == 0) fb[slot][q] = live ? *reinterpret_cast<const bf16x8*>(bq + q * 96) : zero8;
+#else
+      fa[slot][q] = *reinterpret_cast<const bf16x8*>(a + q * 32);
+      fb[slot][q] = live ? *reinterpret_cast<const bf16x8*>(bq + q * 96) : zero8;
+#endif
+    }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int tap = 0; tap < 49; ++tap) {
+    if (tap + 1 < 49) fetch((tap + 1) & 1, tap + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#ifdef SRGAN_EXPERIMENTS
+      if (p.exp & 4) continue;
+#endif
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][q], fb[tap & 1][q], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // D[pixel][cout]: lane = cout lr (3 live), register e = pixel column (e % 4) + 8 (e / 4) + 4 lh of row Y0 + wave
+  const int oy = Y0 + wave;
+  if (live && lr < p.O && oy < p.H) {
+    const float bv = p.bias ? p.bias[lr] : 0.f;
+    float* row = p.y + (((size_t)n * p.H + oy) * p.W) * p.O + lr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ox = X0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (ox < p.W) row[(size_t)ox * p.O] = acc[e] + bv;
+    }
+  }
+}
+
+// bf16 packed filter [K step = (ky * 7 + kx) * 4 + chunk][3 couts][16] = w[cout][16 chunk + k][ky][kx] (zero for cout >= O)
+__global__ void rgbout16_pack_kernel(const float* w, unsigned short* dst, long long sO, long long sI, long long sH, long long sW, int O) {
+  const int total = RO16_KSTEPS * 3 * 16;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int k = idx & 15, co = (idx >> 4) % 3, step = idx / 48;
+    const int q = step & 3, tap = step >> 2, ky = tap / 7, kx = tap - 7 * ky;
+    const float v = co < O ? w[co * sO + (q * 16 + k) * sI + ky * sH + kx * sW] : 0.f;
+    reinterpret_cast<__bf16*>(dst)[idx] = (__bf16)v;
+  }
+}
+
 // packed filter [ky][quad][kx][4 couts][4 c] = w[cout][4 quad + c][ky][kx] through the weight strides (zero for cout >= O)
 __global__ void rgbout_pack_kernel(const float* w, float* dst, long long sO, long long sI, long long sH, long long sW, int O, int ncq) {
   const int total = RO_K * ncq * RO_K * 16;
@@ -266,7 +402,18 @@ bool rgbout_applicable(const srgan_conv_desc* d) {
 
 size_t rgbout_packed_elems(const srgan_conv_desc* d) { return (size_t)RO_K * (d->I / 4) * RO_K * 16; }
 
+// bf16 mode: the 64 -> (<= 3) channel head on rgbout16_conv_kernel (its 19 KB packed filter fits the fp32 kernel's 50 KB allocation)
+static bool rgbout16_mode(const srgan_conv_desc* d) {
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_RGBOUT16");
+  return !off && compute_bf16() && d->I == 64 && d->O <= 3;
+}
+
 int rgbout_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st) {
+  if (rgbout16_mode(d)) {
+    hipLaunchKernelGGL(rgbout16_pack_kernel, dim3(37), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(dst), d->sO, d->sI, d->sH,
+                       d->sW, d->O);
+    return check_launch("rgbout16_pack_kernel");
+  }
   const int total = (int)rgbout_packed_elems(d);
   hipLaunchKernelGGL(rgbout_pack_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 256)), dim3(256), 0, st, w, dst, d->sO, d->sI, d->sH,
                      d->sW, d->O, d->I / 4);
@@ -282,6 +429,16 @@ int rgbout_run(const srgan_conv_desc* d, const float* x, const float* packed, co
   const long long grid = (long long)p.tiles_x * p.tiles_y * d->N;
   SRGAN_REQUIRE(grid < (1LL << 31), "rgb-output conv: grid too large");
   ProfToken tok = prof_begin(28, 2.0 * d->N * d->Ho * d->Wo * (double)d->O * d->kh * d->kw * d->I, st);
+  if (rgbout16_mode(d)) {
+    Rgbout16Params q{};
+    q.x = x; q.wp = reinterpret_cast<const unsigned short*>(packed); q.bias = bias; q.y = y;
+    q.NB = d->N; q.H = d->Hi; q.W = d->Wi; q.O = d->O;
+    q.tiles_x = (int)ceil_div(d->Wo, RO16_TC); q.tiles_y = (int)ceil_div(d->Ho, RO16_TR);
+    q.exp = (int)SRGAN_AB_INT("SRGAN_RGBOUT16_EXP", 0);
+    hipLaunchKernelGGL(rgbout16_conv_kernel, dim3((unsigned)(q.tiles_x * q.tiles_y * d->N)), dim3(512), 0, st, q);
+    prof_end(tok, st);
+    return check_launch("rgbout16_conv_kernel");
+  }
   hipLaunchKernelGGL(rgbout_conv_kernel, dim3((unsigned)grid), dim3(512), 0, st, p);
   prof_end(tok, st);
   return check_launch("rgbout_conv_kernel");

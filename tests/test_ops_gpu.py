@@ -1,6 +1,8 @@
 """GPU: every HIP op of libsrgan_hip.so (through the C ABI / ctypes) against a PyTorch-CPU fp32/fp64
 restatement of the same op.  Tolerance: 2e-5 relative to the tensor's max magnitude for fp32 kernels
 (exact-fp32 MFMA, different summation order), stated per test."""
+import contextlib
+
 import numpy as np
 import pytest
 import torch
@@ -1092,4 +1094,44 @@ def test_generator_bf16_activation_storage_vs_fp32_tensors(ops):
         worst = max(worst, e_s)
         # ReLU-mask flips of bf16-rounded pre-activations dominate both bf16 paths (cf. test_residual_block_bf16_storage)
         assert e_s <= 1.6 * e_c + 1e-2, (name, e_s, e_c)
-    assert worst <= 0.15, worst
+    assert worst <= 0.3, worst          # sanity cap (0.17 measured on the noisiest tensor once the RGB layers multiply in bf16 too)
+
+
+def test_rgb_input_form_bf16_compute_mode(ops):
+    """Round 4: in the bf16 mode the 3 -> 64 channel 7x7 form -- the generator's RGB input layer forward and the input gradient
+    of its RGB output layer -- runs on rgbin16_conv_kernel (bf16 MFMA, halo with 4 channels per pixel) and the 64 -> 3 head's
+    forward on rgbout16_conv_kernel: equal to the fp32 convolution of the bf16-ROUNDED operands; the weight gradients of both
+    layers stay on the exact-fp32 kernels."""
+    torch.set_num_threads(16)
+    x = rnd(2, 3, 32, 64, seed=11)
+    w_in = rnd(64, 3, 7, 7, seed=12) / np.sqrt(147)
+    h = rnd(2, 64, 32, 64, seed=13)
+    w_out = rnd(3, 64, 7, 7, seed=14) / np.sqrt(3136)
+    gy_in, gy_out = rnd(2, 64, 32, 64, seed=15), rnd(2, 3, 32, 64, seed=16)
+    y_ref = F.conv2d(_bf16_round(x), _bf16_round(w_in), None, 1, 3)
+    hr = h.clone().requires_grad_(True)
+    F.conv2d(hr, _bf16_round(w_out), None, 1, 3).backward(_bf16_round(gy_out))
+    ops.set_compute_dtype("bf16")
+    try:
+        for cached in (False, True):
+            xd, wd = x.cuda(), w_in.cuda().requires_grad_(True)
+            hd, wo = h.cuda().requires_grad_(True), w_out.cuda().requires_grad_(True)
+            ctx = ops.pack_cache() if cached else contextlib.nullcontext()
+            with ctx:
+                y = ops.conv2d(xd, wd, None, 1, 3)
+                y.backward(gy_in.cuda())
+                yo = ops.conv2d(hd, wo, None, 1, 3)
+                yo.backward(gy_out.cuda())
+            close(y, y_ref)
+            close(hd.grad, hr.grad)
+            # exact-fp32 parts
+            wr = w_in.clone().requires_grad_(True)
+            F.conv2d(x, wr, None, 1, 3).backward(gy_in)
+            close(wd.grad, wr.grad)
+            close(yo, F.conv2d(_bf16_round(h), _bf16_round(w_out), None, 1, 3))      # rgbout16_conv_kernel
+            wor = w_out.clone().requires_grad_(True)
+            F.conv2d(h, wor, None, 1, 3).backward(gy_out)
+            close(wo.grad, wor.grad)
+    finally:
+        ops.set_compute_dtype("fp32")
+        ops.invalidate_packed()
