@@ -607,7 +607,9 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   f32x4 a_reg[A_IT], b_reg[B_IT];
-  float b_msk[B_IT];
+  float a_msk[A_IT], b_msk[B_IT];      // 0 / 1 per staged float4, applied when the tile is written to LDS (keeps the loads in flight)
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) a_msk[i] = 1.f;
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) b_msk[i] = 1.f;
 
@@ -673,9 +675,9 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
     for (int i = 0; i < A_IT; ++i) {
       const int idx = tid + NT * i;
       const int r = idx / A_PR, c4 = idx - r * A_PR;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (co0 + c4 * 4 < p.Cd) v = *reinterpret_cast<const f32x4*>(abase + (size_t)r * p.Cd + c4 * 4);
-      a_reg[i] = v;
+      const bool ok = co0 + c4 * 4 < p.Cd;      // unconditional load, masked at the LDS store (see load_tile)
+      a_reg[i] = *reinterpret_cast<const f32x4*>(ok ? abase + (size_t)r * p.Cd + c4 * 4 : p.dy);
+      a_msk[i] = ok ? 1.f : 0.f;
     }
     // B': source row y is uniform for the tile; x = (b0 + r)*stride - pad + tx varies with the thread's row
     int y = rw_a * p.stride - p.pad + tap_ty;
@@ -716,18 +718,22 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
       const int idx = tid + NT * i;
       const int r = idx / A_PR, c4 = idx - r * A_PR;
       const int m = mb + r, co = co0 + c4 * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < m_end) {
-        const float* src = p.dy + (size_t)m * p.Cd + co;
-        if (cd_vec) {
-          if (co < p.Cd) v = *reinterpret_cast<const f32x4*>(src);
-        } else {
+      if (cd_vec) {
+        // UNCONDITIONAL load from a clamped (always valid) address, masked at the LDS store: a load under a branch whose result is
+        // merged with zeros makes the compiler wait for every load in turn (round 4: ~6 us per tile against 2 us of MFMAs)
+        const bool ok = m < m_end && co < p.Cd;
+        a_reg[i] = *reinterpret_cast<const f32x4*>(p.dy + (ok ? (size_t)m * p.Cd + co : (size_t)0));
+        a_msk[i] = ok ? 1.f : 0.f;
+      } else {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < m_end) {
+          const float* src = p.dy + (size_t)m * p.Cd + co;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (co + e < p.Cd) v[e] = src[e];
         }
+        a_reg[i] = v;
       }
-      a_reg[i] = v;
     }
     if constexpr (VEC) {
       const int tp = nn0 / p.Cs, c0 = nn0 - tp * p.Cs;
@@ -738,9 +744,8 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
         const int r = idx / B_PR, c4 = idx - r * B_PR;
         bool ok;
         const size_t off = gather(buf, r, ty, tx, ok);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(p.x + off + c0 + c4 * 4);
-        b_reg[i] = v;
+        b_reg[i] = *reinterpret_cast<const f32x4*>(p.x + (ok ? off + c0 + c4 * 4 : (size_t)0));      // (see the A operand above)
+        b_msk[i] = ok ? 1.f : 0.f;
       }
     } else {
       // generic channel counts: the thread's 4 columns nn = (tap, channel) are the same for every tile -> their
@@ -782,20 +787,20 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
       for (int i = 0; i < A_IT; ++i) {
         const int idx = tid + NT * i;
         const int r = idx / A_PR, c4 = idx - r * A_PR;
-        *reinterpret_cast<bf16x4*>(&Ah[r * LDA + c4 * 4]) = __builtin_convertvector(a_reg[i], bf16x4);
+        *reinterpret_cast<bf16x4*>(&Ah[r * LDA + c4 * 4]) = __builtin_convertvector(a_reg[i] * a_msk[i], bf16x4);
       }
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int idx = tid + NT * i;
         const int r = idx / B_PR, c4 = idx - r * B_PR;
-        *reinterpret_cast<bf16x4*>(&Bh[r * LDB + c4 * 4]) = __builtin_convertvector(ROWS ? b_reg[i] * b_msk[i] : b_reg[i], bf16x4);
+        *reinterpret_cast<bf16x4*>(&Bh[r * LDB + c4 * 4]) = __builtin_convertvector(b_reg[i] * b_msk[i], bf16x4);
       }
       return;
     }
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(&As[(tid + NT * i) * 4]) = a_reg[i];
+    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(&As[(tid + NT * i) * 4]) = a_reg[i] * a_msk[i];
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(&Bs[(tid + NT * i) * 4]) = ROWS ? b_reg[i] * b_msk[i] : b_reg[i];
+    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(&Bs[(tid + NT * i) * 4]) = b_reg[i] * b_msk[i];
   };
   auto mfma_range = [&](int buf, int kp0, int kp1) {
     const float* As = As2[buf];

@@ -268,43 +268,48 @@ __global__ __launch_bounds__(512) void rgbout16_conv_kernel(Rgbout16Params p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   int b = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);      // neighbouring tiles (shared halo rows / columns) on one XCD
   const int tx = b % p.tiles_x; b /= p.tiles_x;
   const int ty = b % p.tiles_y;
   const int n = b / p.tiles_y;
   const int X0 = tx * RO16_TC, Y0 = ty * RO16_TR;
 
   {
-    const f32x4* src = reinterpret_cast<const f32x4*>(p.wp);
-    f32x4* dst = reinterpret_cast<f32x4*>(wl);
-    for (int e = tid; e < RO16_KSTEPS * 3 * 2; e += 512) dst[e] = src[e];
-  }
-  {
-    // thread = (pixel of the pass, 16-byte piece of its 256-byte channel row): a wave instruction covers 4 pixels x 256 contiguous
-    // bytes = 8 whole lines (with 8 channels per thread every instruction touched 16 half lines and the texture path, ~2.3 cycles
-    // per line, set the pace).  UNCONDITIONAL loads: an out-of-image pixel reads the image's first pixel (in bounds) and is zeroed
-    // when it is parked (a conditional load merged with a zero made the compiler wait for every load in turn: 240 us per launch).
-    constexpr int NPX = RO16_HR * RO16_HC, PPP = 512 / 16, NPASS = (NPX + PPP - 1) / PPP, HALF = (NPASS + 1) / 2;
+    // ONE round trip to memory for the whole prologue: every load of the filter copy and of the halo is issued before the first
+    // LDS store (copy loops of the form "load, store, load, store" cost a memory latency per iteration: five of them in the
+    // first version of this prologue, ~10 us per workgroup with one workgroup per CU).
+    // Halo: thread = (pixel of the pass, 16-byte piece of its 256-byte channel row): a wave instruction covers 4 pixels x 256
+    // contiguous bytes.  UNCONDITIONAL loads: an out-of-image pixel reads the image's first pixel (in bounds) and is zeroed when
+    // it is parked (a load under a branch, merged with a zero, made the compiler wait for every load in turn).
+    constexpr int NPX = RO16_HR * RO16_HC, PPP = 512 / 16, NPASS = (NPX + PPP - 1) / PPP;
+    constexpr int NW = (RO16_KSTEPS * 3 * 2 + 511) / 512;
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wp);
+    f32x4 wv[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) wv[i] = wsrc[min(tid + 512 * i, RO16_KSTEPS * 3 * 2 - 1)];
     const int piece = tid & 15, hpl = tid >> 4;
     const float* img = p.x + (size_t)n * p.H * p.W * 64 + piece * 4;
+    f32x4 v[NPASS];
+    bool okv[NPASS];
 #pragma unroll
-    for (int bt = 0; bt < 2; ++bt) {
-      f32x4 v[HALF];
-      bool okv[HALF];
+    for (int g = 0; g < NPASS; ++g) {
+      const int hp = g * PPP + hpl;
+      const int hr = hp / RO16_HC, hc = hp - hr * RO16_HC;
+      const int gy = Y0 - 3 + hr, gx = X0 - 3 + hc;
+      okv[g] = hp < NPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      v[g] = *reinterpret_cast<const f32x4*>(img + (okv[g] ? ((size_t)gy * p.W + gx) * 64 : 0));
+    }
+    f32x4* wdst = reinterpret_cast<f32x4*>(wl);
 #pragma unroll
-      for (int g = 0; g < HALF; ++g) {
-        const int hp = (bt * HALF + g) * PPP + hpl;
-        const int hr = hp / RO16_HC, hc = hp - hr * RO16_HC;
-        const int gy = Y0 - 3 + hr, gx = X0 - 3 + hc;
-        okv[g] = hp < NPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        v[g] = *reinterpret_cast<const f32x4*>(img + (okv[g] ? ((size_t)gy * p.W + gx) * 64 : 0));
-      }
+    for (int i = 0; i < NW; ++i)
+      if (tid + 512 * i < RO16_KSTEPS * 3 * 2) wdst[tid + 512 * i] = wv[i];
 #pragma unroll
-      for (int g = 0; g < HALF; ++g) {
-        const int hp = (bt * HALF + g) * PPP + hpl;
-        if (hp < NPX) {
-          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<bf16x4*>(&halo[hp * RO16_PS + piece * 8]) = __builtin_convertvector(okv[g] ? v[g] : z4, bf16x4);
-        }
+    for (int g = 0; g < NPASS; ++g) {
+      const int hp = g * PPP + hpl;
+      if (hp < NPX) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<bf16x4*>(&halo[hp * RO16_PS + piece * 8]) = __builtin_convertvector(okv[g] ? v[g] : z4, bf16x4);
       }
     }
   }
