@@ -107,6 +107,11 @@ def hooks_need_live_grads():
     return is_distributed() and _recorder is None
 
 
+def recording():
+    """True while a data-parallel step is being recorded into hipGraph segments (collectives become cuts of the recording)."""
+    return is_distributed() and _recorder is not None
+
+
 def set_recorder(rec):
     """rec: object with ``cut(comm)`` (end the current graph segment, run ``comm()`` after it on every replay) or None."""
     global _recorder

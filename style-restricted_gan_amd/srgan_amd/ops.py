@@ -484,6 +484,7 @@ def _run_conv_wgrad(desc, x, dy, dw, dbias, v_image=None):
 # weight-gradient calls (``srgan_wgrad_defer_begin``): they wait in an arena and run as a few large launches instead of one
 # ~12 us launch per layer (145 per train step).  ``SRGAN_NO_WGRAD_DEFER=1`` keeps the immediate sums.
 _grad_sink = None
+_sink_seed = False
 _defer_depth = 0
 _NO_WGRAD_DEFER = _lib.ab("SRGAN_NO_WGRAD_DEFER")
 _WGRAD_ARENA_BYTES = 1024 << 20
@@ -506,14 +507,21 @@ class fused_param_grads:
     """``device``: where the pass runs (default: the current device) -- the arena of the deferred slab sums lives there and the
     sums run on that device's current stream."""
 
-    def __init__(self, enabled=True, device=None):
+    def __init__(self, enabled=True, device=None, seed=False):
+        """``seed``: a parameter that already HAS a gradient (an earlier scope of the same backward pass bound it) takes this
+        scope's contributions on top of it -- its ``p.grad`` is the sink slot and the kernels add into it -- instead of into a
+        fresh buffer that the scope's exit would add with one elementwise launch per parameter."""
         self._enabled = enabled
         self._device = device
+        self._seed = seed
 
     def __enter__(self):
         global _grad_sink, _defer_depth
+        global _sink_seed
         self._prev = _grad_sink
+        self._prev_seed = _sink_seed
         _grad_sink = {} if self._enabled else None
+        _sink_seed = bool(self._seed and self._enabled)
         self._defer = False
         if self._enabled and not _NO_WGRAD_DEFER and _defer_depth == 0:
             a = _wgrad_arena(self._device)
@@ -525,7 +533,9 @@ class fused_param_grads:
 
     def __exit__(self, et, ev, tb):
         global _grad_sink, _defer_depth
+        global _sink_seed
         sink, _grad_sink = _grad_sink, self._prev
+        _sink_seed = self._prev_seed
         if self._defer:
             _defer_depth = 0
             err = _lib.load().srgan_wgrad_defer_end()          # the queued sums, before anyone binds or reads the buffers
@@ -536,7 +546,7 @@ class fused_param_grads:
                 for p, buf in sink.values():
                     if p.grad is None:
                         p.grad = buf
-                    else:
+                    elif p.grad is not buf:      # (a seeded slot IS p.grad: the kernels have added into it)
                         p.grad.add_(buf)
         return False
 
@@ -552,6 +562,10 @@ def _sink_slots(*params):
     if any(seen) and not all(seen):
         return None
     if not seen[0]:
+        if _sink_seed and all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in params):
+            for p in params:                     # seeded scope: add into the gradient an earlier scope left
+                _grad_sink[id(p)] = (p, p.grad)
+            return [p.grad for p in params], True
         for p in params:
             _grad_sink[id(p)] = (p, torch.empty(p.shape, dtype=torch.float32, device=p.device))
     return [_grad_sink[id(p)][1] for p in params], seen[0]

@@ -298,6 +298,14 @@ class SRGAN_training():
             feat = E.features(src) if hasattr(E, "features") else None
             source_enc_info = self._encode(src, feat)
             pair = feat is not None and L["idt"] > 0
+            # Recorded data-parallel step (round 4): phase 1 reaches the kept target_image graph LAST in its backward (autograd
+            # runs the youngest nodes first and that graph was built in the last discriminator update) -- after E's gradients are
+            # final.  The pass is cut there: phase 1 reads target_image through a detached alias, the first backward stops at the
+            # alias, E's all-reduce is started on the communication stream, and the stale graph is back-propagated from the
+            # alias's gradient UNDER it (the same two contributions summed in the same order: the alias's gradient is what the
+            # engine's input buffer would hold).
+            cut = pair and dp.recording() and self.target_image.requires_grad
+            t_img = self.target_image.detach().requires_grad_(True) if cut else self.target_image
             if pair:
                 # the reference calls E(source) a second time for the identity path: same weights, same input -> same
                 # mu; only the reparametrisation noise is drawn again (keeps the CPU RNG sequence identical).  The
@@ -306,7 +314,7 @@ class SRGAN_training():
                 pick = 0 if self.encoded_feature == "latent" else 1
                 oh = self._onehot("source")
                 c_pair = torch.cat([torch.cat([oh, source_enc_info[pick]], 1), torch.cat([oh, idt_info[pick]], 1)], 0)
-                both = self.G(ops.cat_batch([self.target_image, src]), c_pair)
+                both = self.G(ops.cat_batch([t_img, src]), c_pair)
                 nb = src.shape[0]
                 recon_image, identity_image = both[:nb], both[nb:]
             else:
@@ -318,12 +326,12 @@ class SRGAN_training():
             g_terms, e_terms, rep_terms = [], [], []
             with _frozen(list(self.D.parameters())):       # D's weight grads would be discarded
                 if fused:
-                    outs, logits = dp.unwrap(self.D).forward_logits(self.target_image)
+                    outs, logits = dp.unwrap(self.D).forward_logits(t_img)
                     d_total, parts = ops.d_losses(outs, logits, self._label_dev("target"), self.target_image.shape[0], 1., 0., L["class"])
                     errG_dis, errG_class = parts[0], parts[1]
                     g_terms.append((d_total, 1.0))
                 else:
-                    errG_dis, errG_class = self._d_losses(self.target_image, 1., "target", True)
+                    errG_dis, errG_class = self._d_losses(t_img, 1., "target", True)
                     g_terms += [(errG_dis, 1.0), (errG_class, L["class"])]
             errG_cycle = ops.l1_mean(src, recon_image, 1.0)
             g_terms.append((errG_cycle, L["cycle"]))
@@ -370,10 +378,20 @@ class SRGAN_training():
             # graph): their weight-gradient kernels add the second contribution themselves (ops.fused_param_grads)
             with ops.fused_param_grads(not dp.hooks_need_live_grads(), self.device):
                 total_p1.backward(retain_graph=True)     # target_image's graph is needed again in phase 2
+            redE = None
+            if cut:
+                # E's gradients are final: flatten its buckets and start their all-reduce (a cut of the recording), then run the
+                # stale-graph generator backward under it; the generator's parameters take their second contribution on top of
+                # the first (ops.fused_param_grads(seed=True): the weight-gradient kernels add into p.grad)
+                redE = self._reduce_start("E", self.optE)
+                dp.launch_pending()
+                with ops.fused_param_grads(True, self.device, seed=True):
+                    self.target_image.backward(t_img.grad, retain_graph=True)
         # Data parallel: E's buckets go out first, G's behind them on the same communication stream; E's optimiser step, its
         # repack and phase 2's E(source) forward (which needs the new E, not the new G) then run UNDER G's all-reduce.  The two
         # Adam steps touch disjoint parameters, so their order does not matter.
-        redE = self._reduce_start("E", self.optE)
+        if redE is None:
+            redE = self._reduce_start("E", self.optE)
         redG = self._reduce_start("G", self.optG)
         dp.launch_pending(then_wait=redE)
         if redE is not None:
@@ -523,7 +541,7 @@ class SRGAN_training():
         re-create), the second captures and replays, later ones only stage the step's inputs (image batch, labels, the
         CPU-generator noise drawn in the reference's order) into static device buffers and launch the graph.  Inputs of
         another shape (an epoch's last partial batch) run eagerly.  Results are bit-identical to eager execution.
-        Under a process group the recording is cut where a collective starts and where its result is needed (2k + 5 graph
+        Under a process group the recording is cut where a collective starts and where its result is needed (2k + 6 graph
         segments; between them the all-reduces are enqueued on the communication stream and run UNDER the following segment --
         the next translation, phase 1's forward passes, E's optimiser step: ``_Recording``, ``dp.launch_pending``); if any rank
         fails to record, all ranks drop graph mode together and continue eagerly
@@ -843,7 +861,7 @@ class _Recording:
     under the last discriminator all-reduce, E's optimiser step and phase 2's E(source) under G's -- run UNDER the collectives;
     the "wait" callable makes the compute stream wait for the ``done`` events right before the optimiser-step segment.  Nothing
     of RCCL is captured and no stream is forked inside a capture: the collectives stay ordinary eager calls on static buffers in
-    a fixed order.  2k + 5 segments per step (k x (start, wait), the all-gather, start(E, G) + wait(E), wait(G),
+    a fixed order.  2k + 6 segments per step (k x (start, wait), the all-gather, start(E) inside phase 1's backward, start(G) + wait(E), wait(G),
     start(G) + wait(G): a wait that follows its start directly rides in the same callable).  All segments allocate from one private pool and are replayed in recording order, so a tensor made in one segment
     is valid in the following ones."""
 

@@ -70,8 +70,9 @@ def _run(rank, world, out_q=None, kl=0.0, graph=False, recipe=None):
         assert sg._graph is None and not sg.graph_active          # every rank gave the recording up together
     elif graph:
         # data parallel: the recording is cut where a collective starts and where its result is needed -- K x (start, wait) for
-        # the discriminator, the mu all-gather, start(E + G) with wait(E) / wait(G), start(G) with its wait: 2K + 5 graph segments
-        assert sg.graph_active and len(sg._graph.graph.segments) == (2 * K + 5 if dp.is_distributed() else 1)
+        # the discriminator, the mu all-gather, start(E) inside phase 1's backward (round 4), start(G) with wait(E), wait(G),
+        # start(G) with its wait: 2K + 6 graph segments
+        assert sg.graph_active and len(sg._graph.graph.segments) == (2 * K + 6 if dp.is_distributed() else 1)
         if dp.is_distributed():
             _check_overlap_order(sg._graph.graph.trace)
     state = {f"{n}.{k}": v.detach().cpu().numpy().copy() for n, net in (("G", sg.G), ("D", sg.D), ("E", sg.E)) for k, v in net.state_dict().items()}
@@ -89,16 +90,19 @@ def _check_overlap_order(tr):
     with E's optimiser step.  (Whether the two streams really run side by side is the device's business -- and with gloo the
     all-reduce blocks the host -- so the ORDER of the enqueues is what is asserted.)"""
     kinds = [k for k, _ in tr if k != "segment"]
-    assert kinds == ["all_reduce", "wait"] * K + ["all_gather", "all_reduce", "wait", "all_reduce"], kinds
+    assert kinds == ["all_reduce", "wait"] * K + ["all_gather", "all_reduce", "all_reduce", "wait", "all_reduce"], kinds
     pos = {(k, i): n for n, (k, i) in enumerate(tr)}
     starts = [i for k, i in tr if k == "all_reduce"]
     waits = [i for k, i in tr if k == "wait"]
     for d in range(K):                       # discriminator update d: start after segment s, wait after segment s + 1
         s, w = starts[d], waits[d]
         assert w == s + 1 and pos[("all_reduce", s)] < pos[("segment", s + 1)] < pos[("wait", w)], (d, s, w)
-    # phase 1: start(E, G) (E awaited in the same callable), wait(G) one segment (E's step + E(source)) later
-    s, wg = starts[K], waits[K]
-    assert wg == s + 1 and pos[("all_reduce", s)] < pos[("segment", s + 1)] < pos[("wait", wg)]
+    # phase 1 (round 4): start(E) INSIDE the backward -- the segment launched right after it holds the stale-graph generator
+    # backward, which therefore runs under E's all-reduce; start(G) (E awaited in the same callable) after that segment,
+    # wait(G) one more segment (E's step + E(source)) later
+    se, sgen, wg = starts[K], starts[K + 1], waits[K]
+    assert sgen == se + 1 and wg == sgen + 1
+    assert pos[("all_reduce", se)] < pos[("segment", se + 1)] < pos[("all_reduce", sgen)] < pos[("segment", sgen + 1)] < pos[("wait", wg)]
 
 
 def _worker(rank, world, port, out_q, kl=0.0, backend="gloo", force=False, graph=False, recipe=None, inject=None):
