@@ -19,3 +19,12 @@ run c3_bf16 --batch-per-gpu 64 --dtype bf16 &&
 run c3_fp32 --batch-per-gpu 64 &&
 run c4_bf16 --size 256 --batch-per-gpu 16 --dtype bf16 &&
 run c4_fp32 --size 256 --batch-per-gpu 16
+# the data-parallel code path on ONE rank over RCCL (real collectives on the communication stream, 2k + 6 graph segments), and eager
+dp1() {
+  tag=$1; shift
+  SRGAN_DP_FORCE=1 "$@" python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-micro > $O/$tag.json 2> $O/$tag.err || { echo "$tag FAILED"; return 1; }
+  python3 -c "import json; d=json.loads(open('$O/$tag.json').read().strip().splitlines()[-1]); print('%-12s %8.1f images/s %7.2f ms/step  %s' % ('$tag', d['value'], d['ms_per_step'], d['config']['execution'][:70]))"
+}
+python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-micro > $O/c1_fp32_plain.json 2> $O/c1_fp32_plain.err && python3 -c "import json; d=json.loads(open('$O/c1_fp32_plain.json').read().strip().splitlines()[-1]); print('%-12s %8.1f images/s %7.2f ms/step' % ('c1 plain', d['value'], d['ms_per_step']))"
+dp1 dp1_graph env
+dp1 dp1_eager env SRGAN_DP_GRAPH=0

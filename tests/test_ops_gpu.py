@@ -1135,3 +1135,96 @@ def test_rgb_input_form_bf16_compute_mode(ops):
     finally:
         ops.set_compute_dtype("fp32")
         ops.invalidate_packed()
+
+
+def test_instance_norm_in_place_call_takes_the_separate_finalize(ops):
+    """with the statistics finalize folded into the apply pass every workgroup re-reads the shift sample x[n][0][c]
+    while workgroup 0 may already be storing y there -- an in-place call (y == x) through the C ABI now takes the separate
+    finalize launch and must give the out-of-place result (to fp32 rounding)."""
+    import ctypes
+    from srgan_amd import _lib
+    lib = _lib.load()
+    n, c, h, w = 4, 64, 96, 96                     # two-pass shape (9216 pixels), C | 1024
+    x = (rnd(n, h, w, c, seed=21) * 3 + 1).cuda()
+    sc, sh = (1 + 0.2 * rnd(n, c, seed=22)).cuda(), (0.3 * rnd(n, c, seed=23)).cuda()
+    nb = lib.srgan_instnorm_workspace(n, h * w, c)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def run(src, dst):
+        mean, rstd = torch.empty(n * c, device="cuda"), torch.empty(n * c, device="cuda")
+        _lib.check(lib.srgan_instnorm_fwd(P(src), P(sc), P(sh), None, P(dst), P(mean), P(rstd), n, h * w, c, 1e-5, ops.ACT_RELU, 0.0,
+                                          P(ws), nb, st), "instnorm_fwd")
+        return mean, rstd
+    y = torch.empty_like(x)
+    m0, r0 = run(x, y)
+    xi = x.clone()
+    m1, r1 = run(xi, xi)
+    torch.cuda.synchronize()
+    # (the stand-alone finalize kernel may contract the same expression differently: equal to fp32 rounding, not bit for bit)
+    close(m1, m0, 1e-6)
+    close(r1, r0, 1e-6)
+    close(xi, y, 2e-6)
+
+
+def test_wgrad_arena_is_one_per_device(ops):
+    """the deferred slab sums' arena was keyed by (device, raw stream pointer) -- every re-recorded step (a new capture
+    stream each time) took another GiB.  One arena per device, whatever stream opens the scope."""
+    arena_keys = lambda: [k for k in ops._workspaces if k[0] == "wgrad_arena"]
+    saved = ops._WGRAD_ARENA_BYTES
+    for k in arena_keys():
+        del ops._workspaces[k]
+    ops._WGRAD_ARENA_BYTES = 8 << 20
+    try:
+        w = (rnd(64, 64, 3, 3, seed=1) / 24).cuda().requires_grad_(True)
+        x = rnd(2, 64, 16, 16, seed=2).cuda()
+        for stream in (torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()):
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                w.grad = None
+                with ops.pack_cache(), ops.fused_param_grads(True):
+                    ops.conv2d(x, w, None, 1, 1).sum().backward()
+            torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+        assert len(arena_keys()) == 1, arena_keys()
+    finally:
+        ops._WGRAD_ARENA_BYTES = saved
+        for k in arena_keys():
+            del ops._workspaces[k]
+        ops.invalidate_packed()
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 96, 96), (32, 128, 16, 16)])      # two-pass kernels; slab kernels (32 x 4 slabs)
+@pytest.mark.parametrize("io", [(False, True), (True, True), (True, False)])
+def test_instance_norm_16bit_io(ops, shape, io):
+    """Round 4: instance norm with an fp32 or bf16 input and a bf16 or fp32 output (the norms between the generator's stride-2
+    convolutions in the bf16 mode): equal to the fp32 op on the bf16-ROUNDED input, output rounded once; the backward takes the
+    gradient in the output's type and returns dx in the input's."""
+    n, c, h, w = shape
+    x16, y16 = io
+    ops.set_compute_dtype("bf16")
+    try:
+        assert ops.norm_io_applicable(n, c, h, w)
+        x = rnd(n, c, h, w, seed=1) * 2 + 0.5
+        sc, sh = 1 + 0.3 * rnd(n, c, seed=2), 0.5 * rnd(n, c, seed=3)
+        gy = rnd(n, c, h, w, seed=4)
+        xr = (_bf16_round(x) if x16 else x).clone().requires_grad_(True)
+        scr, shr = sc.clone().requires_grad_(True), sh.clone().requires_grad_(True)
+        yr = torch.relu(F.instance_norm(xr, eps=1e-5) * scr[:, :, None, None] + shr[:, :, None, None])
+        gyr = _bf16_round(gy) if y16 else gy
+        yr.backward(gyr)
+        nhwc = lambda t, dt: t.permute(0, 2, 3, 1).contiguous().to(dt).cuda().permute(0, 3, 1, 2)
+        xd = nhwc(x, torch.bfloat16 if x16 else torch.float32).requires_grad_(True)
+        scd, shd = sc.cuda().requires_grad_(True), sh.cuda().requires_grad_(True)
+        y = ops.instance_norm_act_io(xd, scd, shd, ops.ACT_RELU, 0.0, 1e-5, y16)
+        assert y.dtype == (torch.bfloat16 if y16 else torch.float32)
+        y.backward(nhwc(gy, y.dtype))
+        assert xd.grad.dtype == xd.dtype
+        tol_y = 6e-3 if y16 else 2e-5                       # one bf16 rounding of the result: 2^-8 relative
+        close(y.float(), yr, tol_y)
+        close(xd.grad.float(), xr.grad, 6e-3 if x16 else 1e-4)
+        close(scd.grad, scr.grad, 1e-4)
+        close(shd.grad, shr.grad, 1e-4)
+    finally:
+        ops.set_compute_dtype("fp32")
