@@ -79,8 +79,8 @@ def test_train_trajectory_vs_reference_full_size(golden_dir):
 
 def test_train_step_bf16_compute_mode_full_size(golden_dir):
     """BASELINE configs [2]-[4] run the convolutions on the bf16 MFMA (fp32 accumulation, fp32 storage): the full-size train
-    step must track the fp32 reference trajectory within bf16 rounding of the conv operands -- 1e-2 on every loss over two
-    steps (measured: <= 6e-3)."""
+    step must track the fp32 reference trajectory within bf16 rounding of the conv operands -- 5e-3 on every loss over two
+    steps (round 4, tightened from 1e-2; measured 1.0e-3 with the 16-bit activation storage and the bf16 RGB kernels)."""
     from srgan_amd import ops
     gold = np.load(os.path.join(golden_dir, "train_F_b2_k1.npz"))
     ops.set_compute_dtype("bf16")
@@ -88,7 +88,7 @@ def test_train_step_bf16_compute_mode_full_size(golden_dir):
         _, traj = run_hip("F", 2, 1, 2, seed=0)
     finally:
         ops.set_compute_dtype("fp32")
-    np.testing.assert_allclose(traj, gold["losses"], rtol=1e-2)
+    np.testing.assert_allclose(traj, gold["losses"], rtol=5e-3)
     assert not np.allclose(traj, gold["losses"], rtol=1e-6)      # the mode really changed the arithmetic
 
 
@@ -272,7 +272,8 @@ def test_bs64_step_vs_oracle_tier_T():
     ("train_T256_b2_k2", "T256", 2, 2, 2, False, 256)])            # configs[4]: 256x256 geometry + bf16 convolutions
 def test_bf16_mode_on_config_recipes_tier_T(golden_dir, name, tier, batch, k, steps, pre, size):
     """The bf16 MFMA compute mode combined with the recipes BASELINE configs[2] / [4] name, against the reference's own fp32
-    trajectories within bf16 rounding of the conv operands (3e-2)."""
+    trajectories within bf16 rounding of the conv operands: 2e-3 (round 4, tightened from 3e-2; measured 1.4e-4 .. 1.9e-4 --
+    at tier-T widths only the layers with >= 32 channels multiply in bf16; scratch/bf16_deviation.py prints the numbers)."""
     from srgan_amd import ops
     gold = np.load(os.path.join(golden_dir, name + ".npz"))
     ops.set_compute_dtype("bf16")
@@ -280,7 +281,7 @@ def test_bf16_mode_on_config_recipes_tier_T(golden_dir, name, tier, batch, k, st
         _, traj = run_hip(tier, batch, k, steps, seed=0, pretrained_e=pre, size=size)
     finally:
         ops.set_compute_dtype("fp32")
-    np.testing.assert_allclose(traj, gold["losses"], rtol=3e-2)
+    np.testing.assert_allclose(traj, gold["losses"], rtol=2e-3)
 
 
 def test_latent_mode_and_generic_encoder_path():
