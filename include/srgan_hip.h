@@ -253,11 +253,14 @@ int srgan_instnorm_slab_bwd_io(const void* x, int x_bf16, const void* dy, int dy
 /* Instance norm (+ affine, activation) with fp32 or bf16 tensors on either side, for the shapes the slab kernels or the fast
  * two-pass kernels serve (srgan_instnorm_io_applicable: HW <= 1024 with C % 32 == 0, or C | 1024 with C % 4 == 0): the norms
  * between the generator's down / up convolutions when the bf16 mode keeps those activations in 16 bits (pyfiles/model.py:54-67,
- * 228, 231, 245-246).  Statistics, scale / shift and their gradients are fp32.  Backward: dx has x's type.  ws:
+ * 228, 231, 245-246) and, on maps too large for the slab kernels, the norms inside a residual block with bf16 intermediates
+ * (`res`: fp32 skip tensor added to an fp32 result; pyfiles/model.py:86-94).  Statistics, scale / shift and their gradients are
+ * fp32.  Backward: dx has x's type.  ws:
  * srgan_instnorm_workspace(N, HW, C) bytes. */
 int srgan_instnorm_io_applicable(int N, int HW, int C);
-int srgan_instnorm_fwd_io(const void* x, int x_bf16, const float* scale, const float* shift, void* y, int y_bf16, float* mean,
-                          float* rstd, int N, int HW, int C, float eps, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int srgan_instnorm_fwd_io(const void* x, int x_bf16, const float* scale, const float* shift, const float* res, void* y, int y_bf16,
+                          float* mean, float* rstd, int N, int HW, int C, float eps, int act, float slope, void* ws, size_t ws_bytes,
+                          void* stream);
 int srgan_instnorm_bwd_io(const void* x, int x_bf16, const void* dy, int dy_bf16, const float* scale, const float* shift,
                           const float* mean, const float* rstd, void* dx, int dx_bf16, float* dscale, float* dshift, int N, int HW,
                           int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);

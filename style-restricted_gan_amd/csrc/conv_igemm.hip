@@ -46,8 +46,8 @@ static const char* const kProfNames[] = {
     "wino43_kernel", "wino43_input_kernel", "rgbin_conv_kernel", "rgb_wgrad_kernel", "wino43_wgrad_kernel", "wino43_dy_kernel",
     "halo16_kernel", "halo16_wgrad_kernel", "halo16s2_wgrad_kernel", "halo16t_kernel", "rgbout_conv_kernel", "halo16s_kernel",
     // HBM-bound passes (norm.hip): the "flops" slot of their brackets carries ALGORITHMIC BYTES (tensor bytes each pass must move)
-    "in_stats_partial", "in_apply", "in_bwd_partial", "in_bwd_apply", "in_fwd_slab", "in_bwd_slab"};
-constexpr int kProfKernels = 36;
+    "in_stats_partial", "in_apply", "in_bwd_partial", "in_bwd_apply", "in_fwd_slab", "in_bwd_slab", "igemm16_kernel"};
+constexpr int kProfKernels = 37;
 
 struct ProfScope {
   bool on;
@@ -113,6 +113,9 @@ struct IgemmParams {
   int m_tiles, n_tiles;
   int ksplit, kt_per_split;      // split-K (blockIdx.z): K tiles [z * kt_per_split, ...) -> partial sums into dst + z * split_stride
   long long split_stride;
+#ifdef SRGAN_EXPERIMENTS
+  int exp;                       // timing ablations of igemm16_kernel (wrong results): scratch/README.md
+#endif
 };
 
 constexpr int BK = 32;
@@ -483,6 +486,281 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
           v = apply_act(v, p.act, p.slope);
           dst_base[(size_t)o * p.Cd + n] = v;
         }
+      }
+    }
+  }
+}
+
+// ---- bf16 mode: implicit GEMM with 64-deep K tiles (round 4) --------------------------------------------------------------
+// The layers of the bf16 compute mode that no LDS-resident-patch kernel serves (the style encoder's 3x3 reflect-padded
+// convolutions on 62 / 31 / 15 / 7-pixel maps, the discriminators' 4x4 stride-2 layers on 16- and 8-pixel maps, and the input
+// gradients of both; pyfiles/model.py:100-121, 128-160) ran on igemm_kernel<.., BF>: a 32-deep K tile per barrier with 2-8 MFMAs
+// per wave, ~100 vector instructions of address arithmetic, masking and conversion around them and fp32 weights (158-290
+// TFLOP/s).  Here: 128 x BN output tiles, 4 waves of 64 x (BN / 2), K tiles of 64 channels of ONE tap (Cs % 64 == 0), 16 or 32
+// MFMAs (32x32x16 bf16) per wave and barrier; the gathered rows are masked by a select on the packed bf16 pairs; fragments of
+// K step q + 1 are read under the MFMAs of step q; tile kt + 1 goes to LDS in the middle of tile kt and the loads of tile
+// kt + 2 are issued behind it.  Rows are 144 bytes apart in LDS (36 banks: the 16-lane groups of ds_read_b128 and the 8-lane
+// row segments of ds_write_b64 land on distinct banks).  Source, weights (packed fp32 [phases][Npad][Kpad], as for
+// igemm_kernel) and destination stay fp32 in HBM; operands are rounded to bf16 (RNE) on the way into LDS, exactly as in
+// igemm_kernel<.., BF>, so the two kernels produce the same sums up to fp32 summation order.
+constexpr int BK16 = 64;
+constexpr int LDH16 = BK16 + 8;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
+  constexpr int BM = 128;
+  constexpr int TN = BN / 64;               // 32-wide column blocks per wave (2 waves across N)
+  constexpr int A_IT = BM / 32, B_IT = BN / 32;
+  static_assert(BN == 128 || BN == 64, "BN");
+  __shared__ __attribute__((aligned(16))) unsigned short Ah2[2][BM * LDH16];
+  __shared__ __attribute__((aligned(16))) unsigned short Bh2[2][BN * LDH16];
+  __shared__ __attribute__((aligned(16))) int row_o[BM];
+
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // neighbouring pixel tiles (shared image rows) on one XCD
+  const int mt = bid % p.m_tiles, nt = bid / p.m_tiles;
+  const int phase = blockIdx.y;
+  const int s = p.stride;
+  int py = 0, px = 0;
+  if (p.mode == 1) { py = phase / s; px = phase % s; }
+  const int sgn = p.mode == 0 ? 1 : -1;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // window origin and destination pixel of GEMM row m.  The two divisions are float multiplications by a reciprocal with one
+  // correction step (exact for m < 2^23, igemm16_ok): the prologue runs once per 128 x BN tile and K loops here are as short as
+  // 9 tiles, so the ~60-instruction integer divisions and per-tap loops of igemm_kernel's prologue cost as much as the loop
+  const int hw_g = p.Hg * p.Wg;
+  const float inv_hw = 1.f / (float)hw_g, inv_w = 1.f / (float)p.Wg;
+  const int qy = p.mode == 1 ? (py + p.pad) / s : 0, qx = p.mode == 1 ? (px + p.pad) / s : 0;
+  auto fdiv = [](int m, int d, float inv, int& q, int& r) __attribute__((always_inline)) {
+    q = (int)((float)m * inv);
+    r = m - q * d;
+    if (r >= d) { ++q; r -= d; }
+    if (r < 0) { --q; r += d; }
+  };
+  auto row_geom = [&](int m, int& n, int& y0, int& x0, int& o) __attribute__((always_inline)) {
+    n = 0; y0 = -(1 << 28); x0 = -(1 << 28); o = -1;
+    if (m < p.M) {
+      int rem, a, b;
+      fdiv(m, hw_g, inv_hw, n, rem);
+      fdiv(rem, p.Wg, inv_w, a, b);
+      if (p.mode == 0) {
+        y0 = a * s - p.pad; x0 = b * s - p.pad + p.xpad_off;
+        o = (n * p.Hd + a) * p.Wd + b;
+      } else {
+        const int oy = a * s + py, ox = b * s + px;
+        if (oy < p.Hd && ox < p.Wd) {
+          y0 = a + qy; x0 = b + qx;
+          o = (n * p.Hd + oy) * p.Wd + ox;
+        }
+      }
+    }
+  };
+  if (tid < BM) {
+    int n, y0, x0, o;
+    row_geom(m0 + tid, n, y0, x0, o);
+    row_o[tid] = o;
+  }
+
+  const float* wp = p.wp + (size_t)phase * p.Npad * p.Kpad;
+  const int kt0 = p.ksplit > 1 ? (int)blockIdx.z * p.kt_per_split : 0;
+  const int nk = p.ksplit > 1 ? max(min(p.Kpad / BK16 - kt0, p.kt_per_split), 0) : p.Kpad / BK16;
+
+  // a thread stages 4 pixel rows (8 lanes per row: floats [4 seg, 4 seg + 4) and [32 + 4 seg, ...) of the 64-channel slice);
+  // per row ONE 32-bit byte offset, the valid tap rows / tap columns as two 8-bit ranges (zero padding is separable) and, for
+  // reflect padding, the mirrored tap displacements as nibbles
+  const unsigned seg16 = (tid & 7) * 16;
+  unsigned voff[A_IT], vmask[A_IT];          // vmask: bits 0-7 valid tap rows, bits 8-15 valid tap columns
+  unsigned mapy[A_IT], mapx[A_IT];
+  const long long bias = ((long long)max(p.pad, p.Ty) * p.Ws + max(p.pad, p.Tx)) * p.Cs;   // keeps offsets >= 0
+  auto bits = [](int lo, int hi) -> unsigned { return hi >= lo ? ((2u << (hi & 31)) - 1u) & ~((1u << (lo & 31)) - 1u) : 0u; };
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int n, y0, x0, o;
+    row_geom(m0 + (tid >> 3) + 32 * i, n, y0, x0, o);
+    const bool rowok = y0 > -(1 << 27);
+    const long long lin = rowok ? ((long long)(n * p.Hs + y0) * p.Ws + x0) * p.Cs : 0;
+    voff[i] = (unsigned)((lin + bias) * 4) + seg16;
+    unsigned m = 0, my = 0, mx = 0;
+    if (p.reflect) {
+      if (rowok) {
+        m = 0xffffu;
+        for (int t = 0; t < p.Ty; ++t) {
+          int y = y0 + t;
+          y = y < 0 ? -y : y;
+          y = y >= p.Hs ? 2 * p.Hs - 2 - y : y;
+          my |= (unsigned)(y - y0) << (4 * t);
+        }
+        for (int t = 0; t < p.Tx; ++t) {
+          int x = x0 + t;
+          x = x < 0 ? -x : x;
+          x = x >= p.Ws ? 2 * p.Ws - 2 - x : x;
+          mx |= (unsigned)(x - x0) << (4 * t);
+        }
+      }
+    } else if (rowok) {
+      // tap ty reads image row y0 + sgn ty: valid for ty in [lo, hi]
+      const unsigned ym = sgn > 0 ? bits(max(0, -y0), min(p.Ty - 1, p.Hs - 1 - y0)) : bits(max(0, y0 - p.Hs + 1), min(p.Ty - 1, y0));
+      const unsigned xm = sgn > 0 ? bits(max(0, -x0), min(p.Tx - 1, p.Ws - 1 - x0)) : bits(max(0, x0 - p.Ws + 1), min(p.Tx - 1, x0));
+      m = ym | (xm << 8);
+    }
+    vmask[i] = m; mapy[i] = my; mapx[i] = mx;
+  }
+  int tap_y = 0, tap_x = 0, tap_c = 0;       // position of the NEXT tile to load (wave-uniform)
+  if (kt0 > 0) {
+    const int k0 = kt0 * BK16, t = k0 / p.Cs;
+    tap_c = k0 - t * p.Cs;
+    tap_y = t / p.Tx;
+    tap_x = t - tap_y * p.Tx;
+  }
+  // weight rows of this thread: n0 + (tid >> 3) + 32 i, clamped to the packed rows (columns >= Cd are never stored)
+  unsigned woff[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) woff[i] = (unsigned)(((size_t)min(n0 + (tid >> 3) + 32 * i, p.Npad - 1) * p.Kpad) * 4) + seg16;
+
+  f32x4 a_reg[A_IT][2], b_reg[B_IT][2];
+  bool a_ok[A_IT];
+  auto load_tiles = [&](int kt_rel) __attribute__((always_inline)) {
+    const int k0 = (kt0 + kt_rel) * BK16;
+    const unsigned cs4 = p.Cs * 4;
+    const long long tap_lin = p.reflect ? 0 : (long long)sgn * (tap_y * p.Ws + tap_x) * p.Cs;
+    const char* sb = reinterpret_cast<const char*>(p.src) + (tap_lin + tap_c - bias) * 4;   // wave-uniform
+    const unsigned safe = (unsigned)((bias - tap_lin) * 4) + seg16;                          // -> src + tap_c
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const bool ok = ((vmask[i] >> tap_y) & (vmask[i] >> (8 + tap_x)) & 1u) != 0;
+      // reflect: mirrored displacement from the nibble maps (all-zero maps otherwise)
+      const unsigned dyv = (mapy[i] >> (4 * tap_y)) & 15u, dxv = (mapx[i] >> (4 * tap_x)) & 15u;
+      unsigned off = voff[i] + (dyv * p.Ws + dxv) * cs4;
+      off = ok ? off : safe;
+#ifdef SRGAN_EXPERIMENTS
+      if (p.exp & 1) { a_reg[i][0] = f32x4{1.f, 1.f, 1.f, 1.f}; a_reg[i][1] = a_reg[i][0]; a_ok[i] = ok; continue; }
+#endif
+      a_reg[i][0] = *reinterpret_cast<const f32x4*>(sb + off);
+      a_reg[i][1] = *reinterpret_cast<const f32x4*>(sb + off + 128);
+      a_ok[i] = ok;
+    }
+    tap_c += BK16;
+    const int wc = tap_c == p.Cs;
+    tap_c = wc ? 0 : tap_c;
+    tap_x += wc;
+    const int wx = tap_x == p.Tx;
+    tap_x = wx ? 0 : tap_x;
+    tap_y += wx;
+    const char* wb = reinterpret_cast<const char*>(wp) + (size_t)k0 * 4;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+#ifdef SRGAN_EXPERIMENTS
+      if (p.exp & 2) { b_reg[i][0] = f32x4{1.f, 1.f, 1.f, 1.f}; b_reg[i][1] = b_reg[i][0]; continue; }
+#endif
+      b_reg[i][0] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
+      b_reg[i][1] = *reinterpret_cast<const f32x4*>(wb + woff[i] + 128);
+    }
+  };
+  auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+    unsigned short* Ah = Ah2[buf];
+    unsigned short* Bh = Bh2[buf];
+    const int seg = tid & 7;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int r = (tid >> 3) + 32 * i;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x2 v = __builtin_bit_cast(u32x2, __builtin_convertvector(a_reg[i][h], bf16x4));
+        v[0] = a_ok[i] ? v[0] : 0u;
+        v[1] = a_ok[i] ? v[1] : 0u;
+        *reinterpret_cast<u32x2*>(&Ah[r * LDH16 + h * 32 + seg * 4]) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int r = (tid >> 3) + 32 * i;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        *reinterpret_cast<bf16x4*>(&Bh[r * LDH16 + h * 32 + seg * 4]) = __builtin_convertvector(b_reg[i][h], bf16x4);
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  bf16x8 ah[2][2], bh[2][TN];
+  auto read_frags = [&](int buf, int q, int slot) __attribute__((always_inline)) {
+    const unsigned short* Ah = Ah2[buf];
+    const unsigned short* Bh = Bh2[buf];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ah[slot][i] = *reinterpret_cast<const bf16x8*>(&Ah[(wm * 64 + i * 32 + lr) * LDH16 + q * 16 + lh * 8]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bh[slot][j] = *reinterpret_cast<const bf16x8*>(&Bh[(wn * (BN / 2) + j * 32 + lr) * LDH16 + q * 16 + lh * 8]);
+  };
+  auto mma = [&](int slot) __attribute__((always_inline)) {
+#ifdef SRGAN_EXPERIMENTS
+    if (p.exp & 4) return;
+#endif
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot][i], bh[slot][j], acc[i][j], 0, 0, 0);
+  };
+
+  if (nk > 0) {
+    load_tiles(0);
+    store_tiles(0);
+    if (nk > 1) load_tiles(1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      read_frags(cur, 0, 0);
+      read_frags(cur, 1, 1);
+      mma(0);
+      read_frags(cur, 2, 0);
+      mma(1);
+      if (kt + 1 < nk) store_tiles(cur ^ 1);       // tile kt + 1: requested a whole tile ago
+      read_frags(cur, 3, 1);
+      if (kt + 2 < nk) load_tiles(kt + 2);
+      mma(0);
+      mma(1);
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float* const dst_base = p.ksplit > 1 ? p.dst + (size_t)blockIdx.z * p.split_stride : p.dst;
+#ifdef SRGAN_EXPERIMENTS
+  if ((p.exp & 8) && acc[0][0][0] != 12345.f) return;
+#endif
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const bool relu = p.act == SRGAN_ACT_RELU;
+  const float neg = p.act == SRGAN_ACT_LRELU ? p.slope : 1.f;      // branch-free apply_act (same values)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    i32x4 ro[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ro[g] = *reinterpret_cast<const i32x4*>(&row_o[wm * 64 + i * 32 + 8 * g + 4 * lh]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + lr;
+      const bool nok = n < p.Cd;
+      const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int o = ro[e >> 2][e & 3];
+        const float v = acc[i][j][e] + bv;
+        if (nok && o >= 0) dst_base[(size_t)o * p.Cd + n] = v > 0.f ? v : (relu ? 0.f : v * neg);
       }
     }
   }
@@ -1109,6 +1387,29 @@ int launch_igemm(const IgemmParams& p, int phases, bool vec, hipStream_t st, dou
 int run_igemm_tiles(IgemmParams p, int phases, hipStream_t st, double flops);
 int run_igemm(IgemmParams p, int phases, hipStream_t st, double flops, float* slab = nullptr);
 
+// bf16 mode: layers whose K tiles are 64 channels of one tap run on igemm16_kernel (128 x 128 tiles; 128 x 64 for 64 outputs)
+static bool igemm16_ok(const IgemmParams& p) {
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_IGEMM16");
+  if (off || !compute_bf16() || p.Cs % BK16 != 0 || p.Kpad != p.K || p.Cd < 64 || p.Ty > 8 || p.Tx > 8 || p.M >= (1 << 23)) return false;
+  // byte offsets of the gather are 32-bit (as in igemm_kernel's vector path)
+  return (long long)p.NB * p.Hs * p.Ws * p.Cs < (1LL << 29) && (long long)p.Npad * p.Kpad < (1LL << 29);
+}
+static int igemm16_bn(const IgemmParams& p) { return p.Cd <= 64 ? 64 : 128; }
+
+static int launch_igemm16(IgemmParams p, int phases, hipStream_t st, double flops) {
+  const int bn = igemm16_bn(p);
+#ifdef SRGAN_EXPERIMENTS
+  p.exp = (int)SRGAN_AB_INT("SRGAN_IG16_EXP", 0);
+#endif
+  p.m_tiles = (int)ceil_div(p.M, 128);
+  p.n_tiles = (int)ceil_div(p.Cd, bn);
+  ProfScope scope(36, flops, st);
+  dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)phases, (unsigned)std::max(p.ksplit, 1));
+  if (bn == 64) hipLaunchKernelGGL(igemm16_kernel<64>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(igemm16_kernel<128>, grid, dim3(256), 0, st, p);
+  return check_launch("igemm16_kernel");
+}
+
 // ---- split-K for layers with few pixel tiles and long K loops (the encoder's 7x7 / 3x3 maps, the discriminators' 8x8 / 4x4
 // maps): 64-200 four-wave workgroups walking 64-144 K tiles leave most SIMDs with one wave and nothing to hide its loads
 // behind (22-48 TFLOP/s).  The K range is cut into `ksplit` pieces (grid z), every piece writes raw partial sums into its own
@@ -1138,10 +1439,11 @@ static SplitKPlan plan_splitk(const IgemmParams& p, int phases) {
   SplitKPlan s{1, 0, (long long)p.NB * p.Hd * p.Wd * p.Cd};
   static const bool off = SRGAN_AB_SET("SRGAN_NO_SPLITK");
   static const int target = SRGAN_AB_INT("SRGAN_SPLITK_TARGET", 768);
-  const TileChoice tc = final_tile(p);
+  const bool k16 = igemm16_ok(p);
+  const TileChoice tc = k16 ? TileChoice{128, igemm16_bn(p)} : final_tile(p);
   if (off || tc.BM == 256 || (p.Cd & 3) != 0 || s.dst_elems >= (1LL << 28)) return s;
   const long long wgs = ceil_div(p.M, tc.BM) * ceil_div(p.Cd, tc.BN) * phases;
-  const int nk = p.Kpad / BK;
+  const int nk = p.Kpad / (k16 ? BK16 : BK);      // kt_per_split counts the serving kernel's K tiles
   long long ks = std::min<long long>(8, std::min<long long>(target / std::max<long long>(wgs, 1), nk / 8));
   if (ks < 2) return s;
   s.kt_per_split = (int)ceil_div(nk, ks);
@@ -1178,6 +1480,7 @@ int run_igemm(IgemmParams p, int phases, hipStream_t st, double flops, float* sl
 }
 
 int run_igemm_tiles(IgemmParams p, int phases, hipStream_t st, double flops) {
+  if (igemm16_ok(p)) return launch_igemm16(p, phases, st, flops);
   TileChoice tc = choose_tile(p.M, p.Cd);
   p.m_tiles = (int)ceil_div(p.M, tc.BM);
   p.n_tiles = (int)ceil_div(p.Cd, tc.BN);

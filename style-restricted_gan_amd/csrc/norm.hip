@@ -970,13 +970,14 @@ extern "C" int srgan_instnorm_io_applicable(int N, int HW, int C) {
   return (N > 0 && HW > 0 && C > 0 && (slab_fast(N, HW, C) || ((C & 3) == 0 && pow2_fast(C, HW)))) ? 1 : 0;
 }
 
-extern "C" int srgan_instnorm_fwd_io(const void* x, int x_bf16, const float* scale, const float* shift, void* y, int y_bf16,
-                                     float* mean, float* rstd, int N, int HW, int C, float eps, int act, float slope, void* ws,
-                                     size_t ws_bytes, void* stream) {
+extern "C" int srgan_instnorm_fwd_io(const void* x, int x_bf16, const float* scale, const float* shift, const float* res, void* y,
+                                     int y_bf16, float* mean, float* rstd, int N, int HW, int C, float eps, int act, float slope,
+                                     void* ws, size_t ws_bytes, void* stream) {
   SRGAN_REQUIRE(x && y && mean && rstd, "instnorm_fwd_io: null pointer");
   SRGAN_REQUIRE(srgan_instnorm_io_applicable(N, HW, C), "instnorm_fwd_io: shape not served (srgan_instnorm_io_applicable)");
-  SRGAN_REQUIRE(x != y, "instnorm_fwd_io: in-place calls are not supported");
-  if (slab_fast(N, HW, C)) return srgan_instnorm_slab_fwd_io(x, x_bf16, scale, shift, nullptr, y, y_bf16, mean, rstd, N, HW, C, eps, act, slope, stream);
+  SRGAN_REQUIRE(x != y && (const void*)res != (const void*)y, "instnorm_fwd_io: in-place calls are not supported");
+  SRGAN_REQUIRE(!(res && y_bf16), "instnorm_fwd_io: the skip tensor is added to an fp32 result only");
+  if (slab_fast(N, HW, C)) return srgan_instnorm_slab_fwd_io(x, x_bf16, scale, shift, res, y, y_bf16, mean, rstd, N, HW, C, eps, act, slope, stream);
   SRGAN_REQUIRE((scale == nullptr) == (shift == nullptr), "instnorm_fwd_io: scale and shift go together");
   hipStream_t st = as_stream(stream);
   int S, rps;
@@ -993,8 +994,8 @@ extern "C" int srgan_instnorm_fwd_io(const void* x, int x_bf16, const float* sca
   }
   const int hwc4 = HW * C / 4;
   dim3 g2((unsigned)apply_grid(hwc4, N), (unsigned)N);
-  ProfToken tok = prof_begin(31, ebytes * ((x_bf16 ? 2 : 4) + (y_bf16 ? 2 : 4)), st);
-#define SRGAN_APPLY_IO(A, B) hipLaunchKernelGGL((in_apply_pow2<A, B>), g2, dim3(256), 0, st, x, scale, shift, (const float*)nullptr, mean, rstd, y, hwc4, C, act, slope, (const float2*)part, S, HW, eps)
+  ProfToken tok = prof_begin(31, ebytes * ((x_bf16 ? 2 : 4) + (y_bf16 ? 2 : 4) + (res ? 4 : 0)), st);
+#define SRGAN_APPLY_IO(A, B) hipLaunchKernelGGL((in_apply_pow2<A, B>), g2, dim3(256), 0, st, x, scale, shift, res, mean, rstd, y, hwc4, C, act, slope, (const float2*)part, S, HW, eps)
   if (x_bf16 && y_bf16) SRGAN_APPLY_IO(true, true);
   else if (x_bf16) SRGAN_APPLY_IO(true, false);
   else if (y_bf16) SRGAN_APPLY_IO(false, true);

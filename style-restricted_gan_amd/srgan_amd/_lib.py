@@ -65,7 +65,7 @@ SIGNATURES = {
     "srgan_halo16_applicable": (c_int, [_DESC]),
     "srgan_halo16s2_applicable": (c_int, [_DESC]),
     "srgan_instnorm_io_applicable": (c_int, [c_int, c_int, c_int]),
-    "srgan_instnorm_fwd_io": (c_int, [P, c_int, P, P, P, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_float, P, c_size_t, P]),
+    "srgan_instnorm_fwd_io": (c_int, [P, c_int, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_float, P, c_size_t, P]),
     "srgan_instnorm_bwd_io": (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "srgan_halo16_conv": (c_int, [_DESC, c_int, P, c_int, P, P, P, c_int, P]),
     "srgan_halo16_wgrad": (c_int, [_DESC, P, c_int, P, c_int, P, P, c_size_t, P]),

@@ -986,12 +986,15 @@ class _ResBlockBf16Fn(Function):
         _lib.check(lib.srgan_halo16_conv(ctypes.byref(d), 0, _ptr(x), 0, _ptr(hit1.buf), None, _ptr(y1), 1, st), "halo16_conv")
         mean1 = torch.empty(n * c, dtype=torch.float32, device=dev)
         rstd1, mean2, rstd2 = torch.empty_like(mean1), torch.empty_like(mean1), torch.empty_like(mean1)
-        _lib.check(lib.srgan_instnorm_slab_fwd_io(_ptr(y1), 1, _ptr(s1), _ptr(h1), None, _ptr(hh), 1, _ptr(mean1), _ptr(rstd1),
-                                                  n, h * w, c, float(eps), ACT_RELU, 0.0, st), "instnorm_slab_fwd_io")
+        # (the slab kernels on maps of <= 1024 pixels, the two-pass kernels with 16-bit I/O on the 64 x 64 trunk maps of 256 x 256)
+        nb = lib.srgan_instnorm_workspace(n, h * w, c)
+        ws = workspace(dev, nb)
+        _lib.check(lib.srgan_instnorm_fwd_io(_ptr(y1), 1, _ptr(s1), _ptr(h1), None, _ptr(hh), 1, _ptr(mean1), _ptr(rstd1),
+                                             n, h * w, c, float(eps), ACT_RELU, 0.0, _ptr(ws), nb, st), "instnorm_fwd_io")
         _lib.check(lib.srgan_halo16_conv(ctypes.byref(d2), 0, _ptr(hh), 1, _ptr(hit2.buf), None, _ptr(y2), 1, st), "halo16_conv")
         out = torch.empty_like(x)
-        _lib.check(lib.srgan_instnorm_slab_fwd_io(_ptr(y2), 1, _ptr(s2), _ptr(h2), _ptr(x), _ptr(out), 0, _ptr(mean2), _ptr(rstd2),
-                                                  n, h * w, c, float(eps), ACT_NONE, 0.0, st), "instnorm_slab_fwd_io")
+        _lib.check(lib.srgan_instnorm_fwd_io(_ptr(y2), 1, _ptr(s2), _ptr(h2), _ptr(x), _ptr(out), 0, _ptr(mean2), _ptr(rstd2),
+                                             n, h * w, c, float(eps), ACT_NONE, 0.0, _ptr(ws), nb, st), "instnorm_fwd_io")
         ctx.d1, ctx.d2, ctx.w1, ctx.w2 = d, d2, w1, w2
         ctx.save_for_backward(x, y1, hh, y2, s1, h1, s2, h2, mean1, rstd1, mean2, rstd2)
         return out
@@ -1013,9 +1016,11 @@ class _ResBlockBf16Fn(Function):
             dy = b16()
             dsc = torch.empty(n, c, dtype=torch.float32, device=dev)
             dsh = torch.empty_like(dsc)
-            _lib.check(lib.srgan_instnorm_slab_bwd_io(_ptr(y), 1, _ptr(gup), gup16, _ptr(sc), _ptr(sh), _ptr(mean), _ptr(rstd),
-                                                      _ptr(dy), 1, _ptr(dsc), _ptr(dsh), n, h * w, c, act, 0.0, st),
-                       "instnorm_slab_bwd_io")
+            nb = lib.srgan_instnorm_workspace(n, h * w, c)
+            ws = workspace(dev, nb)
+            _lib.check(lib.srgan_instnorm_bwd_io(_ptr(y), 1, _ptr(gup), gup16, _ptr(sc), _ptr(sh), _ptr(mean), _ptr(rstd),
+                                                 _ptr(dy), 1, _ptr(dsc), _ptr(dsh), n, h * w, c, act, 0.0, _ptr(ws), nb, st),
+                       "instnorm_bwd_io")
             return dy, dsc, dsh
 
         def wgrad(desc, weight, xin, xin16, dy):
@@ -1175,7 +1180,7 @@ class _InstNormIoFn(Function):
         rstd = torch.empty_like(mean)
         nb = lib.srgan_instnorm_workspace(n, h * w, c)
         ws = workspace(x.device, nb)
-        _lib.check(lib.srgan_instnorm_fwd_io(_ptr(x), _is16(x), _ptr(scale), _ptr(shift), _ptr(y), _is16(y), _ptr(mean), _ptr(rstd),
+        _lib.check(lib.srgan_instnorm_fwd_io(_ptr(x), _is16(x), _ptr(scale), _ptr(shift), None, _ptr(y), _is16(y), _ptr(mean), _ptr(rstd),
                                              n, h * w, c, float(eps), act, float(slope), _ptr(ws), nb, _stream()), "instnorm_fwd_io")
         ctx.act, ctx.slope = act, slope
         ctx.save_for_backward(x, scale, shift, mean, rstd)
@@ -1225,7 +1230,7 @@ def res_block_bf16_fusable(x, w1, w2, s1, s2):
     if tuple(w1.shape) != (c, c, 3, 3) or tuple(w2.shape) != (c, c, 3, 3):
         return False
     lib = _lib.load()
-    if not lib.srgan_instnorm_slab_applicable(n, h * w, c):
+    if not lib.srgan_instnorm_io_applicable(n, h * w, c):
         return False
     desc = _conv_desc(n, h, w, c, h, w, c, 3, 3, 1, 1, PAD_ZERO, w1)
     return bool(lib.srgan_halo16_applicable(ctypes.byref(desc)))
