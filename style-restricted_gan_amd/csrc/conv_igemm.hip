@@ -500,9 +500,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 // MFMAs (32x32x16 bf16) per wave and barrier; the gathered rows are masked by a select on the packed bf16 pairs; fragments of
 // K step q + 1 are read under the MFMAs of step q; tile kt + 1 goes to LDS in the middle of tile kt and the loads of tile
 // kt + 2 are issued behind it.  Rows are 144 bytes apart in LDS (36 banks: the 16-lane groups of ds_read_b128 and the 8-lane
-// row segments of ds_write_b64 land on distinct banks).  Source, weights (packed fp32 [phases][Npad][Kpad], as for
-// igemm_kernel) and destination stay fp32 in HBM; operands are rounded to bf16 (RNE) on the way into LDS, exactly as in
-// igemm_kernel<.., BF>, so the two kernels produce the same sums up to fp32 summation order.
+// row segments of ds_write_b64 land on distinct banks).  Source and destination stay fp32 in HBM and the source is rounded to
+// bf16 (RNE) on the way into LDS; the weights are packed [phases][Npad][Kpad] as for igemm_kernel but already as bf16
+// (PackParams::out16: the same RNE rounding, done once per optimiser step instead of once per tile), so the two kernels
+// produce the same sums up to fp32 summation order.
 constexpr int BK16 = 64;
 constexpr int LDH16 = BK16 + 8;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -518,15 +519,19 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
   __shared__ __attribute__((aligned(16))) int row_o[BM];
 
   const int tid = threadIdx.x;
-  int bid = blockIdx.x;
-  const int nblk = gridDim.x;
-  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // neighbouring pixel tiles (shared image rows) on one XCD
-  const int mt = bid % p.m_tiles, nt = bid / p.m_tiles;
   const int phase = blockIdx.y;
   const int s = p.stride;
   int py = 0, px = 0;
   if (p.mode == 1) { py = phase / s; px = phase % s; }
   const int sgn = p.mode == 0 ? 1 : -1;
+  // Persistent over the output tiles (launch_igemm16: at most two workgroups per CU): a workgroup's result stores drain under
+  // its next tile's prologue and K loop instead of holding its CU slot until they have landed -- with one tile per workgroup
+  // the rounds run in lockstep and the epilogue of a 9-tile K loop (the encoder's 62 x 62 maps) was 40 % of the kernel.
+  const int total_tiles = p.m_tiles * p.n_tiles;
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+  int bid = tile;
+  if ((total_tiles & 7) == 0) bid = (bid & 7) * (total_tiles >> 3) + (bid >> 3);   // neighbouring pixel tiles (shared image rows) on one XCD
+  const int mt = bid % p.m_tiles, nt = bid / p.m_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
 
   // window origin and destination pixel of GEMM row m.  The two divisions are float multiplications by a reciprocal with one
@@ -565,9 +570,12 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
     row_o[tid] = o;
   }
 
-  const float* wp = p.wp + (size_t)phase * p.Npad * p.Kpad;
+  const unsigned short* wp = reinterpret_cast<const unsigned short*>(p.wp) + (size_t)phase * p.Npad * p.Kpad;
   const int kt0 = p.ksplit > 1 ? (int)blockIdx.z * p.kt_per_split : 0;
-  const int nk = p.ksplit > 1 ? max(min(p.Kpad / BK16 - kt0, p.kt_per_split), 0) : p.Kpad / BK16;
+  int nk = p.ksplit > 1 ? max(min(p.Kpad / BK16 - kt0, p.kt_per_split), 0) : p.Kpad / BK16;
+#ifdef SRGAN_EXPERIMENTS
+  if (p.exp & 16) nk = 0;
+#endif
 
   // a thread stages 4 pixel rows (8 lanes per row: floats [4 seg, 4 seg + 4) and [32 + 4 seg, ...) of the 64-channel slice);
   // per row ONE 32-bit byte offset, the valid tap rows / tap columns as two 8-bit ranges (zero padding is separable) and, for
@@ -619,9 +627,9 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
   // weight rows of this thread: n0 + (tid >> 3) + 32 i, clamped to the packed rows (columns >= Cd are never stored)
   unsigned woff[B_IT];
 #pragma unroll
-  for (int i = 0; i < B_IT; ++i) woff[i] = (unsigned)(((size_t)min(n0 + (tid >> 3) + 32 * i, p.Npad - 1) * p.Kpad) * 4) + seg16;
+  for (int i = 0; i < B_IT; ++i) woff[i] = (unsigned)(((size_t)min(n0 + (tid >> 3) + 32 * i, p.Npad - 1) * p.Kpad) * 2) + seg16;
 
-  f32x4 a_reg[A_IT][2], b_reg[B_IT][2];
+  f32x4 a_reg[A_IT][2], b_reg[B_IT];          // b_reg: 8 bf16 weights (row, k = 8 seg .. 8 seg + 7)
   bool a_ok[A_IT];
   auto load_tiles = [&](int kt_rel) __attribute__((always_inline)) {
     const int k0 = (kt0 + kt_rel) * BK16;
@@ -650,14 +658,13 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
     const int wx = tap_x == p.Tx;
     tap_x = wx ? 0 : tap_x;
     tap_y += wx;
-    const char* wb = reinterpret_cast<const char*>(wp) + (size_t)k0 * 4;
+    const char* wb = reinterpret_cast<const char*>(wp) + (size_t)k0 * 2;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
 #ifdef SRGAN_EXPERIMENTS
-      if (p.exp & 2) { b_reg[i][0] = f32x4{1.f, 1.f, 1.f, 1.f}; b_reg[i][1] = b_reg[i][0]; continue; }
+      if (p.exp & 2) { b_reg[i] = f32x4{1.f, 1.f, 1.f, 1.f}; continue; }
 #endif
-      b_reg[i][0] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
-      b_reg[i][1] = *reinterpret_cast<const f32x4*>(wb + woff[i] + 128);
+      b_reg[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
     }
   };
   auto store_tiles = [&](int buf) __attribute__((always_inline)) {
@@ -676,12 +683,7 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int r = (tid >> 3) + 32 * i;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        *reinterpret_cast<bf16x4*>(&Bh[r * LDH16 + h * 32 + seg * 4]) = __builtin_convertvector(b_reg[i][h], bf16x4);
-    }
+    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(&Bh[((tid >> 3) + 32 * i) * LDH16 + seg * 8]) = b_reg[i];
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -741,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
   // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   float* const dst_base = p.ksplit > 1 ? p.dst + (size_t)blockIdx.z * p.split_stride : p.dst;
 #ifdef SRGAN_EXPERIMENTS
-  if ((p.exp & 8) && acc[0][0][0] != 12345.f) return;
+  if ((p.exp & 8) && acc[0][0][0] != 12345.f) { __syncthreads(); continue; }
 #endif
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const bool relu = p.act == SRGAN_ACT_RELU;
@@ -763,6 +765,8 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
         if (nok && o >= 0) dst_base[(size_t)o * p.Cd + n] = v > 0.f ? v : (relu ? 0.f : v * neg);
       }
     }
+  }
+  __syncthreads();        // row_o and the operand buffers are rewritten by the next tile
   }
 }
 
@@ -1404,7 +1408,10 @@ static int launch_igemm16(IgemmParams p, int phases, hipStream_t st, double flop
   p.m_tiles = (int)ceil_div(p.M, 128);
   p.n_tiles = (int)ceil_div(p.Cd, bn);
   ProfScope scope(36, flops, st);
-  dim3 grid((unsigned)(p.m_tiles * p.n_tiles), (unsigned)phases, (unsigned)std::max(p.ksplit, 1));
+  // two resident workgroups per CU over all (phase, split) planes; a workgroup walks its plane's tiles with that stride
+  const long long planes = (long long)phases * std::max(p.ksplit, 1), tiles = (long long)p.m_tiles * p.n_tiles;
+  const long long gx = std::min<long long>(tiles, std::max<long long>(8, (512 / planes) & ~7LL));
+  dim3 grid((unsigned)gx, (unsigned)phases, (unsigned)std::max(p.ksplit, 1));
   if (bn == 64) hipLaunchKernelGGL(igemm16_kernel<64>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(igemm16_kernel<128>, grid, dim3(256), 0, st, p);
   return check_launch("igemm16_kernel");
@@ -1784,6 +1791,7 @@ static PackParams fwd_pack_params(const srgan_conv_desc* d, FwdPath path, const 
   q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
   q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 0; q.stride = d->stride; q.pad = d->pad;
   q.Ty = d->kh; q.Tx = d->kw; q.Cs = d->I; q.N = d->O; q.K = p.K; q.Kpad = p.Kpad; q.Npad = p.Npad; q.phases = 1;
+  q.out16 = (path == PATH_IGEMM && igemm16_ok(p)) ? 1 : 0;
   return q;
 }
 
@@ -1945,6 +1953,7 @@ static PackParams dgrad_pack_params(const srgan_conv_desc* d, const DgradGeom& g
   q.w = w; q.dst = dst; q.sO = d->sO; q.sI = d->sI; q.sH = d->sH; q.sW = d->sW;
   q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 1; q.stride = d->stride; q.pad = g.p.pad;
   q.Ty = g.p.Ty; q.Tx = g.p.Tx; q.Cs = d->O; q.N = d->I; q.K = g.p.K; q.Kpad = g.p.Kpad; q.Npad = g.p.Npad; q.phases = g.phases;
+  q.out16 = (!g.wino && !g.narrow && !g.rgbin && !g.narrow_s2 && igemm16_ok(g.p)) ? 1 : 0;
   return q;
 }
 

@@ -13,7 +13,13 @@ struct PackParams {
   float* dst;
   long long sO, sI, sH, sW;
   int O, I, kh, kw, mode, stride, pad, Ty, Tx, Cs, N, K, Kpad, Npad, phases;
+  int out16;           // 1: the operand is written as bf16 (RNE) at the same element index (igemm16_kernel's layers, bf16 mode)
 };
+
+__device__ __forceinline__ void pack_weights_store(const PackParams& p, long long idx, float v) {
+  if (p.out16) reinterpret_cast<__bf16*>(p.dst)[idx] = (__bf16)v;
+  else p.dst[idx] = v;
+}
 
 __device__ __forceinline__ long long pack_weights_total(const PackParams& p) { return (long long)p.phases * p.Npad * p.Kpad; }
 
@@ -35,7 +41,7 @@ __device__ __forceinline__ void pack_weights_item(const PackParams& p, long long
       if (ky < p.kh && kx < p.kw) v = p.w[c * p.sO + n * p.sI + ky * p.sH + kx * p.sW];
     }
   }
-  p.dst[idx] = v;
+  pack_weights_store(p, idx, v);
 }
 
 // The same rows for one WORKGROUP of 256 threads: one (phase, n) row of K = taps x Cs entries at a time.  With OIHW weights the
@@ -52,9 +58,9 @@ __device__ __forceinline__ void pack_weights_rows(const PackParams& p, float* ti
   const long long rows = (long long)p.phases * p.Npad;
   for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = (int)(row % p.Npad), phase = (int)(row / p.Npad);
-    float* dst = p.dst + row * p.Kpad;
+    const long long dst0 = row * p.Kpad;
     if (n >= p.N) {
-      for (int k = threadIdx.x; k < p.Kpad; k += blockDim.x) dst[k] = 0.f;
+      for (int k = threadIdx.x; k < p.Kpad; k += blockDim.x) pack_weights_store(p, dst0 + k, 0.f);
       continue;
     }
     __syncthreads();                      // the previous row has left the tile
@@ -79,7 +85,7 @@ __device__ __forceinline__ void pack_weights_rows(const PackParams& p, float* ti
         const int t = k / p.Cs, c = k - t * p.Cs;
         v = tile[t * LD + c];
       }
-      dst[k] = v;
+      pack_weights_store(p, dst0 + k, v);
     }
   }
 }
