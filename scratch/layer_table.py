@@ -26,5 +26,5 @@ for i in range(lib.srgan_prof_num_slots()):
 rows = sorted(agg.items(), key=lambda kv: -sum(kv[1]))
 tot = sum(sum(v) for v in agg.values())
 print(f"GEMM launches total {tot:.2f} ms")
-for (name, gf), v in rows[:60]:
+for (name, gf), v in rows[:int(os.environ.get("ROWS", "60"))]:
     print(f"{name:32s} {gf:8.2f} GF x{len(v):3d}  avg {1e3*sum(v)/len(v):8.1f} us  {gf/ (sum(v)/len(v)):7.1f} TF   total {sum(v):6.2f} ms")
