@@ -37,6 +37,8 @@ def prof_name(n):
         return "wino43_input_kernel"
     if n.startswith("wino43_kernel"):
         return "wino43_kernel"
+    if n.startswith("igemm16_kernel"):
+        return "igemm16_kernel"
     if "halo16t_kernel" in n:
         return "halo16t_kernel"
     if "halo16s2_wgrad_kernel" in n:

@@ -95,6 +95,7 @@ CONV_CASES = [
     (8, 64, 30, 22, 64, 3, 1, 1, False, True),    # even but not multiple-of-4 map, zero padding, bias
     (6, 32, 15, 15, 64, 3, 1, 1, True, False),    # E.layers.2 map size, reflect
     (2, 96, 13, 18, 32, 3, 1, 1, True, True),     # odd sizes in both directions, 3 channel groups, one cout block, bias
+    (16, 64, 66, 66, 64, 3, 1, 1, True, False),   # bf16 mode: 545 pixel tiles of igemm16_kernel on <= 512 persistent workgroups (reflect, 64 couts)
 ]
 
 
