@@ -479,6 +479,68 @@ def test_conv2d_bf16_compute_mode(ops, case):
         ops.set_compute_dtype("fp32")
 
 
+def _random_bf16_conv_cases(n_cases, seed):
+    """Seeded random geometries of the layers the bf16 kernels serve (Cin a multiple of 32, Cout >= 32): patch kernels, the
+    64-deep-K implicit GEMM (Cin % 64 == 0: ragged pixel / channel tiles, stride-2 phases, reflect, 1x1, split-K) and the rest."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < n_cases:
+        k = int(rng.choice([1, 3, 3, 4, 4]))
+        s_ = int(rng.choice([1, 1, 2]))
+        i = int(rng.choice([32, 64, 64, 96, 128, 128, 192, 256]))
+        o = int(rng.choice([32, 64, 96, 128, 160, 256, 512]))
+        h, w = int(rng.randint(max(k, 3), 41)), int(rng.randint(max(k, 3), 41))
+        p_ = int(rng.randint(0, k // 2 + 1))
+        reflect = bool(s_ == 1 and 0 < p_ < min(h, w) and k == 3 and rng.rand() < 0.4)
+        n = int(rng.randint(1, 9))
+        if (h + 2 * p_ - k) // s_ + 1 < 1 or (w + 2 * p_ - k) // s_ + 1 < 1 or n * i * h * w > 3_000_000:
+            continue
+        cases.append((n, i, h, w, o, k, s_, p_, reflect, bool(rng.rand() < 0.5)))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_bf16_conv_cases(32, seed=20261004))
+def test_conv2d_bf16_random_geometries(ops, case):
+    """test_conv2d_bf16_compute_mode's check on seeded random geometries inside a packed-weight scope (the trainer's mode: bf16
+    packed operands of igemm16_kernel, split-K slabs, persistent tile loop)."""
+    n, i, h, w, o, k, s, p, reflect, has_bias = case
+    torch.set_num_threads(16)
+    x = rnd(n, i, h, w, seed=1)
+    wt = rnd(o, i, k, k, seed=2) / np.sqrt(i * k * k)
+    b = (rnd(o, seed=3) * 0.1) if has_bias else None
+
+    def ref(xv, wv, gyv=None):
+        xv, wv = xv.clone().requires_grad_(True), wv.clone().requires_grad_(True)
+        xin = F.pad(xv, (p, p, p, p), mode="reflect") if reflect else xv
+        yv = F.conv2d(xin, wv, b, s, 0 if reflect else p)
+        if gyv is not None:
+            yv.backward(gyv)
+        return yv.detach(), xv.grad, wv.grad
+
+    y_ref, _, _ = ref(_bf16_round(x), _bf16_round(wt))
+    gy = rnd(*y_ref.shape, seed=4)
+    _, dx_ref, _ = ref(x, _bf16_round(wt), _bf16_round(gy))
+    _, _, dw_ref = ref(_bf16_round(x), wt, _bf16_round(gy))
+    ops.set_compute_dtype("bf16")
+    try:
+        xd, wd = x.cuda().requires_grad_(True), wt.cuda().requires_grad_(True)
+        bd = b.cuda().requires_grad_(True) if has_bias else None
+        ops.invalidate_packed()
+        with ops.pack_cache():
+            y = ops.conv2d(xd, wd, bd, s, p, ops.PAD_REFLECT if reflect else ops.PAD_ZERO)
+            y.backward(gy.cuda())
+        try:
+            close(y, y_ref)
+        except AssertionError:
+            # heads with a 1 x 1 output map run on the exact-fp32 direct kernels in both modes (csrc/conv_narrow.hip)
+            close(y, ref(x, wt)[0])
+        close(xd.grad, dx_ref)
+        close(wd.grad, dw_ref, 5e-5)
+    finally:
+        ops.set_compute_dtype("fp32")
+        ops.invalidate_packed()
+
+
 @pytest.mark.parametrize("case", [(3, 64, 8, 32, 64), (2, 256, 32, 32, 256), (1, 128, 12, 64, 128)])
 def test_conv2d_skip_bf16_mode(ops, case):
     """bf16 mode on the residual-trunk shapes: the skip path's gradient is added in the epilogue of the LDS-resident-patch kernel
