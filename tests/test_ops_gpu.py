@@ -1112,6 +1112,39 @@ def test_leaky_relu_backward_in_the_consumers_input_gradient(ops, n, c0, c1, c2,
         close(a, b, 1e-6)
 
 
+@pytest.mark.parametrize("n,c0,c1,c2,hw", [(2, 8, 64, 128, 128), (2, 16, 128, 256, 64), (2, 16, 128, 256, 32), (4, 8, 256, 512, 32)])
+def test_leaky_relu_backward_in_the_consumers_input_gradient_bf16_mode(ops, n, c0, c1, c2, hw):
+    """The same chain in the bf16 mode: the consumer's input gradient runs on halo16t_kernel (first shape) or igemm16_kernel
+    (with and without split-K) followed by the in-place LeakyReLU-backward pass (fusing the mask into those epilogues was
+    measured in round 4: the pass disappears, the kernels take as much longer -- profiles/LOG.md).  Chained and unchained calls
+    multiply the same fp32 input gradient by the same 1 / 0.2, so they agree like the fp32 ones; both are held to the exact-fp32
+    chain at bf16 accuracy."""
+    x = rnd(n, c0, hw, hw, seed=31)
+    w1 = rnd(c1, c0, 4, 4, seed=32) / np.sqrt(c0 * 16)
+    w2 = rnd(c2, c1, 4, 4, seed=33) / np.sqrt(c1 * 16)
+    gy = rnd(n, c2, hw // 4, hw // 4, seed=34)
+    xr, w1r, w2r = (t.clone().requires_grad_(True) for t in (x, w1, w2))
+    F.conv2d(F.leaky_relu(F.conv2d(xr, w1r, None, 2, 1), 0.2), w2r, None, 2, 1).backward(gy)
+    res = {}
+    ops.invalidate_packed()
+    ops.set_compute_dtype("bf16")
+    try:
+        for chained in (False, True):
+            xg, w1g, w2g = (t.clone().cuda().requires_grad_(True) for t in (x, w1, w2))
+            with ops.pack_cache():
+                h = ops.conv2d(xg, w1g, None, 2, 1, ops.PAD_ZERO, ops.ACT_LRELU, 0.2, None, chained)
+                y = ops.conv2d(h, w2g, None, 2, 1, ops.PAD_ZERO, ops.ACT_NONE, 0.0, 0.2 if chained else None, False)
+                y.backward(gy.cuda())
+            res[chained] = (y.detach(), xg.grad, w1g.grad, w2g.grad)
+    finally:
+        ops.set_compute_dtype("fp32")
+        ops.invalidate_packed()
+    for a, b in zip(res[True], res[False]):
+        close(a, b, 1e-6)
+    for got, want in zip(res[True][1:], (xr.grad, w1r.grad, w2r.grad)):
+        assert float((got.cpu() - want).norm() / want.norm()) < 2e-2          # bf16 operands (2^-9 each), a few sign flips of h
+
+
 def test_generator_bf16_activation_storage_vs_fp32_tensors(ops):
     """Round 4: in the bf16 mode the tensors between the generator's stride-2 convolutions and their norms live in HBM as bf16
     (ops.py "bf16 activation storage": halo16s / halo16t / halo16s2_wgrad kernels with 16-bit I/O, instance norm with 16-bit
