@@ -39,6 +39,11 @@ def prof_name(n):
         return "wino43_kernel"
     if n.startswith("igemm16_kernel"):
         return "igemm16_kernel"
+    # the instance-norm passes (HBM-bound: their traffic against the tensor bytes is the point)
+    for k in ("in_stats_partial", "in_apply_pow2", "in_bwd_partial", "in_bwd_apply_pow2", "in_fwd_slab_v16", "in_bwd_slab_vz",
+              "in_fwd_slab", "in_bwd_slab"):
+        if n.startswith(k):
+            return {"in_apply_pow2": "in_apply", "in_bwd_apply_pow2": "in_bwd_apply"}.get(k, k)
     if "halo16t_kernel" in n:
         return "halo16t_kernel"
     if "halo16s2_wgrad_kernel" in n:
