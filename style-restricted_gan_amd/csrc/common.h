@@ -108,7 +108,7 @@ struct WinoParams {
   int pad, reflect;
   int TH, TW, T;      // tile grid per image (of the phase image in mode 2), tiles in total
   int nchunk, n_tiles, m_tiles;
-  int cpp;            // mode 1: chunks per input phase (C / 8)
+  int cpp;            // mode 1: chunks per input phase (C / 8; F(4x4,2x2): C / 16)
   int act;            // fused activation of the epilogue (SRGAN_ACT_*)
   float slope;
   const float* res;   // F(4x4,3x3) only: tensor of the destination's shape added in the epilogue (residual gradient), or null
@@ -116,6 +116,8 @@ struct WinoParams {
   float mask_slope;   //   (the LeakyReLU backward of the layer that produced the destination's forward tensor), or null
 };
 
+// conv_wino42.hip: F(4x4,2x2) kernels of the 4x4 / stride-2 layers behind wino_run (variant 7): kind 0 = strided form, 1 = transposed
+int wino42_launch(const WinoParams& p, int kind, long long grid, bool mask, double flops, hipStream_t st);
 // conv_wino43.hip: F(4x4,3x3) kernel behind wino_run
 size_t wino43_scratch_floats(long long T, int C);
 int wino43_launch(const WinoParams& p, float* vimg, long long grid, double flops, hipStream_t st, bool v_ready = false);

@@ -46,8 +46,9 @@ static const char* const kProfNames[] = {
     "wino43_kernel", "wino43_input_kernel", "rgbin_conv_kernel", "rgb_wgrad_kernel", "wino43_wgrad_kernel", "wino43_dy_kernel",
     "halo16_kernel", "halo16_wgrad_kernel", "halo16s2_wgrad_kernel", "halo16t_kernel", "rgbout_conv_kernel", "halo16s_kernel",
     // HBM-bound passes (norm.hip): the "flops" slot of their brackets carries ALGORITHMIC BYTES (tensor bytes each pass must move)
-    "in_stats_partial", "in_apply", "in_bwd_partial", "in_bwd_apply", "in_fwd_slab", "in_bwd_slab", "igemm16_kernel"};
-constexpr int kProfKernels = 37;
+    "in_stats_partial", "in_apply", "in_bwd_partial", "in_bwd_apply", "in_fwd_slab", "in_bwd_slab", "igemm16_kernel",
+    "wino42_kernel", "wino42_wgrad_kernel"};
+constexpr int kProfKernels = 39;
 
 struct ProfScope {
   bool on;

@@ -802,9 +802,14 @@ static bool wino_s2_disabled() {
   static const bool off = SRGAN_AB_SET("SRGAN_NO_WINOGRAD_S2");
   return off;
 }
+static bool wino42_disabled() {
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_WINOGRAD42");
+  return off;
+}
 
 // 0: none, 1: F(2x2,3x3) on a 3x3 stride-1 pad-1 layer, 2: F(3x3,2x2) on a 4x4 stride-2 pad-1 layer,
 // 3: F(4x4,3x3) (conv_wino43.hip) on a 3x3 stride-1 zero-pad-1 layer whose map is a multiple of 4 in both directions
+// 7: F(4x4,2x2) (conv_wino42.hip) on a 4x4 stride-2 pad-1 layer whose output map is a multiple of 4 in both directions
 // 4: bf16 mode only -- NOT a Winograd form: the direct bf16 GEMM of conv_halo16.hip (residual-trunk shapes), which shares this
 //    slot's packed-filter / residual-add plumbing
 static int wino_variant(const srgan_conv_desc* d, int kind) {
@@ -836,6 +841,12 @@ static int wino_variant(const srgan_conv_desc* d, int kind) {
   }
   if (d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 1 && d->pad_mode == SRGAN_PAD_ZERO && !wino_s2_disabled()) {
     if ((d->Hi & 1) || (d->Wi & 1)) return 0;
+    // F(4x4,2x2): exact 4x4 tiling, 32 tiles x 64 channels per workgroup (one workgroup per CU); the same lower bound on the
+    // device fill as below
+    if (!wino42_disabled() && d->Ho % 4 == 0 && d->Wo % 4 == 0 && N % 64 == 0 && C % 16 == 0) {
+      const long long b42 = ceil_div((long long)d->N * (d->Ho / 4) * (d->Wo / 4), 32) * (N / 64) * (kind == 1 ? 4 : 1);
+      if (b42 >= 120 * wino_threshold_scale()) return 7;
+    }
     // 3x3 output tiles over Ho x Wo (= the phase image of the transposed form): skip maps the tiling wastes
     const long long th = ceil_div(d->Ho, 3), tw = ceil_div(d->Wo, 3);
     const double eff = (double)d->Ho * d->Wo / (9.0 * th * tw);
@@ -854,9 +865,9 @@ static void wino_dims(const srgan_conv_desc* d, int kind, int* C, int* N, int* n
   const int v = wino_variant(d, kind);
   *C = kind == 0 ? d->I : d->O;
   *N = kind == 0 ? d->O : d->I;
-  *n_tiles = (v >= 4) ? 1 : v == 3 ? *N / 32 : (int)ceil_div(*N, WNB);
-  *nchunk = (v >= 4) ? *C / 32 : (v == 2 && kind == 0 ? 4 : 1) * (*C / WC);      // MODE 1 reduces over (input phase, channel)
-  *phases = (v == 2 && kind == 1) ? 4 : 1;                  // (variant 5 keeps its four phases inside one packed image)                  // MODE 2: one filter image per output phase
+  *n_tiles = v == 7 ? *N / 64 : (v >= 4) ? 1 : v == 3 ? *N / 32 : (int)ceil_div(*N, WNB);
+  *nchunk = v == 7 ? (kind == 0 ? 4 : 1) * (*C / 16) : (v >= 4) ? *C / 32 : (v == 2 && kind == 0 ? 4 : 1) * (*C / WC);      // MODE 1 reduces over (input phase, channel)
+  *phases = ((v == 2 || v == 7) && kind == 1) ? 4 : 1;                  // (variant 5 keeps its four phases inside one packed image)                  // MODE 2: one filter image per output phase
 }
 
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind) {
@@ -866,6 +877,7 @@ size_t wino_packed_bytes(const srgan_conv_desc* d, int kind) {
   if (wino_variant(d, kind) == 6) return halo16s_packed_bytes(d);
   if (wino_variant(d, kind) == 5) return halo16t_packed_bytes(d);
   if (wino_variant(d, kind) == 3) return (size_t)n_tiles * nchunk * (36 * 256) * sizeof(float);
+  if (wino_variant(d, kind) == 7) return (size_t)phases * n_tiles * nchunk * (25 * 1024) * sizeof(float);
   return (size_t)phases * n_tiles * nchunk * 8192 * sizeof(float);
 }
 
@@ -962,17 +974,18 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
     if (variant == 3) { ot = 4; p.TH = p.Ho / 4; p.TW = p.Wo / 4; }
     else { p.TH = (p.Ho + 1) / 2; p.TW = (p.Wo + 1) / 2; }
   } else {
-    ot = 3;
+    ot = variant == 7 ? 4 : 3;
     p.pad = d->pad; p.reflect = 0;
     if (kind == 0) { p.H = d->Hi; p.W = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo; }
     else { p.H = d->Ho; p.W = d->Wo; p.Ho = d->Hi; p.Wo = d->Wi; }
-    p.TH = (int)ceil_div(d->Ho, 3); p.TW = (int)ceil_div(d->Wo, 3);      // tiles over Ho x Wo (kind 1: the phase image)
+    p.TH = (int)ceil_div(d->Ho, ot); p.TW = (int)ceil_div(d->Wo, ot);      // tiles over Ho x Wo (kind 1: the phase image)
+    if (variant == 7) p.cpp = C / 16;
   }
   (void)ot;
   const long long T = (long long)p.NB * p.TH * p.TW;
   SRGAN_REQUIRE(T < (1LL << 30), "winograd: too many tiles");
   p.T = (int)T;
-  p.m_tiles = (int)ceil_div(T, WT);
+  p.m_tiles = (int)ceil_div(T, variant == 7 ? 32 : WT);
   const long long grid = (long long)p.m_tiles * p.n_tiles;
   SRGAN_REQUIRE(grid < (1LL << 31), "winograd: grid too large");
   // ALGORITHMIC FLOPs of the direct convolution; the kernel issues ~2.25x fewer on the matrix pipe
@@ -986,6 +999,14 @@ int wino_run(const srgan_conv_desc* d, int kind, const float* src, const float* 
     return check_launch("wino43_kernel");
   }
   SRGAN_REQUIRE(!v_ready, "winograd: a prepared V image only serves the F(4x4,3x3) path");
+  if (variant == 7) {
+    SRGAN_REQUIRE(p.pad == 1 && p.nchunk >= 2 && p.Cd % 64 == 0 && p.C % 16 == 0 && d->Ho % 4 == 0 && d->Wo % 4 == 0, "winograd F(4,2): geometry");
+    if (kind == 1 && mask) {
+      p.mask = mask; p.mask_slope = mask_slope;
+      if (mask_done) *mask_done = true;
+    }
+    return wino42_launch(p, kind, grid, kind == 1 && mask != nullptr, conv_flops_of(d), st);
+  }
   ProfToken tok = prof_begin(variant == 1 ? 14 : 16, conv_flops_of(d), st);
   if (variant == 1) hipLaunchKernelGGL(wino_kernel<0>, dim3((unsigned)grid), dim3(512), 0, st, p);
   else if (kind == 0) hipLaunchKernelGGL(wino_kernel<1>, dim3((unsigned)grid), dim3(512), 0, st, p);

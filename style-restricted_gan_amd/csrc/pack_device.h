@@ -104,6 +104,7 @@ __device__ __host__ __forceinline__ long long wino_pack_total(const WinoPackPara
   if (p.variant == 5 || p.variant == 6) return (long long)p.N * (p.C / 8);         // one item = 8 reduce channels of one output channel, 16 taps
   if (p.variant == 4) return (long long)p.nchunk * p.N * 4;                      // one item = 8 reduce channels of one cout, 9 taps
   if (p.variant == 3) return (long long)p.n_tiles * 32 * p.nchunk * 2;          // one item = 4 channels of one cout
+  if (p.variant == 7) return (long long)p.phases * p.n_tiles * p.nchunk * 256;  // one item = 4 channels of one cout
   return (long long)p.n_tiles * WP_WNB * p.nchunk * WP_WC * p.phases;
 }
 
@@ -321,8 +322,66 @@ __device__ __forceinline__ void halo16s_pack_item(const WinoPackParams& p, long 
   }
 }
 
+// variant 7, F(4x4,2x2) (conv_wino42.hip):  U = G g G^T (5x5 from the 2x2 taps of a phase), G = [1/2 0; -1/2 -1/2; -1/6 1/6;
+// 1/6 1/3; 0 1], laid out [out phase][n_tile (64 couts)][chunk (16 ch)][25 pos][8-ch half][cout half][lane = lh * 32 + cout][4 ch]:
+// the A-operand register image of wino42_kernel.  kind 0 (strided form): reduce index k = (input phase pq, c), g[a][b] =
+// w[n][c][2a+p][2b+q];  kind 1 (transposed form): one image per OUTPUT phase rs, g[a][b] = w[c][n][3-2a-r][3-2b-s].
+__device__ __forceinline__ void wino42_pack_item(const WinoPackParams& p, long long idx) {
+  long long r = idx;
+  const int nl = (int)(r % 32); r /= 32;
+  const int lh = (int)(r % 2); r /= 2;
+  const int h = (int)(r % 2); r /= 2;
+  const int hb = (int)(r % 2); r /= 2;
+  const int chunk = (int)(r % p.nchunk); r /= p.nchunk;
+  const int ntile = (int)(r % p.n_tiles);
+  const int ophase = (int)(r / p.n_tiles);
+  const int n = ntile * 64 + h * 32 + nl;
+  f32x4 u[25];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = chunk * 16 + hb * 8 + lh * 4 + j;
+    int c, pp, qq;
+    if (p.kind == 0) { const int ph = k / p.C; c = k - ph * p.C; pp = ph >> 1; qq = ph & 1; }
+    else { c = k; pp = ophase >> 1; qq = ophase & 1; }
+    const bool ok = n < p.N && c < p.C && (p.kind == 1 || k < 4 * p.C);
+    float g[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float v = 0.f;
+        if (ok) v = p.kind == 0 ? p.w[n * p.sO + c * p.sI + (2 * a + pp) * p.sH + (2 * b + qq) * p.sW]
+                                : p.w[c * p.sO + n * p.sI + (3 - 2 * a - pp) * p.sH + (3 - 2 * b - qq) * p.sW];
+        g[a][b] = v;
+      }
+    float hm[5][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float x = g[0][b], y = g[1][b];
+      hm[0][b] = 0.5f * x;
+      hm[1][b] = -0.5f * (x + y);
+      hm[2][b] = (1.f / 6.f) * (y - x);
+      hm[3][b] = (1.f / 6.f) * x + (1.f / 3.f) * y;
+      hm[4][b] = y;
+    }
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      const float x = hm[a][0], y = hm[a][1];
+      u[a * 5 + 0][j] = 0.5f * x;
+      u[a * 5 + 1][j] = -0.5f * (x + y);
+      u[a * 5 + 2][j] = (1.f / 6.f) * (y - x);
+      u[a * 5 + 3][j] = (1.f / 6.f) * x + (1.f / 3.f) * y;
+      u[a * 5 + 4][j] = y;
+    }
+  }
+  float* out = p.dst + ((((size_t)ophase * p.n_tiles + ntile) * p.nchunk + chunk) * 25) * 1024 + hb * 512 + h * 256 + lh * 128 + nl * 4;
+#pragma unroll
+  for (int k = 0; k < 25; ++k) *reinterpret_cast<f32x4*>(out + k * 1024) = u[k];
+}
+
 __device__ __forceinline__ void wino_pack_item(const WinoPackParams& p, long long idx) {
   constexpr int WNB = WP_WNB, WC = WP_WC;
+  if (p.variant == 7) { wino42_pack_item(p, idx); return; }
   if (p.variant == 6) { halo16s_pack_item(p, idx); return; }
   if (p.variant == 5) { halo16t_pack_item(p, idx); return; }
   if (p.variant == 4) { halo16_pack_item(p, idx); return; }
