@@ -197,9 +197,12 @@ def is_hbm_kernel(name):
 
 def executed_divisor(name):
     """Algorithmic conv FLOPs / MFMA FLOPs actually issued: Winograd F(4x4,3x3) multiplies 36 values per 16 outputs x 9 taps
-    (4x fewer), F(2x2,3x3) / F(3x3,2x2) 16 per 36 (2.25x fewer, before the waste of ragged edge tiles); 1 for the direct forms."""
+    (4x fewer), F(4x4,2x2) 25 per 16 x 4 (2.56x fewer), F(2x2,3x3) / F(3x3,2x2) 16 per 36 (2.25x fewer, before the waste of ragged
+    edge tiles); 1 for the direct forms."""
     if name.startswith("wino43"):
         return 4.0
+    if name.startswith("wino42"):
+        return 2.56          # F(4x4,2x2): 25 multiplies per 16 outputs x 4 taps
     if name.startswith("wino"):
         return 2.25
     return 1.0

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include "srgan_hip.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -32,8 +33,8 @@ inline int check_launch(const char* what) {
   } while (0)
 
 // Timing ablations (wrong results) and phase stamps are compile-time variants of the kernels: never in the product library.
-#if !defined(SRGAN_EXPERIMENTS) && (defined(WINO_EXP) || defined(RGBOUT_EXP) || defined(W43_DIAG))
-#error "WINO_EXP / RGBOUT_EXP / W43_DIAG are experiment builds: make exp EXPFLAGS=-DWINO_EXP=n (writes scratch/libsrgan_exp.so)"
+#if !defined(SRGAN_EXPERIMENTS) && (defined(WINO_EXP) || defined(WINO42_EXP) || defined(RGBOUT_EXP) || defined(W43_DIAG))
+#error "WINO_EXP / WINO42_EXP / RGBOUT_EXP / W43_DIAG are experiment builds: make exp EXPFLAGS=-DWINO_EXP=n (writes scratch/libsrgan_exp.so)"
 #endif
 
 // A/B switches of the measurement scripts under scratch/: only `make exp` (-DSRGAN_EXPERIMENTS, which writes
@@ -77,16 +78,19 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// The activation as one select: `act` is uniform, and written as `if (act == ...)` the compiler keeps a scalar branch per
+// ELEMENT of an unrolled epilogue (~30 instructions and two taken branches around each 16-byte store: the row pass + stores of
+// wino42_kernel's epilogue took 7000 cycles, round 5).  Negative-side slope: 1 (none), 0 (ReLU), slope (LeakyReLU); the
+// `+ 0.f` keeps ReLU's zero positive.  Same values as the branch form for every input (a NaN stays a NaN).
+__device__ __forceinline__ float act_neg_slope(int act, float slope) {
+  return act == SRGAN_ACT_LRELU ? slope : (act == SRGAN_ACT_RELU ? 0.f : 1.f);
+}
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
-  if (act == SRGAN_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == SRGAN_ACT_LRELU) return v > 0.f ? v : v * slope;
-  return v;
+  return v > 0.f ? v : __builtin_fmaf(v, act_neg_slope(act, slope), 0.f);
 }
 // derivative from the (pre- or post-activation) sign; slope > 0 keeps signs equal
 __device__ __forceinline__ float act_grad(float v, int act, float slope) {
-  if (act == SRGAN_ACT_RELU) return v > 0.f ? 1.f : 0.f;
-  if (act == SRGAN_ACT_LRELU) return v > 0.f ? 1.f : slope;
-  return 1.f;
+  return v > 0.f ? 1.f : act_neg_slope(act, slope);
 }
 
 
@@ -109,6 +113,7 @@ struct WinoParams {
   int TH, TW, T;      // tile grid per image (of the phase image in mode 2), tiles in total
   int nchunk, n_tiles, m_tiles;
   int cpp;            // mode 1: chunks per input phase (C / 8; F(4x4,2x2): C / 16)
+  int ipw;            // F(4x4,2x2): items per workgroup (set by wino42_launch)
   int act;            // fused activation of the epilogue (SRGAN_ACT_*)
   float slope;
   const float* res;   // F(4x4,3x3) only: tensor of the destination's shape added in the epilogue (residual gradient), or null

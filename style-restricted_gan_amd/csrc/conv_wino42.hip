@@ -70,8 +70,9 @@ __device__ __forceinline__ void bt5(float& x0, float& x1, float& x2, float& x3, 
 }
 
 // A^T of F(4,2): [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 0; 0 1 -1 8 1]
-__device__ __forceinline__ void at5(const f32x4& m0, const f32x4& m1, const f32x4& m2, const f32x4& m3, const f32x4& m4, f32x4* y) {
-  const f32x4 s = m1 + m2, d = m1 - m2;
+template <typename V>
+__device__ __forceinline__ void at5(const V& m0, const V& m1, const V& m2, const V& m3, const V& m4, V* y) {
+  const V s = m1 + m2, d = m1 - m2;
   y[0] = m0 + s + m3;
   y[1] = d + 2.f * m3;
   y[2] = s + 4.f * m3;
@@ -91,31 +92,36 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
   constexpr int PXS = MODE == 2 ? 2 : 1;  // pixel stride of the outputs in the destination
   constexpr int TS = MODE == 1 ? 8 : 4;   // source pixels between tile origins
   constexpr int DS = MODE == 1 ? 2 : 1;   // source pixels between patch elements
-  const int ph_r = MODE == 2 ? (int)blockIdx.y >> 1 : 0, ph_s = MODE == 2 ? (int)blockIdx.y & 1 : 0;
+  constexpr int NPH = MODE == 2 ? 4 : 1;  // output phases = items per (tile block, channel block) unit
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
+  // A workgroup walks a contiguous range of items = (tile block, output-channel block, output phase), phase fastest: the items of
+  // a range read the same (MODE 2: one-pixel-shifted) patches.  XCD-aware order of the ranges: see wino_kernel.
   int bid = blockIdx.x;
   const int nblk = gridDim.x;
-  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);      // XCD-aware: see wino_kernel
-  const int m_tile = bid / p.n_tiles, n_tile = bid - m_tile * p.n_tiles;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int n_items = p.m_tiles * p.n_tiles * NPH;
+  const int item0 = bid * p.ipw, item1 = min(item0 + p.ipw, n_items);
   const int nk = p.nchunk;
+#if WINO42_EXP & 128
+  long long stamp[12];
+  auto tick = [&](int k) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    stamp[k] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  tick(0);
+#else
+  auto tick = [&](int) __attribute__((always_inline)) {};
+#endif
 
   // ---- gather role: thread = (tile tl, channel ch of the chunk) ----
   const int tl = tid >> 4, ch = tid & 15;
   constexpr unsigned kOutside = 0x80000000u;
-  int g_b, g_ty, g_tx;
-  bool g_tv;
-  {
-    const int t = m_tile * W2T + tl;
-    g_tv = t < p.T;
-    const int tt = g_tv ? t : 0;
-    const int per = p.TH * p.TW;
-    g_b = tt / per;
-    const int r = tt - g_b * per;
-    g_ty = r / p.TW; g_tx = r - g_ty * p.TW;
-    if (ch == 0) tile_o[tl] = g_tv ? (g_b * p.Ho + PXS * 4 * g_ty + ph_r) * p.Wo + PXS * 4 * g_tx + ph_s : -1;
-  }
+  int g_b = 0, g_ty = 0, g_tx = 0, g_mt = -1, g_to = -1;
+  bool g_tv = false;
+  int ph_r = 0, ph_s = 0, n_tile = 0;
   // Patch element (i, j) = source pixel (TS ty + DS i + o_y, TS tx + DS j + o_x), o = phase - 1.  Only i, j = 0 can lie above /
   // left of the image and only i, j = 4 below / right of it (maps are multiples of the tile): per row one offset for columns
   // 1..3 (the column goes into the scalar offset), one for column 0 and one for column 4, each the element's byte offset or a
@@ -136,14 +142,36 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
       off4[i] = rok && c4ok ? base + 3u * (unsigned)CS : kOutside;
     }
   };
-  set_offsets(0);
+  int lc = 0, lphase = 0;                 // load cursor: chunks are consumed strictly in order
+  // coordinates, gather offsets and load cursor of an item (the tile decode only when the tile block changes)
+  auto setup_item = [&](int item) __attribute__((always_inline)) {
+    const int unit = MODE == 2 ? item >> 2 : item, oph = MODE == 2 ? item & 3 : 0;
+    const int m_tile = unit / p.n_tiles;
+    n_tile = unit - m_tile * p.n_tiles;
+    ph_r = oph >> 1; ph_s = oph & 1;
+    if (m_tile != g_mt) {
+      g_mt = m_tile;
+      const int t = m_tile * W2T + tl;
+      g_tv = t < p.T;
+      const int tt = g_tv ? t : 0;
+      const int per = p.TH * p.TW;
+      g_b = tt / per;
+      const int r = tt - g_b * per;
+      g_ty = r / p.TW; g_tx = r - g_ty * p.TW;
+    }
+    g_to = g_tv ? (g_b * p.Ho + PXS * 4 * g_ty + ph_r) * p.Wo + PXS * 4 * g_tx + ph_s : -1;
+    lc = 0; lphase = 0;
+    set_offsets(0);
+  };
   const unsigned src_bytes = (unsigned)((size_t)p.NB * p.H * p.W * p.C * 4);
   const auto rs_x = uniform_rsrc42(p.src, src_bytes);
-  const auto rs_u = uniform_rsrc42(p.u + ((size_t)(MODE == 2 ? blockIdx.y : 0) * p.n_tiles + n_tile) * p.nchunk * W2UCH,
-                                   (unsigned)p.nchunk * (unsigned)(W2UCH * 4));
+  // destination (and mask) through buffer instructions too: one 32-bit offset per thread, the pixel of the tile in the scalar
+  // offset -- sixteen 64-bit store addresses would cost 32 registers beside the output transform
+  const unsigned dst_bytes = (unsigned)((size_t)p.NB * p.Ho * p.Wo * p.Cd * 4);
+  const auto rs_y = uniform_rsrc42(p.dst, dst_bytes);
+  const auto rs_m = uniform_rsrc42(MASK ? p.mask : p.dst, dst_bytes);
 
   float d[25];
-  int lc = 0, lphase = 0;                 // load cursor: chunks are consumed strictly in order
   auto ldx = [&](unsigned vo, int so) __attribute__((always_inline)) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, vo, so, 0));
   };
@@ -160,7 +188,7 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
     d[i * 5 + 4] = ldx(off4[i], so);
     if constexpr (i == 4) {
       ++lc;
-      if (MODE == 1 && lc == p.cpp) {     // next input phase: new patch origin and padding (wave-uniform, 3x per kernel)
+      if (MODE == 1 && lc == p.cpp) {     // next input phase: new patch origin and padding (wave-uniform, 3x per item)
         lc = 0;
         ++lphase;
         if (lphase < 4) set_offsets(lphase);
@@ -188,6 +216,9 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
   using I4 = std::integral_constant<int, 4>;
+  auto load_patch = [&]() __attribute__((always_inline)) {
+    load_row(I0{}); load_row(I1{}); load_row(I2{}); load_row(I3{}); load_row(I4{});
+  };
   // the side work of one iteration in eight pieces: transform + store of chunk kc + 1 (ST), gather of chunk kc + 2 (LD); a
   // row of d is reloaded as soon as its row pass has left for LDS
   auto side = [&](int nbuf, auto piece_c, auto st_c, auto ld_c) __attribute__((always_inline)) {
@@ -214,12 +245,13 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
     const int g = wave >> 1, h = wave & 1;
     const int pbase = NP == 7 ? 0 : 7 + 6 * (g - 1);
     f32x16 acc[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     f32x4 ufr[NP];
     const unsigned ulane = (unsigned)((pbase * 4 + h) * 256 + lane * 4) * 4u;
+    // filter image of the item: [output phase][n_tile][chunk][25 pos][2 halves of 8 ch][2 cout halves][64 lanes][4]
+    auto u_rsrc = [&]() __attribute__((always_inline)) {
+      return uniform_rsrc42(p.u + ((size_t)(ph_r * 2 + ph_s) * p.n_tiles + n_tile) * p.nchunk * W2UCH, (unsigned)p.nchunk * (unsigned)(W2UCH * 4));
+    };
+    auto rs_u = u_rsrc();
     auto load_u = [&](int slot, int hb, int kc) __attribute__((always_inline)) {
 #if WINO42_EXP & 8
       if (kc > 0) return;                 // ablation: filter fragments of the first chunk only
@@ -244,8 +276,12 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
           __syncthreads();
           if constexpr (ST) vf[0] = read_v(cur ^ 1, 0);
         }
+#if WINO42_EXP & 32
+        asm volatile("" ::"v"(ufr[slot]), "v"(vf[i & 1]));      // ablation: no MFMAs (operands kept alive)
+#else
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc[slot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[slot][s], vf[i & 1][s], acc[slot], 0, 0, 0);
+#endif
         // the fragment this slot needs half a chunk from now
         if (i < NP) load_u(slot, 1, kc);
         else if constexpr (ST) load_u(slot, 0, kc + 1);
@@ -261,28 +297,10 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
       }
     };
 
-    // prologue: chunk 0 transformed into buffer 0, chunk 1 in flight, the first NP filter fragments requested
-    load_row(I0{}); load_row(I1{}); load_row(I2{}); load_row(I3{}); load_row(I4{});
-#pragma unroll
-    for (int j = 0; j < 5; ++j) col_pass(j);
-#pragma unroll
-    for (int r = 0; r < 5; ++r) row_store(0, r);
-    load_row(I0{}); load_row(I1{}); load_row(I2{}); load_row(I3{}); load_row(I4{});      // nk >= 2
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int a = 0; a < NP; ++a) load_u(a, 0, 0);
-    __syncthreads();
-    vf[0] = read_v(0, 0);
-    int kc = 0;
-    for (; kc + 2 < nk; ++kc) iter(kc, T{}, T{});
-    iter(kc, T{}, F{});
-    iter(kc + 1, F{}, F{});
-
     // ---- epilogue: the two output-channel halves, one after the other.  The half is a compile-time constant of the code a
     // wave runs, so that its accumulators are provably dead once they have left for LDS (the transform needs ~180 registers) ----
-    const int tq = (wave >> 1) * 64 + lane;         // index among the 256 threads that transform a pass
-    const int cq = tq & 7, et = tq >> 3;
-    auto pass = [&](int hp) __attribute__((always_inline)) {
+    // e_nt / e_mask0: output-channel block and destination of THIS item (the gather state already belongs to the next one)
+    auto pass = [&](int hp, int e_nt, auto mid_c) __attribute__((always_inline)) {
       // accumulator lane = tile lr, register e = output channel 8 * (e / 4) + 4 * lh + e % 4 of the half
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
@@ -293,74 +311,172 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
           *reinterpret_cast<f32x4*>(X + 8 * k) = v;
         }
       }
+      tick(3);
       __syncthreads();
-      const int n = n_tile * W2N + hp * 32 + cq * 4;
+      tick(4);
+      // (derived from an opaque copy of the lane index: computed here, not carried through the main loop in registers)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int tq = (wave >> 1) * 64 + ln;         // index among the 256 threads that transform a pass
+      const int cq = tq & 7, et = tq >> 3;
+      const int n = e_nt * W2N + hp * 32 + cq * 4;
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
       const int o = tile_o[et];
-      // MASK: requested before the LDS reads and the output transform, consumed at the stores
+      // MASK: row 0 is requested before the LDS reads and the output transform, row a + 1 before row a is computed and stored
+      // (all sixteen up front do not fit beside the transform's registers)
       f32x4 mk[4][4];
-      if constexpr (MASK) {
-        if (o >= 0) {
-          const float* mp = p.mask + (size_t)o * p.Cd + n;
+      const unsigned yoff = o >= 0 ? (unsigned)(o * p.Cd + n) * 4u : kOutside;      // outside: loads return 0, stores are dropped
+      auto load_mask = [&](int a) __attribute__((always_inline)) {
 #pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b2 = 0; b2 < 4; ++b2) mk[a][b2] = *reinterpret_cast<const f32x4*>(mp + (size_t)(a * p.Wo + b2) * PXS * p.Cd);
-        }
-      }
+        for (int b2 = 0; b2 < 4; ++b2)
+          mk[a][b2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_m, yoff + (unsigned)((a * p.Wo + b2) * PXS * p.Cd * 4), 0, 0));
+      };
+      if constexpr (MASK) load_mask(0);
+      // Output transform of the thread's four channels as two PAIRS, one after the other: the first pair's 16 results wait in
+      // registers while the second pair goes through (82 live registers at the peak instead of 116 for all four at once --
+      // with the next item's patch in flight the four-channel form spilled, and spill reloads wait for the stores before them).
       const float* M = lds + et * W2XT + cq * 4;
-      f32x4 hh[4][5];
+      f32x2 ya[4][4];
 #pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        f32x4 y[4];
-        at5(*reinterpret_cast<const f32x4*>(M + (0 * 5 + c) * W2XP), *reinterpret_cast<const f32x4*>(M + (1 * 5 + c) * W2XP),
-            *reinterpret_cast<const f32x4*>(M + (2 * 5 + c) * W2XP), *reinterpret_cast<const f32x4*>(M + (3 * 5 + c) * W2XP),
-            *reinterpret_cast<const f32x4*>(M + (4 * 5 + c) * W2XP), y);
+      for (int pr = 0; pr < 2; ++pr) {
+        f32x2 hh[4][5];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) hh[a][c] = y[a];
-      }
-      if (o >= 0) {
-        float* dp = p.dst + (size_t)o * p.Cd + n;
+        for (int c = 0; c < 5; ++c) {
+          f32x2 y[4];
+          at5(*reinterpret_cast<const f32x2*>(M + (0 * 5 + c) * W2XP + 2 * pr), *reinterpret_cast<const f32x2*>(M + (1 * 5 + c) * W2XP + 2 * pr),
+              *reinterpret_cast<const f32x2*>(M + (2 * 5 + c) * W2XP + 2 * pr), *reinterpret_cast<const f32x2*>(M + (3 * 5 + c) * W2XP + 2 * pr),
+              *reinterpret_cast<const f32x2*>(M + (4 * 5 + c) * W2XP + 2 * pr), y);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          f32x4 y[4];
-          at5(hh[a][0], hh[a][1], hh[a][2], hh[a][3], hh[a][4], y);
+          for (int a = 0; a < 4; ++a) hh[a][c] = y[a];
+          __builtin_amdgcn_sched_barrier(0);          // keeps the LDS reads of later columns / the other pair from being hoisted
+        }
+        if (pr == 0) {
 #pragma unroll
-          for (int b2 = 0; b2 < 4; ++b2) {
-            f32x4 v = y[b2] + bv;
+          for (int a = 0; a < 4; ++a) at5(hh[a][0], hh[a][1], hh[a][2], hh[a][3], hh[a][4], ya[a]);
+        } else {
+          tick(5);
+          // pass 0: the image has been read -- the other half's accumulators may come in under this half's row pass and stores
+          if constexpr (decltype(mid_c)::value) __syncthreads();
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], p.act, p.slope);
-            if constexpr (MASK) {
+          for (int a = 0; a < 4; ++a) {
+            if constexpr (MASK) { if (a + 1 < 4) load_mask(a + 1); }
+            f32x2 yb[4];
+            at5(hh[a][0], hh[a][1], hh[a][2], hh[a][3], hh[a][4], yb);
 #pragma unroll
-              for (int c = 0; c < 4; ++c) v[c] *= act_grad(mk[a][b2][c], SRGAN_ACT_LRELU, p.mask_slope);
+            for (int b2 = 0; b2 < 4; ++b2) {
+              f32x4 v = f32x4{ya[a][b2][0], ya[a][b2][1], yb[b2][0], yb[b2][1]} + bv;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], p.act, p.slope);
+              if constexpr (MASK) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] *= act_grad(mk[a][b2][c], SRGAN_ACT_LRELU, p.mask_slope);
+              }
+              // (the pixel offset rides in the VECTOR offset: with it in the scalar-offset operand this store put dwords 1 and 3
+              // of some lanes one pixel off on gfx950 / ROCm 7.2 -- scratch/wino42/check.py, profiles/LOG.md round 5)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), rs_y,
+                                                     yoff + (unsigned)((a * p.Wo + b2) * PXS * p.Cd * 4), 0, 0);
             }
-            *reinterpret_cast<f32x4*>(dp + (size_t)(a * p.Wo + b2) * PXS * p.Cd) = v;
           }
         }
       }
     };
-    if (h == 0) {
-      pass(0);
-      __syncthreads();                              // pass 0 has been read
-      __syncthreads();                              // pass 1 is in LDS
-    } else {
-      __syncthreads();                              // pass 0 is in LDS
-      __syncthreads();                              // pass 0 has been read
-      pass(1);
+
+    // ---- the items of this workgroup.  At the top of an item: its gather state is set and its first patch is in flight ----
+    setup_item(item0);
+    load_patch();
+    for (int item = item0; item < item1; ++item) {
+      tick(7);
+      if (ch == 0) tile_o[tl] = g_to;
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+      const int e_nt = n_tile;
+      rs_u = u_rsrc();
+      // prologue: chunk 0 transformed into buffer 0, chunk 1 in flight, the first NP filter fragments requested
+#pragma unroll
+      for (int j = 0; j < 5; ++j) col_pass(j);
+#pragma unroll
+      for (int r = 0; r < 5; ++r) row_store(0, r);
+      tick(8);
+      load_patch();                                 // nk >= 2
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < NP; ++a) load_u(a, 0, 0);
+      tick(9);
+      __syncthreads();
+      tick(1);
+      vf[0] = read_v(0, 0);
+      int kc = 0;
+      for (; kc + 2 < nk; ++kc) iter(kc, T{}, T{});
+      iter(kc, T{}, F{});
+      iter(kc + 1, F{}, F{});
+      tick(2);
+      const bool more = item + 1 < item1;
+
+#if WINO42_EXP & 16
+      {                                               // ablation: no epilogue (accumulators kept alive)
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) keep += acc[i][e];
+        if (keep == 12345.678f) p.dst[tid] = keep;
+        __syncthreads();
+        continue;
+      }
+#endif
+      if (h == 0) {
+        pass(0, e_nt, T{});
+        __syncthreads();                              // pass 1 is in LDS
+      } else {
+        __syncthreads();                              // pass 0 is in LDS
+        __syncthreads();                              // pass 0 has been read
+        pass(1, e_nt, F{});
+      }
+      if (more) {
+        // (requesting the next item's first patch before this item's epilogue was measured: no gain -- what the gap between two
+        // items costs is the ISSUE of 2 x 25 gather instructions per thread with no MFMAs to hide behind, not their latency)
+        setup_item(item + 1);
+        load_patch();
+        __syncthreads();                              // pass 1 and tile_o have been read: the next item may overwrite them
+      }
     }
+    tick(6);
+#if WINO42_EXP & 128
+    __builtin_amdgcn_s_waitcnt(0);                  // the stamps land in the words of pixel 0, which this workgroup wrote
+    __syncthreads();
+    if (item0 == 0 && lane == 0) {
+      float* o = p.dst + wave * 12;
+#pragma unroll
+      for (int k = 1; k < 10; ++k) o[k] = (float)(stamp[k] - stamp[0]);
+      o[0] = (float)nk;
+    }
+#endif
   };
 
+  if (item0 >= item1) return;
   if (wave < 2) role(std::integral_constant<int, 7>{});
   else role(std::integral_constant<int, 6>{});
 }
 
 // ---- host side (dispatch and geometry live in conv_wino.hip: variant 7) ----
-int wino42_launch(const WinoParams& p, int kind, long long grid, bool mask, double flops, hipStream_t st) {
+// `units` = tile blocks x output-channel blocks; one workgroup per CU at a time (115 KB of LDS, 512 threads).  Transposed form: the
+// items (units x output phases) are dealt in contiguous ranges of ceil(items / CUs) to as many workgroups as that takes -- the
+// phases of a unit re-read the same source pixels, and between two items of a workgroup no store has to be acknowledged before
+// the next one starts (G.down1 input gradient 185 -> 178 us).  Strided form: one item per workgroup (measured 7 us faster than
+// ranges of two on G.down1: a fresh workgroup's prologue is shorter than the gap between two items, see the kernel)
+int wino42_launch(const WinoParams& p0, int kind, long long units, bool mask, double flops, hipStream_t st) {
+  WinoParams p = p0;
+  const long long items = units * (kind == 1 ? 4 : 1);
+  static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  p.ipw = kind == 1 ? (int)ceil_div(items, cus) : 1;
+  const long long grid = ceil_div(items, p.ipw);
   ProfToken tok = prof_begin(37, flops, st);
   if (kind == 0) hipLaunchKernelGGL((wino42_kernel<1>), dim3((unsigned)grid), dim3(512), 0, st, p);
-  else if (mask) hipLaunchKernelGGL((wino42_kernel<2, true>), dim3((unsigned)grid, 4), dim3(512), 0, st, p);
-  else hipLaunchKernelGGL((wino42_kernel<2>), dim3((unsigned)grid, 4), dim3(512), 0, st, p);
+  else if (mask) hipLaunchKernelGGL((wino42_kernel<2, true>), dim3((unsigned)grid), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((wino42_kernel<2>), dim3((unsigned)grid), dim3(512), 0, st, p);
   prof_end(tok, st);
   return check_launch("wino42_kernel");
 }
