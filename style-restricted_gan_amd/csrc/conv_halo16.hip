@@ -1153,7 +1153,6 @@ int halo16_wgrad_run(const srgan_conv_desc* d, const void* x, const void* dy, fl
                      bool d16) {
   SRGAN_REQUIRE(halo16_wgrad_applicable(d), "halo16 wgrad: layer not applicable");
   if (halo16s2_wgrad_ok(d)) {
-    SRGAN_REQUIRE(x16 || !d16, "halo16 stride-2 wgrad: bf16 dy with fp32 x is not instantiated");
     Halo16S2WgradParams q{};
     halo16s2_wgrad_plan(d, &q);
     q.x = x; q.dy = dy; q.slab = slab;
@@ -1163,6 +1162,7 @@ int halo16_wgrad_run(const srgan_conv_desc* d, const void* x, const void* dy, fl
   do {                                                                                                                \
     if (x16 && d16) hipLaunchKernelGGL((halo16s2_wgrad_kernel<PW_, true, true>), grid, dim3(512), 0, st, q);          \
     else if (x16) hipLaunchKernelGGL((halo16s2_wgrad_kernel<PW_, true, false>), grid, dim3(512), 0, st, q);           \
+    else if (d16) hipLaunchKernelGGL((halo16s2_wgrad_kernel<PW_, false, true>), grid, dim3(512), 0, st, q);           \
     else hipLaunchKernelGGL((halo16s2_wgrad_kernel<PW_, false, false>), grid, dim3(512), 0, st, q);                  \
   } while (0)
     if (d->Wo % 32 == 0) SRGAN_S2W(32);

@@ -192,9 +192,13 @@ def set_bucket_dtype(name):
     _wire_dtype = name
 
 
-def bucket_dtype():
+def bucket_dtype(on_gpu=True):
+    """The wire dtype in force: an explicit ``set_bucket_dtype`` choice, else the compute mode's (a CPU / gloo run -- ``on_gpu``
+    false -- has no compute mode to follow and does not load the HIP library to ask)."""
     if _wire_dtype is not None:
         return _wire_dtype
+    if not on_gpu:
+        return "fp32"
     from . import ops
     return "bf16" if ops.get_compute_dtype() == "bf16" else "fp32"
 
@@ -214,7 +218,7 @@ class _Bucket:
         self.expected = sum(1 for p in params if p.requires_grad)
         self.hit = [False] * len(params)
 
-    def materialise(self):
+    def materialise(self, want16):
         p0 = self.params[0]
         if self.flat is None or self.flat.device != p0.device:
             self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=p0.device)
@@ -226,7 +230,6 @@ class _Bucket:
             self.wire = self.wire_views = None
             if p0.is_cuda:
                 self.ready, self.done = torch.cuda.Event(), torch.cuda.Event()
-        want16 = bucket_dtype() == "bf16"
         if want16 and self.wire is None:
             self.wire = torch.zeros(self.flat.numel(), dtype=torch.bfloat16, device=self.flat.device)
             self.wire_views = [self.wire[v.storage_offset():v.storage_offset() + v.numel()].view(v.shape) for v in self.views]
@@ -301,6 +304,10 @@ class GradReducer:
         return buckets
 
     def _reset(self):
+        # the wire dtype of this exchange is resolved ONCE, here (arm() / start()), not per bucket launch: bucket_dtype() asks the
+        # compute mode, which loads the HIP library -- needless on a CPU / gloo run, and a mode switch between two buckets of one
+        # exchange must not split it
+        self._wire16 = bucket_dtype(any(p.is_cuda for p in self.params)) == "bf16"
         for bk in self._buckets_cache:
             bk.launched, bk.count = False, 0
             bk.expected = sum(1 for p in bk.params if p.requires_grad)
@@ -328,7 +335,7 @@ class GradReducer:
 
     def _launch(self, b):
         bk = self._buckets_cache[b]
-        bk.materialise()
+        bk.materialise(self._wire16)
         on_gpu = bk.flat.is_cuda
         if on_gpu and _recorder is None:
             # sent from a hook, inside the backward pass: the bucket's gradients may have been written on more than one stream

@@ -329,16 +329,20 @@ class SingleGenerator(nn.Module):
         x = self.resBlocks([x, c])[0]
         n, _, h, w = x.shape
         iot = [False] * (self.num_cls + 1)
+        nio = [False] * (self.num_cls + 1)       # norm i can run on the 16-bit I/O kernels (its OWN shape: ADVICE r4)
         if x.is_cuda and ops.get_compute_dtype() == "bf16":
             hh, ww = h, w
             for i in range(self.num_cls):
                 cv = self.up_convs[i]
                 probe = torch.empty((n, cv.in_channels, hh, ww), device="meta")
-                iot[i] = cv.s2_io_applicable(probe) and ops.norm_io_applicable(n, cv.out_channels, 2 * hh, 2 * ww)
+                nio[i] = ops.norm_io_applicable(n, cv.out_channels, 2 * hh, 2 * ww)
+                iot[i] = cv.s2_io_applicable(probe) and nio[i]
                 hh, ww = 2 * hh, 2 * ww
         for i in range(self.num_cls):
             y = self.up_convs[i](x, io16=True) if iot[i] else self.up_convs[i](x)
-            x = self.up_norms[i](y, ACT_RELU, out_bf16=iot[i + 1])
+            # norm i writes bf16 for a 16-bit up conv i + 1 only if norm i itself is served (with iot[i] false and iot[i + 1] true
+            # -- a 16 x 64 input: the trunk map is 4 x 16 -- the fp32-in / bf16-out norm used to run unchecked)
+            x = self.up_norms[i](y, ACT_RELU, out_bf16=iot[i + 1] and nio[i])
         return ops.tanh(self.up_convs[-1](x))
 
 

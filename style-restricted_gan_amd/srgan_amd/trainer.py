@@ -657,15 +657,20 @@ class _StepGraph:
         try:
             mode = self._local_mode(source_image, label)
         except NotImplementedError as e:
-            #  a rank that can no longer take graph mode must still join the agreement below -- raising before the
-            # collective would leave the other ranks blocked in it: vote "eager", let every rank leave the step together, then raise
-            failure, mode = e, 0
+            # A rank that can no longer take graph mode must still join the agreement below -- raising before the collective would
+            # leave the other ranks blocked in it.  It votes -1, a value no healthy rank uses (a vote of 0 read as
+            # "eager" on the peers, which then entered the eager step and blocked in its first gradient all-reduce until the dead
+            # rank's connection timed out); on a negative minimum EVERY rank raises, at the same point of its program.
+            failure, mode = e, -1
             if not dp.is_distributed():
                 raise
         if dp.is_distributed():
             agreed = dp.all_min(mode)
             if failure is not None:
                 raise failure
+            if agreed < 0:
+                raise RuntimeError("SRGAN_training graph mode: another rank cannot take this step (see its own error); no rank "
+                                   "runs it")
             if agreed < 2 and self.graph is not None:
                 if agreed == 1:
                     key = self.key

@@ -280,3 +280,47 @@ def test_bench_launcher_spawns_ranks_before_any_gpu_call():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env2,
                         capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0
+
+
+def _worker_vote(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import time
+    from srgan_amd import dp
+    from srgan_amd.trainer import _StepGraph
+    dp.init_from_env("gloo")
+    g = object.__new__(_StepGraph)           # the agreement logic only: no networks, no device
+    g.graph, g.key = None, None
+
+    def local_mode(source_image, label):
+        if rank == 1:
+            raise NotImplementedError("SRGAN_training graph mode: optG is not srgan_amd.optim.Adam")
+        return 0
+    g._local_mode = local_mode
+    t0 = time.time()
+    try:
+        g.accepts(torch.zeros(1), {})
+        res = "returned"
+    except NotImplementedError:
+        res = "NotImplementedError"
+    except RuntimeError as e:
+        res = "RuntimeError" if "another rank cannot take this step" in str(e) else "other: " + str(e)
+    out.put((rank, res, time.time() - t0))
+
+
+def test_graph_step_agreement_with_one_failing_rank_raises_on_every_rank():
+    """a rank whose ``_local_mode`` raises votes -1 in the collective agreement of ``_StepGraph.accepts``; the failing
+    rank re-raises its own error and every OTHER rank raises too, at once -- none of them walks into the eager step's first
+    gradient all-reduce to wait for a peer that has left."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_vote, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r, (what, dt)) for r, what, dt in (out.get(timeout=120) for _ in procs))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1][0] == "NotImplementedError" and res[0][0] == "RuntimeError", res
+    assert max(dt for _, dt in res.values()) < 30.0, res

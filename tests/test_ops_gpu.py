@@ -1145,8 +1145,11 @@ def test_leaky_relu_backward_in_the_consumers_input_gradient_bf16_mode(ops, n, c
         assert float((got.cpu() - want).norm() / want.norm()) < 2e-2          # bf16 operands (2^-9 each), a few sign flips of h
 
 
-def test_generator_bf16_activation_storage_vs_fp32_tensors(ops):
-    """Round 4: in the bf16 mode the tensors between the generator's stride-2 convolutions and their norms live in HBM as bf16
+@pytest.mark.parametrize("hw", [(16, 128), (16, 64)])
+def test_generator_bf16_activation_storage_vs_fp32_tensors(ops, hw):
+    """(16 x 64, ADVICE r4: the trunk map is 4 x 16, so up conv 0 is NOT served by the 16-bit patch kernels while up conv 1 is --
+    norm 0 of the up path then has to decide on its own shape whether it may write bf16.)
+    Round 4: in the bf16 mode the tensors between the generator's stride-2 convolutions and their norms live in HBM as bf16
     (ops.py "bf16 activation storage": halo16s / halo16t / halo16s2_wgrad kernels with 16-bit I/O, instance norm with 16-bit
     I/O).  A full-width generator on a 16 x 128 image (so that every down / up layer is served: 8 x 64 and 4 x 32 maps) runs
     forward + backward with the storage on and off; both are bf16-mode results, so they are held to each other and, for scale,
@@ -1154,9 +1157,9 @@ def test_generator_bf16_activation_storage_vs_fp32_tensors(ops):
     from srgan_amd import model
     torch.manual_seed(0)
     G = model.SingleGenerator(3, 64, 2, 2, 1, "instance", num_con=12).cuda()
-    x = (torch.rand(2, 3, 16, 128) * 2 - 1).cuda()
+    x = (torch.rand(2, 3, *hw) * 2 - 1).cuda()
     c = torch.cat([torch.eye(4)[torch.tensor([1, 3])], torch.randn(2, 8)], 1).cuda()
-    gy = rnd(2, 3, 16, 128, seed=5).cuda()
+    gy = rnd(2, 3, *hw, seed=5).cuda()
     params = [p for p in G.parameters()]
 
     def run(mode, storage):
@@ -1167,8 +1170,11 @@ def test_generator_bf16_activation_storage_vs_fp32_tensors(ops):
                 p.grad = None
             with ops.pack_cache():
                 if mode == "bf16":
-                    probe = torch.empty((2, 64, 16, 128), device="meta")
+                    probe = torch.empty((2, 64, *hw), device="meta")
                     assert G.down_convs[1].s2_io_applicable(probe) == storage      # the path under test is really taken
+                    if hw == (16, 64) and storage:
+                        t0, t1 = torch.empty((2, 256, 4, 16), device="meta"), torch.empty((2, 128, 8, 32), device="meta")
+                        assert not G.up_convs[0].s2_io_applicable(t0) and G.up_convs[1].s2_io_applicable(t1)
                 y = G(x, c)
                 (y * gy).sum().backward()
             return y.detach().clone(), [p.grad.detach().clone() for p in params]
@@ -1181,18 +1187,94 @@ def test_generator_bf16_activation_storage_vs_fp32_tensors(ops):
     yc, gc = run("bf16", False)          # bf16 products, fp32 tensors
     ys, gs = run("bf16", True)           # bf16 products, bf16 tensors between conv and norm
 
+    # The yardstick (round 5, scratch/bf16_grad_errors.py): the exact-fp32 mode with the input and the weights rounded to bf16
+    # ONCE -- a 2^-9 perturbation of the first operands, fp32 arithmetic everywhere.  It already moves the gradients of the early
+    # layers by 11-13.5 % in relative L2 (output: 0.55 %): 0.06-0.3 % of the ReLU masks of every norm + ReLU flip (measured per
+    # layer), a flipped element switches its whole gradient path on or off, and under ~12 such layers every upstream gradient is a
+    # sum over flipped and unflipped paths -- so the error is broad (median error / median magnitude 0.16), unlike the single
+    # flips close_grad handles.  The bf16 mode rounds the operands of EVERY convolution and sits at 1.0-1.6x that: the 0.169 that
+    # broke the former 0.15 bound is down_cnorms.0.ConBias.0.weight (0.165 here; 0.141 with the RGB input layer on the fp32
+    # kernel, SRGAN_NO_RGBIN16 in the exp build: its bf16 products perturb the first pre-activations) -- the network's
+    # sensitivity to operand rounding, not an error of the 16-bit kernels, which are held to the fp32 convolution of the
+    # bf16-rounded operands at 2e-5 one by one (test_rgb_input_form_bf16_compute_mode, test_conv2d_bf16_compute_mode).
+    def bf16r(t):
+        return t.to(torch.bfloat16).to(torch.float32)
+    keep, x_keep = [p.data.clone() for p in params], x.clone()
+    try:
+        for p in params:
+            p.data.copy_(bf16r(p.data))
+        x.copy_(bf16r(x))
+        yp, gp = run("fp32", True)
+    finally:
+        for p, k in zip(params, keep):
+            p.data.copy_(k)
+        x.copy_(x_keep)
+
     def rel(a, b):
         return float((a - b).norm() / (b.norm() + 1e-12))
 
     assert rel(ys, y32) <= 1.5 * rel(yc, y32) + 2e-3, (rel(ys, y32), rel(yc, y32))
     assert rel(ys, y32) <= 2e-2
-    worst = 0.0
-    for (name, _), a, b, r in zip(G.named_parameters(), gs, gc, g32):
-        e_s, e_c = rel(a, r), rel(b, r)
-        worst = max(worst, e_s)
-        # ReLU-mask flips of bf16-rounded pre-activations dominate both bf16 paths (cf. test_residual_block_bf16_storage)
+    worst = ("", 0.0)
+    for (name, _), a, b, q, r in zip(G.named_parameters(), gs, gc, gp, g32):
+        e_s, e_c, e_p = rel(a, r), rel(b, r), rel(q, r)
+        if e_s > worst[1]:
+            worst = (name, e_s)
+        # storage on against storage off: the same mask-flip noise on both sides
         assert e_s <= 1.6 * e_c + 1e-2, (name, e_s, e_c)
-    assert worst <= 0.3, worst          # sanity cap (0.17 measured on the noisiest tensor once the RGB layers multiply in bf16 too)
+        # against the yardstick: measured e_s / e_p <= 1.58 over all 46 tensors (up_convs.2.weight; 1.47 on the 15 % tensors)
+        assert e_s <= 2.0 * e_p + 5e-3, (name, e_s, e_p)
+    if hw == (16, 128):
+        assert worst[1] <= 0.215, worst      # 1.3 x the largest measured value (0.1653, down_cnorms.0.ConBias.0.weight)
+
+
+@pytest.mark.parametrize("in16", [False, True])
+@pytest.mark.parametrize("out16", [False, True])
+def test_stride2_io_functions_every_dtype_pair(ops, in16, out16):
+    """conv2d_s2_io / conv_transpose2d_io are documented for any fp32 / bf16 mix of input and output; the weight
+    gradient of the (fp32 input side, bf16 output side) pair was not instantiated, so two of the four combinations passed
+    forward and failed in backward.  All four, both functions, forward + input gradient + weight gradient, against the fp32
+    convolution of the bf16-rounded operands (a bf16 result is compared after the same rounding of the reference)."""
+    torch.set_num_threads(16)
+    n, ci, co, h, w = 2, 64, 128, 16, 64
+    x = rnd(n, ci, h, w, seed=21)
+    wt = rnd(co, ci, 4, 4, seed=22) / np.sqrt(ci * 16)
+    xt = rnd(n, co, h // 2, w // 2, seed=23)                   # input of the transposed conv (weight viewed [Cin = co][Cout = ci])
+    gy = rnd(n, co, h // 2, w // 2, seed=24)
+    gyt = rnd(n, ci, h, w, seed=25)
+
+    def r16(t, on):
+        return _bf16_round(t) if on else t
+
+    def run_ref(fn, inp, g):
+        iv, wv = inp.clone().requires_grad_(True), _bf16_round(wt).clone().requires_grad_(True)
+        out = fn(iv, wv)
+        out.backward(g)
+        return out.detach(), iv.grad, wv.grad
+
+    ops.set_compute_dtype("bf16")
+    try:
+        with ops.pack_cache():
+            wd = wt.cuda().requires_grad_(True)
+            probe = torch.empty((n, ci, h, w), device="meta")
+            if not ops.s2_io_applicable(n, ci, h, w, co, wd, False):
+                pytest.skip("patch kernels do not serve this shape")
+            for fn_dev, fn_ref, inp, g in ((ops.conv2d_s2_io, lambda a, b: F.conv2d(a, b, None, 2, 1), x, gy),
+                                           (ops.conv_transpose2d_io, lambda a, b: F.conv_transpose2d(a, b, None, 2, 1), xt, gyt)):
+                # operands as the kernels see them: bf16-rounded input, weight and upstream gradient
+                y_ref, dx_ref, dw_ref = run_ref(fn_ref, _bf16_round(inp), _bf16_round(g))
+                wd.grad = None
+                xd = inp.cuda().contiguous(memory_format=torch.channels_last)
+                xd = (xd.to(torch.bfloat16) if in16 else xd).requires_grad_(True)
+                y = fn_dev(xd, wd, out16)
+                assert y.dtype == (torch.bfloat16 if out16 else torch.float32)
+                y.backward(g.cuda().contiguous(memory_format=torch.channels_last).to(y.dtype))
+                close(y.float(), r16(y_ref, out16), 2e-5 if not out16 else 5e-3)
+                close(xd.grad.float(), r16(dx_ref, in16), 2e-5 if not in16 else 5e-3)
+                close(wd.grad, dw_ref, 5e-5)
+    finally:
+        ops.set_compute_dtype("fp32")
+        ops.invalidate_packed()
 
 
 def test_rgb_input_form_bf16_compute_mode(ops):
