@@ -110,3 +110,24 @@ def close_params(a, b, lr, n_opt_steps, what="", walk=False):
         # generator's RGB input layer, whose gradients are the noisiest; 0.2 * lr * sqrt(40) = 1.26 lr bounds it)
         bound = 0.2 * lr * (max(n_opt_steps, 1) ** 0.5 if walk else 1.0)
         assert float(err.median()) <= bound, f"{what}: median err {float(err.median()):.3e}"
+
+
+def oracle_twenty_steps(k, pre, batch=4, steps=20):
+    """The CPU oracle over the 20-step tier-T trajectory of tests/test_train_gpu.py (ExponentialLR step after step 10; ``pre``:
+    the pretrained-encoder recipe); returns (oracle, losses[steps][3]).  Also run by tests/golden/make_traj20.py."""
+    from oracle import trainer as otrainer
+    PG, PD, PE = oracle_params("T")
+    e_keys = [n for n in PE if n.startswith(("fcmean", "fcvar"))] if pre else None
+    torch.manual_seed(21)
+    orc = otrainer.SRGANOracle(PG, PD, PE, otrainer.DEFAULT_LBD, k, np.eye(4), batch, "mu", 8,
+                               lr=(1e-4, 1e-4, 1e-3 if pre else 1e-4), e_trainable=e_keys)
+    ref = []
+    for s in range(steps):
+        if s == 10:
+            for o in (orc.optG, orc.optD, orc.optE):
+                o.lr *= 0.95
+        x, label = otrainer.synthetic_batch(batch, 128, 4, seed=600 + s)
+        ref.append([float(v) for v in orc.train(x, label)])
+    return orc, np.array(ref)
+
+
