@@ -17,10 +17,12 @@
 //     OUTPUT this kernel gathers / stores 0.83x and adds 1.5x of what F(3x3,2x2) does, next to 0.83x the MFMAs;
 //   * per 16-channel chunk each thread gathers one (tile, channel) 5x5 patch (buffer loads; out-of-image taps point past the
 //     buffer), transforms it in place (10 x 9 operations) and writes the 25 results to LDS [pos][channel quad][tile][4];
-//   * wave = (output-channel half, one of four position groups of 7 / 6 / 6 / 6): per chunk 2 x (7 | 6) units of four MFMAs
+//   * wave = (output-channel half, one of four groups of 6 of the first 24 positions): per chunk 2 x 6 units of four MFMAs
 //     with A = U fragment (32 output channels x 2 reduce channels, straight from the packed image into registers, a ring of
-//     7 | 6 fragments reloaded in place half a chunk ahead) and B = V fragment (one ds_read_b128); waves w and w + 4 share a
-//     SIMD, so the SIMDs carry 13 / 13 / 12 / 12 units;
+//     6 fragments reloaded in place half a chunk ahead) and B = V fragment (one ds_read_b128); the 25th position is cut into
+//     eight 16 x 16 blocks, one per wave, on v_mfma_f32_16x16x4_f32: every wave runs the same code and every SIMD carries the
+//     same 6400 MFMA cycles per chunk (a 7 / 6 / 6 / 6 split of whole positions measured the same time: the chunk takes ~7800
+//     cycles = MFMAs + the transform's vector work + barrier skew either way -- kept for the single code path);
 //   * the pieces of the next chunk's transform, its LDS stores and the gather of the chunk after it sit between the units of
 //     the SAME wave; LDS double-buffered, one barrier per chunk, placed before the last unit so that the first fragment of the
 //     next chunk is read under that unit's MFMAs;
@@ -237,15 +239,22 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
 
   using T = std::true_type;
   using F = std::false_type;
+  if (item0 >= item1) return;
 
-  // ---- multiply role: wave = (output-channel half h, position group g of NP positions) ----
-  auto role = [&](auto np_c) __attribute__((always_inline)) {
-    constexpr int NP = decltype(np_c)::value;
+  // ---- multiply role: wave = (output-channel half h, position group g of 6 of the first 24 positions) on the 32x32x2 MFMA;
+  // the 25th position is cut into eight 16 x 16 (output channel, tile) blocks, one per wave, on v_mfma_f32_16x16x4_f32 (same
+  // FLOPs per cycle): every SIMD carries 2 x (12 units x 256 + 128) = 6400 MFMA cycles per chunk -- with positions dealt 7 / 6 /
+  // 6 / 6 two SIMDs carried 6656 ----
+  {
+    constexpr int NP = 6;
     constexpr int NU = 2 * NP;            // units per chunk: (position slot, 8-channel half), half-major
     const int g = wave >> 1, h = wave & 1;
-    const int pbase = NP == 7 ? 0 : 7 + 6 * (g - 1);
+    const int pbase = NP * g;
+    const int cb25 = wave >> 1, tb25 = wave & 1;      // block of position 24: output channels 16 cb25 .., tiles 16 tb25 ..
     f32x16 acc[NP];
     f32x4 ufr[NP];
+    f32x4 acc25, u25;
+    float v25[4];
     const unsigned ulane = (unsigned)((pbase * 4 + h) * 256 + lane * 4) * 4u;
     // filter image of the item: [output phase][n_tile][chunk][25 pos][2 halves of 8 ch][2 cout halves][64 lanes][4]
     auto u_rsrc = [&]() __attribute__((always_inline)) {
@@ -257,6 +266,20 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
       if (kc > 0) return;                 // ablation: filter fragments of the first chunk only
 #endif
       ufr[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ulane, kc * (W2UCH * 4) + slot * 4096 + hb * 2048, 0));
+    };
+    // position 24's filter block: [4 channel blocks][lane = (channel & 3) * 16 + cout][4 channel quads]
+    const unsigned ulane25 = (unsigned)(24 * 1024 + cb25 * 256 + lane * 4) * 4u;
+    auto load_u25 = [&](int kc) __attribute__((always_inline)) {
+#if WINO42_EXP & 8
+      if (kc > 0) return;
+#endif
+      u25 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ulane25, kc * (W2UCH * 4), 0));
+    };
+    // its V fragment: lane (tile l % 16, channel l / 16 of a quad) reads that channel of the four quads
+    const int vrd25 = 24 * W2PS + (tb25 * 16 + (lane & 15)) * 4 + (lane >> 4);
+    auto read_v25 = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v25[s] = lds[buf * W2VSZ + vrd25 + s * W2QS];
     };
     const int vrd = pbase * W2PS + lh * W2QS + lr * 4;
     f32x4 vf[2];
@@ -272,7 +295,8 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
         const int slot = i % NP;
         if (i + 1 < NU) vf[(i + 1) & 1] = read_v(cur, i + 1);
         if (i == NU - 1) {
-          // every store of chunk kc + 1 has been issued and every wave holds its last fragment of chunk kc
+          read_v25(cur);
+          // every store of chunk kc + 1 has been issued and every wave holds its last fragments of chunk kc
           __syncthreads();
           if constexpr (ST) vf[0] = read_v(cur ^ 1, 0);
         }
@@ -295,12 +319,24 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
         if (i == 7) side(cur ^ 1, std::integral_constant<int, 7>{}, st_c, ld_c);
         __builtin_amdgcn_sched_barrier(0);
       }
+#if !(WINO42_EXP & 32)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc25 = __builtin_amdgcn_mfma_f32_16x16x4f32(u25[s], v25[s], acc25, 0, 0, 0);
+#endif
+      if constexpr (ST) load_u25(kc + 1);
+      __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- epilogue: the two output-channel halves, one after the other.  The half is a compile-time constant of the code a
     // wave runs, so that its accumulators are provably dead once they have left for LDS (the transform needs ~180 registers) ----
     // e_nt / e_mask0: output-channel block and destination of THIS item (the gather state already belongs to the next one)
+    // position 24: lane = tile 16 tb25 + l % 16, registers = output channels 16 cb25 + 4 (l / 16) + r; the waves whose block lies
+    // in half hp (cb25 >> 1 == hp) write it while that half's image is open for writing
+    auto store25 = [&]() __attribute__((always_inline)) {
+      *reinterpret_cast<f32x4*>(lds + 24 * W2XP + (tb25 * 16 + (lane & 15)) * W2XT + (cb25 & 1) * 16 + (lane >> 4) * 4) = acc25;
+    };
     auto pass = [&](int hp, int e_nt, auto mid_c) __attribute__((always_inline)) {
+      if ((cb25 >> 1) == hp) store25();
       // accumulator lane = tile lr, register e = output channel 8 * (e / 4) + 4 * lh + e % 4 of the half
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
@@ -392,6 +428,7 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
       for (int i = 0; i < NP; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+      acc25 = f32x4{0.f, 0.f, 0.f, 0.f};
       const int e_nt = n_tile;
       rs_u = u_rsrc();
       // prologue: chunk 0 transformed into buffer 0, chunk 1 in flight, the first NP filter fragments requested
@@ -404,6 +441,7 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < NP; ++a) load_u(a, 0, 0);
+      load_u25(0);
       tick(9);
       __syncthreads();
       tick(1);
@@ -422,6 +460,7 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
         for (int i = 0; i < NP; ++i)
 #pragma unroll
           for (int e = 0; e < 16; ++e) keep += acc[i][e];
+        keep += acc25[0] + acc25[1] + acc25[2] + acc25[3];
         if (keep == 12345.678f) p.dst[tid] = keep;
         __syncthreads();
         continue;
@@ -429,8 +468,10 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
 #endif
       if (h == 0) {
         pass(0, e_nt, T{});
+        if (cb25 >> 1) store25();                     // (waves 4, 6: their block belongs to half 1, open since the mid barrier)
         __syncthreads();                              // pass 1 is in LDS
       } else {
+        if (!(cb25 >> 1)) store25();                  // (waves 1, 3: their block belongs to half 0)
         __syncthreads();                              // pass 0 is in LDS
         __syncthreads();                              // pass 0 has been read
         pass(1, e_nt, F{});
@@ -454,11 +495,8 @@ __global__ __launch_bounds__(512) void wino42_kernel(WinoParams p) {
       o[0] = (float)nk;
     }
 #endif
-  };
+  }
 
-  if (item0 >= item1) return;
-  if (wave < 2) role(std::integral_constant<int, 7>{});
-  else role(std::integral_constant<int, 6>{});
 }
 
 // ---- host side (dispatch and geometry live in conv_wino.hip: variant 7) ----

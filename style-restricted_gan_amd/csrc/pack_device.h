@@ -324,7 +324,7 @@ __device__ __forceinline__ void halo16s_pack_item(const WinoPackParams& p, long 
 
 // variant 7, F(4x4,2x2) (conv_wino42.hip):  U = G g G^T (5x5 from the 2x2 taps of a phase), G = [1/2 0; -1/2 -1/2; -1/6 1/6;
 // 1/6 1/3; 0 1], laid out [out phase][n_tile (64 couts)][chunk (16 ch)][25 pos][8-ch half][cout half][lane = lh * 32 + cout][4 ch]:
-// the A-operand register image of wino42_kernel.  kind 0 (strided form): reduce index k = (input phase pq, c), g[a][b] =
+// the A-operand register image of wino42_kernel (position 24 in the image of the 16x16x4 MFMA, see the end of the function).  kind 0 (strided form): reduce index k = (input phase pq, c), g[a][b] =
 // w[n][c][2a+p][2b+q];  kind 1 (transposed form): one image per OUTPUT phase rs, g[a][b] = w[c][n][3-2a-r][3-2b-s].
 __device__ __forceinline__ void wino42_pack_item(const WinoPackParams& p, long long idx) {
   long long r = idx;
@@ -374,9 +374,14 @@ __device__ __forceinline__ void wino42_pack_item(const WinoPackParams& p, long l
       u[a * 5 + 4][j] = y;
     }
   }
-  float* out = p.dst + ((((size_t)ophase * p.n_tiles + ntile) * p.nchunk + chunk) * 25) * 1024 + hb * 512 + h * 256 + lh * 128 + nl * 4;
+  float* img = p.dst + ((((size_t)ophase * p.n_tiles + ntile) * p.nchunk + chunk) * 25) * 1024;
+  float* out = img + hb * 512 + h * 256 + lh * 128 + nl * 4;
 #pragma unroll
-  for (int k = 0; k < 25; ++k) *reinterpret_cast<f32x4*>(out + k * 1024) = u[k];
+  for (int k = 0; k < 24; ++k) *reinterpret_cast<f32x4*>(out + k * 1024) = u[k];
+  // position 24 is multiplied on the 16x16x4 MFMA: [16-channel block of the 64][lane = (channel & 3) * 16 + cout & 15][channel quad]
+  float* o24 = img + 24 * 1024 + (2 * h + (nl >> 4)) * 256 + (nl & 15) * 4 + (2 * hb + lh);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o24[j * 64] = u[24][j];
 }
 
 __device__ __forceinline__ void wino_pack_item(const WinoPackParams& p, long long idx) {
