@@ -381,6 +381,26 @@ size_t srgan_prdc_workspace(int N, int M);
 int srgan_prdc_from_dist(const float* dist, int N, int M, const float* r_real, const float* r_fake, int nearest_k,
                          float* out4, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- collectives of the data-parallel step (SURVEY.md 8 e) -----------------------------------------------------------
+ * What replaces torch.nn.DataParallel(net, devices=[0,1,2,3]) of notebook/05-train_Style-Restricted_GAN.ipynb:404-407,446
+ * (scatter the batch, replicate the module, gather the outputs, reduce the gradients on device 0): one process per GPU with
+ * persistent replicas, a bucketed in-place gradient all-reduce and an all-gather of the encoder's mu rows, over RCCL (xGMI).
+ * librccl.so is bound lazily at the first call (srgan_comm_available() asks without a communicator); `comm` is an opaque
+ * ncclComm_t.  The calls only enqueue on `stream` (capturable into a hipGraph on a communication stream); buffers are device
+ * memory owned by the caller; rendezvous -- moving the 128-byte id from rank 0 to the others -- is the caller's.
+ * Return values: 0, <0 invalid argument / library unavailable, 1000 + ncclResult_t for an RCCL error. */
+int srgan_comm_available(void);
+int srgan_comm_unique_id(void* id128);                          /* rank 0: ncclGetUniqueId */
+int srgan_comm_init(const void* id128, int nranks, int rank, void** comm);
+int srgan_comm_size(void* comm, int* nranks);
+int srgan_comm_destroy(void* comm);
+/* gradient bucket: in-place all-reduce of `count` elements (fp32, or bf16 when `bf16` = 1), sum or average over the ranks --
+ * DataParallel's reduce_add of the replicas' gradients (torch/nn/parallel/_functions.py as used by the notebook's wrapper) */
+int srgan_allreduce_bucket(void* comm, void* buf, long long count, int bf16, int average, void* stream);
+/* mu rows of every rank, rank-major: the gather of the replicas' encoder outputs DataParallel performs before the batch-statistics
+ * losses of pyfiles/util.py:455-553 see the GLOBAL batch */
+int srgan_allgather_rows(void* comm, const float* rows, float* all_rows, long long count_per_rank, void* stream);
+
 /* ---- launch timer for bench.py's roofline leg (no reference counterpart) ---------------------
  * While enabled every implicit-GEMM / weight-gradient launch is bracketed by HIP events on its own
  * stream and tagged with its algorithmic FLOPs (2*N*Ho*Wo*O*kh*kw*I).  Collect after a device sync. */

@@ -42,6 +42,13 @@ _DESC = POINTER(ConvDesc)
 # name -> (restype, argtypes); must list EVERY symbol include/srgan_hip.h declares
 SIGNATURES = {
     "srgan_abi_version": (c_int, []),
+    "srgan_comm_available": (c_int, []),
+    "srgan_comm_unique_id": (c_int, [P]),
+    "srgan_comm_init": (c_int, [P, c_int, c_int, POINTER(c_void_p)]),
+    "srgan_comm_size": (c_int, [P, POINTER(c_int)]),
+    "srgan_comm_destroy": (c_int, [P]),
+    "srgan_allreduce_bucket": (c_int, [P, P, c_longlong, c_int, c_int, P]),
+    "srgan_allgather_rows": (c_int, [P, P, P, c_longlong, P]),
     "srgan_last_error": (ctypes.c_char_p, []),
     "srgan_conv2d_workspace": (c_size_t, [_DESC]),
     "srgan_conv2d_fwd": (c_int, [_DESC, P, P, P, P, c_int, c_float, P, c_size_t, P]),

@@ -62,6 +62,8 @@ def init_from_env(backend=None):
         global _control
         _control = None
         control_group()
+        if _transport == "abi" and use_gpu:
+            _abi_comm()              # here, collectively and on the main thread -- not in the first bucket's autograd hook
         _gather_into_tensor.clear()
         _probe_gather_into_tensor(device)
     if os.environ.get("SRGAN_DP_BUCKET_DTYPE"):          # "fp32" / "bf16": see set_bucket_dtype (default: follow the compute mode)
@@ -118,6 +120,61 @@ def set_recorder(rec):
     _recorder = rec
 
 
+# ---- transport of the GPU collectives --------------------------------------------------------------------------------
+# "torch" (default): torch.distributed's nccl backend (= RCCL) issues them.  "abi" (SRGAN_DP_COMM=abi, or set_transport): the
+# library's own entry points over RCCL (csrc/comm.cpp: srgan_allreduce_bucket / srgan_allgather_rows) -- the C-ABI form of the
+# same two exchanges, enqueued on the current stream like any other kernel of the step.  The communicator is
+# made once per process; its 128-byte id travels from rank 0 over the host-side control group.  Only GPU tensors take it (a
+# gloo / CPU run has nothing to hand to RCCL); torch.distributed stays the rendezvous either way.
+_transport = os.environ.get("SRGAN_DP_COMM", "torch")
+_abi = None                   # (communicator handle, library) once made
+
+
+def set_transport(name):
+    global _transport
+    if name not in ("torch", "abi"):
+        raise ValueError(f"set_transport: {name!r}")
+    _transport = name
+
+
+def transport():
+    return _transport
+
+
+def _abi_comm():
+    """The process's RCCL communicator behind the C ABI, created collectively at first use."""
+    global _abi
+    if _abi is None:
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        if not lib.srgan_comm_available():
+            raise _lib.SrganHipError("SRGAN_DP_COMM=abi: librccl.so is not loadable on this host")
+        buf = ctypes.create_string_buffer(128)
+        if dist.get_rank() == 0:
+            _lib.check(lib.srgan_comm_unique_id(buf), "srgan_comm_unique_id")
+        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        dist.broadcast(t, 0, group=control_group())
+        ident = ctypes.create_string_buffer(bytes(t.tolist()), 128)
+        comm = ctypes.c_void_p()
+        with _stdout_to_stderr():
+            _lib.check(lib.srgan_comm_init(ident, dist.get_world_size(), dist.get_rank(), ctypes.byref(comm)), "srgan_comm_init")
+        _abi = (comm, lib)
+    return _abi
+
+
+def abi_comm_destroy():
+    global _abi
+    if _abi is not None:
+        comm, lib = _abi
+        _abi = None
+        lib.srgan_comm_destroy(comm)
+
+
+def _use_abi(t):
+    return _transport == "abi" and t.is_cuda
+
+
 _gather_into_tensor = {}      # backend name -> bool: does it implement all_gather_into_tensor (probed once, collectively)
 
 
@@ -143,6 +200,12 @@ def _all_gather_into(out, src):
     """Rank-ordered rows of every rank's ``src`` into ONE preallocated tensor (``all_gather_into_tensor``: RCCL writes the
     destination directly; a list of per-rank views may be staged through an internal flat buffer and copied out).  Backends
     without the call get the list form on views of ``out`` -- same result.  Errors of the chosen call propagate."""
+    if _use_abi(src) and src.dtype == torch.float32:
+        from . import _lib
+        comm, lib = _abi_comm()
+        _lib.check(lib.srgan_allgather_rows(comm, src.data_ptr(), out.data_ptr(), src.numel(), torch.cuda.current_stream(src.device).cuda_stream),
+                   "srgan_allgather_rows")
+        return
     if _probe_gather_into_tensor(src.device):
         dist.all_gather_into_tensor(out, src)
     else:
@@ -244,6 +307,14 @@ class _Bucket:
         """In-place average of the message across the ranks, then (bf16 message) widened into the fp32 buffer.  Runs on whatever
         stream is current: the communication stream."""
         msg = self.message()
+        if _use_abi(msg):
+            from . import _lib
+            comm, lib = _abi_comm()
+            _lib.check(lib.srgan_allreduce_bucket(comm, msg.data_ptr(), msg.numel(), 1 if msg.dtype == torch.bfloat16 else 0, 1,
+                                                  torch.cuda.current_stream(msg.device).cuda_stream), "srgan_allreduce_bucket")
+            if self.wire is not None:
+                self.flat.copy_(msg)
+            return
         dist.all_reduce(msg, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
         if self.wire is not None:
             self.flat.copy_(msg)

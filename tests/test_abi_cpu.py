@@ -36,6 +36,11 @@ def test_invalid_arguments_are_reported_without_a_gpu(built_lib):
     assert lib.srgan_adam_step(None, None, None, None, 10, 1e-3, 0.5, 0.999, 1e-8, 1, None) == -1
     with pytest.raises(built_lib.SrganHipError, match="adam"):
         built_lib.check(-1, "adam")
+    # collectives (csrc/comm.cpp): argument errors come back before RCCL is touched
+    assert lib.srgan_allreduce_bucket(None, None, 16, 0, 1, None) == -1 and b"no communicator" in lib.srgan_last_error()
+    assert lib.srgan_allgather_rows(None, None, None, 8, None) == -1 and b"no communicator" in lib.srgan_last_error()
+    assert lib.srgan_comm_init(None, 2, 0, None) == -1 and lib.srgan_comm_destroy(None) == 0
+    assert lib.srgan_comm_available() in (0, 1)
 
 
 def test_product_refuses_cpu_tensors(built_lib):

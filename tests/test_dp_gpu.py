@@ -196,17 +196,24 @@ def test_failed_recording_on_one_rank_makes_every_rank_fall_back(inject):
         assert d <= 1e-5, (key, d)
 
 
+@pytest.mark.parametrize("transport", ["torch", "abi"])
 @pytest.mark.parametrize("graph", [False, True])
-def test_rccl_path_one_rank_equals_plain_step(graph):
+def test_rccl_path_one_rank_equals_plain_step(graph, transport):
     """The real RCCL calls on the test box's one GPU: a one-rank ``nccl`` process group with SRGAN_DP_FORCE=1 takes the whole
     data-parallel path -- hook-driven buckets with the G and E reducers armed together, in-place all-reduce of the flat buffers
     on the communication stream (asynchronous: only the ready / done events order it against the compute stream), the mu
     all-gather inside autograd, gradients bound to bucket slices, parameters without gradient left at None -- and must
     reproduce the plain single-process step.  (Two ranks cannot share a device under RCCL; the 2-rank arithmetic is the gloo
     test above.)  graph=True: the same with the step recorded as hipGraph segments, the RCCL all-reduces and the all-gather
-    issued eagerly between the segments on every replay."""
+    issued eagerly between the segments on every replay.  transport="abi" (SRGAN_DP_COMM=abi): the same exchanges through the
+    library's own C-ABI entry points over RCCL (srgan_comm_init with the id from rank 0, srgan_allreduce_bucket,
+    srgan_allgather_rows) instead of torch.distributed's."""
     ref_losses, ref_state, ref_terms = _run(0, 1)
-    (rank, losses, state, terms), = _spawn(1, lambda r, port, q: (0, 1, port, q, 0.0, "nccl", True, graph))
+    os.environ["SRGAN_DP_COMM"] = transport
+    try:
+        (rank, losses, state, terms), = _spawn(1, lambda r, port, q: (0, 1, port, q, 0.0, "nccl", True, graph))
+    finally:
+        os.environ.pop("SRGAN_DP_COMM", None)
     np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=1e-4)
     for key, v in state.items():
         d = float(np.abs(v - ref_state[key]).max())
@@ -296,3 +303,61 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert rec["config"]["parallelism"] == "dp2" and not rec["config"]["graph_fallback"]
     assert "hipGraph segments" in rec["config"]["execution"] and rec["value"] > 0
     assert all(np.isfinite(rec["config"]["losses_last_step"]))
+
+
+def test_abi_collectives_one_rank_eager_and_captured():
+    """The C-ABI collectives (csrc/comm.cpp) without torch.distributed: a one-rank communicator from srgan_comm_unique_id /
+    srgan_comm_init, then an in-place fp32 and bf16 bucket all-reduce (average over one rank = identity) and the row gather,
+    eagerly on a side stream and CAPTURED into a hipGraph on that stream (fork / join by events inside the capture, the form a
+    single-graph data-parallel step takes); replays leave the data intact and RCCL reports no error.  Multi-rank execution of
+    the same calls needs more than one device: unmeasured on this pool."""
+    import ctypes
+    from srgan_amd import _lib
+    lib = _lib.load()
+    assert lib.srgan_comm_available() == 1
+    ident = ctypes.create_string_buffer(128)
+    _lib.check(lib.srgan_comm_unique_id(ident), "id")
+    comm = ctypes.c_void_p()
+    torch.cuda.set_device(0)
+    _lib.check(lib.srgan_comm_init(ident, 1, 0, ctypes.byref(comm)), "init")
+    n = ctypes.c_int(0)
+    _lib.check(lib.srgan_comm_size(comm, ctypes.byref(n)), "size")
+    assert n.value == 1
+    try:
+        g = torch.Generator(device="cuda").manual_seed(3)
+        buf = torch.randn(1 << 20, device="cuda", generator=g)
+        buf16 = torch.randn(1 << 18, device="cuda", generator=g).to(torch.bfloat16)
+        rows = torch.randn(32, 8, device="cuda", generator=g)
+        want, want16 = buf.clone(), buf16.clone()
+        side = torch.cuda.Stream()
+
+        def exchange():
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                st = side.cuda_stream
+                _lib.check(lib.srgan_allreduce_bucket(comm, buf.data_ptr(), buf.numel(), 0, 1, st), "allreduce fp32")
+                _lib.check(lib.srgan_allreduce_bucket(comm, buf16.data_ptr(), buf16.numel(), 1, 1, st), "allreduce bf16")
+                out = torch.empty_like(rows)
+                _lib.check(lib.srgan_allgather_rows(comm, rows.data_ptr(), out.data_ptr(), rows.numel(), st), "allgather")
+            torch.cuda.current_stream().wait_stream(side)
+            return out
+
+        out = exchange()
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want) and torch.equal(buf16, want16) and torch.equal(out, rows)
+        graph = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream()
+        with torch.cuda.stream(cap):
+            with torch.cuda.graph(graph, stream=cap):
+                buf.mul_(2.0)                      # compute before the exchange, on the capture stream
+                out_g = exchange()                 # forked onto the side stream inside the capture, joined again
+                buf.add_(1.0)
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        exp = want
+        for _ in range(3):
+            exp = exp * 2.0 + 1.0
+        assert torch.allclose(buf, exp) and torch.equal(buf16, want16) and torch.equal(out_g, rows)
+    finally:
+        _lib.check(lib.srgan_comm_destroy(comm), "destroy")
