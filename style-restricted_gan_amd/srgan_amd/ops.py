@@ -484,6 +484,7 @@ def _run_conv_wgrad(desc, x, dy, dw, dbias, v_image=None):
 # weight-gradient calls (``srgan_wgrad_defer_begin``): they wait in an arena and run as a few large launches instead of one
 # ~12 us launch per layer (145 per train step).  ``SRGAN_NO_WGRAD_DEFER=1`` keeps the immediate sums.
 _grad_sink = None
+_sink_alloc = None          # optional callable(parameter) -> buffer for its first contribution of a pass (dp.grad_slot), or None
 _sink_seed = False
 _defer_depth = 0
 _NO_WGRAD_DEFER = _lib.ab("SRGAN_NO_WGRAD_DEFER")
@@ -567,7 +568,10 @@ def _sink_slots(*params):
                 _grad_sink[id(p)] = (p, p.grad)
             return [p.grad for p in params], True
         for p in params:
-            _grad_sink[id(p)] = (p, torch.empty(p.shape, dtype=torch.float32, device=p.device))
+            buf = _sink_alloc(p) if _sink_alloc is not None else None      # data parallel: the parameter's bucket slice
+            if buf is None:
+                buf = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+            _grad_sink[id(p)] = (p, buf)
     return [_grad_sink[id(p)][1] for p in params], seen[0]
 
 

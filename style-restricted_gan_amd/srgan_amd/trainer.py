@@ -155,6 +155,7 @@ class SRGAN_training():
         red = self._reducers.get(name)
         if red is None:
             red = self._reducers[name] = dp.GradReducer(self._opt_params(opt))
+            ops._sink_alloc = dp.grad_slot      # the weight-gradient kernels of a recorded step write into the bucket slices
         return red
 
     def _reduce_arm(self, name, opt):
