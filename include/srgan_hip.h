@@ -142,6 +142,9 @@ int srgan_wgrad_defer_begin(void* arena, size_t arena_bytes, void* stream);
 int srgan_wgrad_defer_end(void);
 /* Process totals since load: slab sums that went through the queue, and the launches that ran them. */
 int srgan_wgrad_defer_stats(long long* sums, long long* launches);
+/* Workspace bytes the deferrable calls since the last srgan_wgrad_defer_begin asked for (whether or not they fitted): an arena
+ * of that size holds a whole pass without an early flush -- the caller sizes it from its first pass instead of guessing. */
+int srgan_wgrad_defer_need(long long* bytes);
 int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, const float* dy, float* dw,
                        float* dbias, void* ws, size_t ws_bytes, void* stream);
 

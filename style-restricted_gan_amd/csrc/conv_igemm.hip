@@ -2406,6 +2406,7 @@ struct WgradDefer {
   bool active = false;
   char* arena = nullptr;
   size_t bytes = 0, used = 0;
+  size_t asked = 0;         // workspace bytes the deferrable calls of the scope asked for (srgan_wgrad_defer_need)
   hipStream_t st = nullptr;
   std::vector<MultiReduceEntry> pending;
 };
@@ -2462,6 +2463,7 @@ static int defer_take(const srgan_conv_desc* d, void** ws, size_t* ws_bytes, hip
   if (!q.active) return 0;
   if (st != q.st) return 0;          // a call on another stream (the discriminator's second scale): immediate sum, own scratch
   const size_t need = (size_t)round_up((long long)srgan_conv2d_workspace(d), 256);
+  q.asked += need;
   if (need == 0 || need > q.bytes) return 0;
   if (q.used + need > q.bytes)
     if (int e = defer_launch_pending(true)) return e;
@@ -2572,6 +2574,7 @@ extern "C" int srgan_wgrad_defer_begin(void* arena, size_t arena_bytes, void* st
   srgan::g_defer.arena = static_cast<char*>(arena);
   srgan::g_defer.bytes = arena_bytes & ~(size_t)255;
   srgan::g_defer.used = 0;
+  srgan::g_defer.asked = 0;
   srgan::g_defer.st = as_stream(stream);
   srgan::g_defer.pending.clear();
   return 0;
@@ -2582,6 +2585,13 @@ extern "C" int srgan_wgrad_defer_stats(long long* sums, long long* launches) {
   std::lock_guard<std::mutex> lock(srgan::g_defer_mutex);
   *sums = srgan::g_defer_sums;
   *launches = srgan::g_defer_launches;
+  return 0;
+}
+
+extern "C" int srgan_wgrad_defer_need(long long* bytes) {
+  SRGAN_REQUIRE(bytes, "wgrad_defer_need: null pointer");
+  std::lock_guard<std::mutex> lock(srgan::g_defer_mutex);
+  *bytes = (long long)srgan::g_defer.asked;
   return 0;
 }
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "srgan_wgrad_defer_begin": (c_int, [P, c_size_t, P]),
     "srgan_wgrad_defer_end": (c_int, []),
     "srgan_wgrad_defer_stats": (c_int, [POINTER(c_longlong), POINTER(c_longlong)]),
+    "srgan_wgrad_defer_need": (c_int, [POINTER(c_longlong)]),
     "srgan_conv2d_wgrad": (c_int, [_DESC, P, P, P, P, P, c_size_t, P]),
     "srgan_conv2d_wgrad_v_bytes": (c_size_t, [_DESC]),
     "srgan_conv2d_wgrad_v": (c_int, [_DESC, P, P, P, P, P, c_size_t, P]),

@@ -488,7 +488,9 @@ _sink_alloc = None          # optional callable(parameter) -> buffer for its fir
 _sink_seed = False
 _defer_depth = 0
 _NO_WGRAD_DEFER = _lib.ab("SRGAN_NO_WGRAD_DEFER")
-_WGRAD_ARENA_BYTES = 1024 << 20
+_WGRAD_ARENA_BYTES = 32 << 20      # first size; grown to what a pass asks for (below)
+_WGRAD_ARENA_MAX = 2048 << 20
+_arena_want = {}                    # device index -> bytes the largest pass so far asked for
 
 
 def _wgrad_arena(device=None):
@@ -496,11 +498,19 @@ def _wgrad_arena(device=None):
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
     # one arena per DEVICE: its uses are serialised by stream order (srgan_wgrad_defer_begin records the stream, a
-    # recorded step replays on the caller's stream), so a re-recorded step -- a new capture stream each time -- takes no new GiB
+    # recorded step replays on the caller's stream), so a re-recorded step -- a new capture stream each time -- takes no new GiB.
+    # Sized from use (it was a fixed 1 GiB): the library reports what the deferrable calls of a pass asked
+    # for (srgan_wgrad_defer_need); a pass that did not fit -- it still runs right, with an early flush of the queued sums --
+    # makes the NEXT scope take a larger arena.  A trainer's step 0 is eager, so the arena has its final size before a step is
+    # recorded; growing later drops the recordings (structure epoch), never while a capture is in flight.
     key = ("wgrad_arena", dev.index)
     a = _workspaces.get(key)
-    if a is None:
-        a = _workspaces[key] = torch.empty(_WGRAD_ARENA_BYTES, dtype=torch.uint8, device=dev)
+    want = min(max(_WGRAD_ARENA_BYTES, _arena_want.get(dev.index, 0)), _WGRAD_ARENA_MAX)
+    if a is None or (a.numel() < want and not torch.cuda.is_current_stream_capturing()):
+        if a is not None:
+            bump_structure_epoch()
+        want = (want + (16 << 20) - 1) // (16 << 20) * (16 << 20)
+        a = _workspaces[key] = torch.empty(want, dtype=torch.uint8, device=dev)
     return a
 
 
@@ -526,6 +536,7 @@ class fused_param_grads:
         self._defer = False
         if self._enabled and not _NO_WGRAD_DEFER and _defer_depth == 0:
             a = _wgrad_arena(self._device)
+            self._arena_index = a.device.index
             st = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
             _lib.check(_lib.load().srgan_wgrad_defer_begin(_ptr(a), a.numel(), st), "wgrad_defer_begin")
             self._defer = True
@@ -542,6 +553,11 @@ class fused_param_grads:
             err = _lib.load().srgan_wgrad_defer_end()          # the queued sums, before anyone binds or reads the buffers
             if et is None:
                 _lib.check(err, "wgrad_defer_end")
+            need = ctypes.c_longlong(0)
+            _lib.load().srgan_wgrad_defer_need(ctypes.byref(need))
+            idx = self._arena_index
+            if need.value > _arena_want.get(idx, 0):
+                _arena_want[idx] = int(need.value)
         if et is None and sink:
             with torch.no_grad():
                 for p, buf in sink.values():

@@ -909,7 +909,8 @@ def test_fused_param_grads_equal_autograd_accumulation(ops, mode, defer):
     for k in arena_keys():
         del ops._workspaces[k]
     ops._NO_WGRAD_DEFER = defer == "immediate"
-    ops._WGRAD_ARENA_BYTES = (48 << 20) if defer == "arena48m" else saved[1]
+    ops._WGRAD_ARENA_BYTES = (48 << 20) if defer == "arena48m" else (1 << 30)      # ("arena": one that holds the whole pass)
+    ops._arena_want.clear()
 
     def defer_stats():
         import ctypes
@@ -1368,8 +1369,27 @@ def test_wgrad_arena_is_one_per_device(ops):
             torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         assert len(arena_keys()) == 1, arena_keys()
+        # sized from use: a pass that asks for more than the arena holds still gives the right gradient (early
+        # flush) and makes the next scope take an arena that fits; after that it does not grow again
+        ops._WGRAD_ARENA_BYTES = 1 << 20
+        ops._arena_want.clear()
+        for k in arena_keys():
+            del ops._workspaces[k]
+        wb = (rnd(256, 256, 3, 3, seed=3) / 48).cuda().requires_grad_(True)
+        xb = rnd(8, 256, 32, 32, seed=4).cuda()
+        sizes, grads = [], []
+        for _ in range(3):
+            wb.grad = None
+            with ops.pack_cache(), ops.fused_param_grads(True):
+                ops.conv2d(xb, wb, None, 1, 1).sum().backward()
+            sizes.append(ops._workspaces[arena_keys()[0]].numel())
+            grads.append(wb.grad.clone())
+        assert sizes[1] > sizes[0] and sizes[2] == sizes[1], sizes
+        assert sizes[1] >= ops._arena_want[torch.cuda.current_device()]
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[1], grads[2])
     finally:
         ops._WGRAD_ARENA_BYTES = saved
+        ops._arena_want.clear()
         for k in arena_keys():
             del ops._workspaces[k]
         ops.invalidate_packed()
