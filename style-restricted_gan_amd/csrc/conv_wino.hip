@@ -843,7 +843,9 @@ static int wino_variant(const srgan_conv_desc* d, int kind) {
     if ((d->Hi & 1) || (d->Wi & 1)) return 0;
     // F(4x4,2x2): exact 4x4 tiling, 32 tiles x 64 channels per workgroup (one workgroup per CU); the same lower bound on the
     // device fill as below
-    if (!wino42_disabled() && d->Ho % 4 == 0 && d->Wo % 4 == 0 && N % 64 == 0 && C % 16 == 0) {
+    // (its epilogue addresses the destination through a buffer descriptor with 32-bit byte offsets: < 4 GiB)
+    const long long dst_elems = (long long)d->N * (kind == 0 ? (long long)d->Ho * d->Wo * d->O : (long long)d->Hi * d->Wi * d->I);
+    if (!wino42_disabled() && d->Ho % 4 == 0 && d->Wo % 4 == 0 && N % 64 == 0 && C % 16 == 0 && dst_elems < (1LL << 30)) {
       const long long b42 = ceil_div((long long)d->N * (d->Ho / 4) * (d->Wo / 4), 32) * (N / 64) * (kind == 1 ? 4 : 1);
       if (b42 >= 120 * wino_threshold_scale()) return 7;
     }
