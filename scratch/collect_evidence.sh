@@ -1,9 +1,9 @@
 #!/bin/bash
-# EV_FLAGS (optional, e.g. "--dtype bf16"): extra bench.py flags for every pass.
+# EV_FLAGS (optional, e.g. "--dtype bf16"): extra bench.py flags for every pass.  EV_OUT (optional): directory under gpurun_out/ (default ev).
 # One evidence run on the GPU box: un-profiled bench (with the CPU baseline and the micro-benchmark), --stats run,
 # FETCH_SIZE / WRITE_SIZE / MFMA-busy PMC passes (each in its own run, eager launches: same kernels as the graph replays).
 R=$(cd "$(dirname "$0")/.." && pwd)
-E=$R/gpurun_out/ev
+E=$R/gpurun_out/${EV_OUT:-ev}
 rm -rf $E && mkdir -p $E
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py $EV_FLAGS --steps 20 --warmup 5 > $E/bench_plain.json 2> $E/bench_plain.err || exit 1

@@ -4,7 +4,7 @@ profiles/: the kernel-stats CSV as is, and r<NN>_pmc_traffic.json = per-launch H
 import csv, glob, json, os, re, shutil, sys, collections
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ev = os.path.join(root, "gpurun_out", "ev")
+ev = os.path.join(root, "gpurun_out", os.environ.get("EV_OUT", "ev"))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
 pmc_tag = tag[:-6] if tag.endswith("_final") else tag      # r02_final -> r02_pmc_*.json; r02_bf16 -> r02_bf16_pmc_*.json
 
@@ -17,6 +17,8 @@ def prof_name(n):
     m = re.match(r"wgrad_kernel<\d+, \d+, \d+, \d+, (true|false)", n)
     if m:
         return "wgrad_kernel<%s>" % ("vec" if m.group(1) == "true" else "gen")
+    if n.startswith("wino42_kernel"):
+        return "wino42_kernel"
     m = re.match(r"wino_wgrad_kernel<(\d)>", n)
     if m:
         return "wino_wgrad_kernel" if m.group(1) == "0" else "wino_wgrad_kernel<4x4s2>"
