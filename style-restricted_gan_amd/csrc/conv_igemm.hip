@@ -47,10 +47,10 @@ static const char* const kProfNames[] = {
     "halo16_kernel", "halo16_wgrad_kernel", "halo16s2_wgrad_kernel", "halo16t_kernel", "rgbout_conv_kernel", "halo16s_kernel",
     // HBM-bound passes (norm.hip): the "flops" slot of their brackets carries ALGORITHMIC BYTES (tensor bytes each pass must move)
     "in_stats_partial", "in_apply", "in_bwd_partial", "in_bwd_apply", "in_fwd_slab", "in_bwd_slab", "igemm16_kernel",
-    "wino42_kernel", "wino42_wgrad_kernel",
+    "wino42_kernel",
     // the fused norm + Winograd-transform kernels of the trunk (conv_wino43.hip), HBM-bound too: bytes in the "flops" slot
     "in_fwd_slab_v", "in_bwd_slab_vz"};
-constexpr int kProfKernels = 41;
+constexpr int kProfKernels = 40;
 
 struct ProfScope {
   bool on;

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void in_fwd_slab_v16_kernel(const float* __
 int in_fwd_slab_v_launch(const float* x, const float* scale, const float* shift, float* mean, float* rstd, float* vimg, int N,
                          int C, float eps, int act, float slope, hipStream_t st) {
   // algorithmic bytes: the 32 x 32 x C tensor read once, its transform image (2.25x) written once
-  ProfToken tok = prof_begin(39, 3.25 * 4.0 * N * 1024.0 * C, st);
+  ProfToken tok = prof_begin(38, 3.25 * 4.0 * N * 1024.0 * C, st);
   hipLaunchKernelGGL(in_fwd_slab_v16_kernel, dim3((unsigned)(N * (C / 16))), dim3(256), 0, st, x, scale, shift, mean, rstd, vimg, N,
                        C, eps, act, slope);
   prof_end(tok, st);
@@ -361,7 +361,7 @@ int in_bwd_slab_vz_launch(const float* x, const float* gup, const float* scale, 
                           const float* rstd, float* dscale, float* dshift, float* vimg, float* zimg, int N, int C, int act,
                           float slope, hipStream_t st) {
   // algorithmic bytes: x and the upstream gradient read once, both transform images (2.25x each) written once
-  ProfToken tok = prof_begin(40, 6.5 * 4.0 * N * 1024.0 * C, st);
+  ProfToken tok = prof_begin(39, 6.5 * 4.0 * N * 1024.0 * C, st);
   hipLaunchKernelGGL(in_bwd_slab_vz_kernel, dim3((unsigned)(N * (C / 16))), dim3(256), 0, st, x, gup, scale, shift, mean, rstd, dscale,
                      dshift, vimg, zimg, N, C, act, slope);
   prof_end(tok, st);
