@@ -96,6 +96,9 @@ CONV_CASES = [
     (6, 32, 15, 15, 64, 3, 1, 1, True, False),    # E.layers.2 map size, reflect
     (2, 96, 13, 18, 32, 3, 1, 1, True, True),     # odd sizes in both directions, 3 channel groups, one cout block, bias
     (16, 64, 66, 66, 64, 3, 1, 1, True, False),   # bf16 mode: 545 pixel tiles of igemm16_kernel on <= 512 persistent workgroups (reflect, 64 couts)
+    (9, 256, 64, 16, 64, 4, 2, 1, False, False),  # round 5: 256 input channels keep the strided 4x4 / stride-2 form OFF F(4x4,2x2) (1024 reduce terms: 2.07e-5 there); its input gradient (64 reduce channels) takes it
+    (4, 128, 32, 48, 192, 4, 2, 1, False, True),  # round 5: F(4x4,2x2) both directions, 3 channel blocks forward, 24 tiles per image (ragged 32-tile blocks), bias
+    (40, 64, 16, 16, 64, 4, 2, 1, False, False),  # round 5: F(4x4,2x2) transposed form on 160 tiles x 4 phases = 20 items over persistent workgroups
 ]
 
 
