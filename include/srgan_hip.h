@@ -216,6 +216,10 @@ int srgan_avgpool3s2_bwd(const float* dy, float* dx, int N, int H, int W, int C,
 /* nn.AvgPool2d(2,2) (floor)  model.py:365,368,426,429 */
 int srgan_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int srgan_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* The same with an fp32 or bf16 tensor on either side (C % 4 == 0): around the 16-bit convolutions of the style encoder in the
+ * bf16 mode (pyfiles/model.py:409-411). */
+int srgan_avgpool2_fwd_io(const void* x, int x_bf16, void* y, int y_bf16, int N, int H, int W, int C, void* stream);
+int srgan_avgpool2_bwd_io(const void* dy, int dy_bf16, void* dx, int dx_bf16, int N, int H, int W, int C, void* stream);
 /* LeakyReLU(slope) -> AdaptiveAvgPool2d(1)  (Encoder.last_layer, model.py:454,475-480) */
 int srgan_lrelu_gap_fwd(const float* x, float* y, int N, int HW, int C, float slope, void* stream);
 int srgan_lrelu_gap_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C, float slope, void* stream);
@@ -243,6 +247,18 @@ int srgan_halo16_conv(const srgan_conv_desc* d, int kind, const void* src, int s
                       void* dst, int dst_bf16, void* stream);
 int srgan_halo16_wgrad(const srgan_conv_desc* d, const void* x, int x_bf16, const void* dy, int dy_bf16, float* dw, void* ws,
                        size_t ws_bytes, void* stream);
+/* Round 5: the generic layers of the bf16 mode (no LDS-resident-patch kernel: the style encoder's 3x3 reflect-padded
+ * convolutions on 62 / 31 / 15 / 7-pixel maps, pyfiles/model.py:413-437) with bf16 TENSORS on either side.  srgan_igemm16_io_applicable:
+ * forward (with `act`), input gradient and weight gradient of d all run on the 64-deep-K-tile implicit GEMM and the vector
+ * weight-gradient kernel (bf16 mode, Cin % 64 == 0, Cout % 64 == 0 ...).  srgan_igemm16_conv: kind 0 forward (bias / activation as
+ * srgan_conv2d_fwd_packed), kind 1 input gradient (no bias / activation; reflect padding folds into dst's type); `packed`: the
+ * ordinary packed operand of (d, kind, act); ws: srgan_conv2d_packed_scratch(d, kind) bytes.  srgan_igemm16_wgrad: x and dy both
+ * bf16, dw fp32 through the descriptor's weight strides; ws: srgan_conv2d_workspace(d) bytes; honours
+ * srgan_set_wgrad_accumulate / the deferred slab sums like srgan_conv2d_wgrad. */
+int srgan_igemm16_io_applicable(const srgan_conv_desc* d, int act);
+int srgan_igemm16_conv(const srgan_conv_desc* d, int kind, const void* src, int src_bf16, const void* packed, const float* bias,
+                       void* dst, int dst_bf16, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int srgan_igemm16_wgrad(const srgan_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, void* stream);
 /* Single-pass instance norm (+ per-sample scale / shift, activation, optional fp32 skip tensor) of maps with <= 1024 pixels with
  * bf16 tensors on either side; statistics, sums, scale / shift gradients in fp32.  Backward: x = the normalised tensor's INPUT
  * (fp32 or bf16), dy fp32 or bf16, dx of x's type.  srgan_instnorm_slab_applicable: the shape is served (C % 32 == 0, HW <= 1024, enough slabs). */

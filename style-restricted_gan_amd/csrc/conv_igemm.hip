@@ -116,6 +116,7 @@ struct IgemmParams {
   int m_tiles, n_tiles;
   int ksplit, kt_per_split;      // split-K (blockIdx.z): K tiles [z * kt_per_split, ...) -> partial sums into dst + z * split_stride
   long long split_stride;
+  int src16, dst16;              // igemm16_kernel only: src / dst are bf16 tensors (the 16-bit activations of the bf16 mode)
 #ifdef SRGAN_EXPERIMENTS
   int exp;                       // timing ablations of igemm16_kernel (wrong results): scratch/README.md
 #endif
@@ -511,9 +512,10 @@ constexpr int BK16 = 64;
 constexpr int LDH16 = BK16 + 8;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int BN>
+template <int BN, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
   constexpr int BM = 128;
+  constexpr int ESZ = IN16 ? 2 : 4;         // bytes per source element
   constexpr int TN = BN / 64;               // 32-wide column blocks per wave (2 waves across N)
   constexpr int A_IT = BM / 32, B_IT = BN / 32;
   static_assert(BN == 128 || BN == 64, "BN");
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
     row_geom(m0 + (tid >> 3) + 32 * i, n, y0, x0, o);
     const bool rowok = y0 > -(1 << 27);
     const long long lin = rowok ? ((long long)(n * p.Hs + y0) * p.Ws + x0) * p.Cs : 0;
-    voff[i] = (unsigned)((lin + bias) * 4) + seg16;
+    voff[i] = (unsigned)((lin + bias) * ESZ) + seg16;
     unsigned m = 0, my = 0, mx = 0;
     if (p.reflect) {
       if (rowok) {
@@ -636,10 +638,10 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
   bool a_ok[A_IT];
   auto load_tiles = [&](int kt_rel) __attribute__((always_inline)) {
     const int k0 = (kt0 + kt_rel) * BK16;
-    const unsigned cs4 = p.Cs * 4;
+    const unsigned cs4 = p.Cs * ESZ;
     const long long tap_lin = p.reflect ? 0 : (long long)sgn * (tap_y * p.Ws + tap_x) * p.Cs;
-    const char* sb = reinterpret_cast<const char*>(p.src) + (tap_lin + tap_c - bias) * 4;   // wave-uniform
-    const unsigned safe = (unsigned)((bias - tap_lin) * 4) + seg16;                          // -> src + tap_c
+    const char* sb = reinterpret_cast<const char*>(p.src) + (tap_lin + tap_c - bias) * ESZ;   // wave-uniform
+    const unsigned safe = (unsigned)((bias - tap_lin) * ESZ) + seg16;                          // -> src + tap_c
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const bool ok = ((vmask[i] >> tap_y) & (vmask[i] >> (8 + tap_x)) & 1u) != 0;
@@ -650,8 +652,9 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
 #ifdef SRGAN_EXPERIMENTS
       if (p.exp & 1) { a_reg[i][0] = f32x4{1.f, 1.f, 1.f, 1.f}; a_reg[i][1] = a_reg[i][0]; a_ok[i] = ok; continue; }
 #endif
+      // IN16: the 64-channel slice of a pixel is 128 bytes -- one 16-byte piece per lane, already in LDS order
       a_reg[i][0] = *reinterpret_cast<const f32x4*>(sb + off);
-      a_reg[i][1] = *reinterpret_cast<const f32x4*>(sb + off + 128);
+      if constexpr (!IN16) a_reg[i][1] = *reinterpret_cast<const f32x4*>(sb + off + 128);
       a_ok[i] = ok;
     }
     tap_c += BK16;
@@ -677,6 +680,11 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int r = (tid >> 3) + 32 * i;
+      if constexpr (IN16) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&Ah[r * LDH16 + seg * 8]) = a_ok[i] ? a_reg[i][0] : z;
+        continue;
+      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         u32x2 v = __builtin_bit_cast(u32x2, __builtin_convertvector(a_reg[i][h], bf16x4));
@@ -765,7 +773,12 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
       for (int e = 0; e < 16; ++e) {
         const int o = ro[e >> 2][e & 3];
         const float v = acc[i][j][e] + bv;
-        if (nok && o >= 0) dst_base[(size_t)o * p.Cd + n] = v > 0.f ? v : (relu ? 0.f : v * neg);
+        const float r = v > 0.f ? v : (relu ? 0.f : v * neg);
+        if constexpr (OUT16) {      // (a split-K launch writes fp32 slabs: launch_igemm16 takes OUT16 only with ksplit == 1)
+          if (nok && o >= 0) reinterpret_cast<__bf16*>(dst_base)[(size_t)o * p.Cd + n] = (__bf16)r;
+        } else {
+          if (nok && o >= 0) dst_base[(size_t)o * p.Cd + n] = r;
+        }
       }
     }
   }
@@ -812,6 +825,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackEntry* __rest
 // ---- reflect-pad fold (dgrad of a reflect-padded conv) --------------------------------------
 // dxp: [N][H+2P][W+2P][C] gradient w.r.t. the padded image; dx[n][y][x][c] sums every padded
 // position that mirrors onto (y,x).  P = pad (1 in the reference).
+template <bool OUT16 = false>
 __global__ void reflect_fold_kernel(const float* dxp, float* dx, int N, int H, int W, int C, int P) {
   const long long total = (long long)N * H * W * C;
   const int Hp = H + 2 * P, Wp = W + 2 * P;
@@ -833,7 +847,8 @@ __global__ void reflect_fold_kernel(const float* dxp, float* dx, int N, int H, i
     float v = 0.f;
     for (int i = 0; i < ny; ++i)
       for (int j = 0; j < nx; ++j) v += dxp[((size_t)(n * Hp + ys[i]) * Wp + xs[j]) * C + c];
-    dx[idx] = v;
+    if constexpr (OUT16) reinterpret_cast<__bf16*>(dx)[idx] = (__bf16)v;
+    else dx[idx] = v;
   }
 }
 
@@ -855,9 +870,12 @@ struct WgradParams {
 // come from NHWC memory) and the MFMA operands -- 8 consecutive PIXELS of one channel per lane -- are fetched with the
 // transposing read ds_read_b64_tr_b16 (a 16-lane group reads 4 pixel rows x 16 channels and receives them column-major).
 // Row stride = channels * 2 + 64 bytes: the four rows of a block start 16 banks apart, the two blocks of a half 8 banks.
-template <int BMc, int BNn, int WM, int WN, bool VEC, bool ROWS = false, bool BF = false>
+// IO16 (with BF, without ROWS): x and dy are bf16 TENSORS (the 16-bit activations of the bf16 mode outside the patch kernels:
+// the style encoder's blocks); a staged piece is 4 channels = 8 bytes and goes to LDS as loaded.
+template <int BMc, int BNn, int WM, int WN, bool VEC, bool ROWS = false, bool BF = false, bool IO16 = false>
 __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel(WgradParams p) {
   static_assert(!BF || VEC, "the bf16 variant rides on the vector gather");
+  static_assert(!IO16 || (BF && !ROWS), "16-bit tensors: bf16 compute, generic row decode");
   constexpr int TM = BMc / (WM * 32), TN = BNn / (WN * 32);
   constexpr int NT = (WM * WN > 4 ? WM * WN : 4) * 64;   // threads: 4 waves (some idle for small tiles) or 8 waves
   constexpr int A_IT = 8 * BMc / NT, B_IT = 8 * BNn / NT;     // float4 per thread per 32-row tile
@@ -892,6 +910,7 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   f32x4 a_reg[A_IT], b_reg[B_IT];
+  u32x2 a16[A_IT], b16[B_IT];          // IO16: the staged pieces are 4 bf16 values
   float a_msk[A_IT], b_msk[B_IT];      // 0 / 1 per staged float4, applied when the tile is written to LDS (keeps the loads in flight)
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) a_msk[i] = 1.f;
@@ -1007,7 +1026,12 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
         // UNCONDITIONAL load from a clamped (always valid) address, masked at the LDS store: a load under a branch whose result is
         // merged with zeros makes the compiler wait for every load in turn (round 4: ~6 us per tile against 2 us of MFMAs)
         const bool ok = m < m_end && co < p.Cd;
-        a_reg[i] = *reinterpret_cast<const f32x4*>(p.dy + (ok ? (size_t)m * p.Cd + co : (size_t)0));
+        if constexpr (IO16) {
+          const u32x2 t = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.dy) + (ok ? (size_t)m * p.Cd + co : (size_t)0));
+          a16[i] = t;
+        } else {
+          a_reg[i] = *reinterpret_cast<const f32x4*>(p.dy + (ok ? (size_t)m * p.Cd + co : (size_t)0));
+        }
         a_msk[i] = ok ? 1.f : 0.f;
       } else {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -1029,7 +1053,12 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
         const int r = idx / B_PR, c4 = idx - r * B_PR;
         bool ok;
         const size_t off = gather(buf, r, ty, tx, ok);
-        b_reg[i] = *reinterpret_cast<const f32x4*>(p.x + (ok ? off + c0 + c4 * 4 : (size_t)0));      // (see the A operand above)
+        if constexpr (IO16) {
+          const u32x2 t = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.x) + (ok ? off + c0 + c4 * 4 : (size_t)0));
+          b16[i] = t;
+        } else {
+          b_reg[i] = *reinterpret_cast<const f32x4*>(p.x + (ok ? off + c0 + c4 * 4 : (size_t)0));      // (see the A operand above)
+        }
         b_msk[i] = ok ? 1.f : 0.f;
       }
     } else {
@@ -1072,13 +1101,23 @@ __global__ __launch_bounds__((WM * WN > 4 ? WM * WN : 4) * 64) void wgrad_kernel
       for (int i = 0; i < A_IT; ++i) {
         const int idx = tid + NT * i;
         const int r = idx / A_PR, c4 = idx - r * A_PR;
-        *reinterpret_cast<bf16x4*>(&Ah[r * LDA + c4 * 4]) = __builtin_convertvector(a_reg[i] * a_msk[i], bf16x4);
+        if constexpr (IO16) {
+          const u32x2 z = {0u, 0u};
+          *reinterpret_cast<u32x2*>(&Ah[r * LDA + c4 * 4]) = a_msk[i] != 0.f ? a16[i] : z;
+        } else {
+          *reinterpret_cast<bf16x4*>(&Ah[r * LDA + c4 * 4]) = __builtin_convertvector(a_reg[i] * a_msk[i], bf16x4);
+        }
       }
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int idx = tid + NT * i;
         const int r = idx / B_PR, c4 = idx - r * B_PR;
-        *reinterpret_cast<bf16x4*>(&Bh[r * LDB + c4 * 4]) = __builtin_convertvector(b_reg[i] * b_msk[i], bf16x4);
+        if constexpr (IO16) {
+          const u32x2 z = {0u, 0u};
+          *reinterpret_cast<u32x2*>(&Bh[r * LDB + c4 * 4]) = b_msk[i] != 0.f ? b16[i] : z;
+        } else {
+          *reinterpret_cast<bf16x4*>(&Bh[r * LDB + c4 * 4]) = __builtin_convertvector(b_reg[i] * b_msk[i], bf16x4);
+        }
       }
       return;
     }
@@ -1415,8 +1454,17 @@ static int launch_igemm16(IgemmParams p, int phases, hipStream_t st, double flop
   const long long planes = (long long)phases * std::max(p.ksplit, 1), tiles = (long long)p.m_tiles * p.n_tiles;
   const long long gx = std::min<long long>(tiles, std::max<long long>(8, (512 / planes) & ~7LL));
   dim3 grid((unsigned)gx, (unsigned)phases, (unsigned)std::max(p.ksplit, 1));
-  if (bn == 64) hipLaunchKernelGGL(igemm16_kernel<64>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(igemm16_kernel<128>, grid, dim3(256), 0, st, p);
+  const bool o16 = p.dst16 != 0 && p.ksplit <= 1;
+#define SRGAN_IG16(BN_)                                                                                      \
+  do {                                                                                                        \
+    if (p.src16 && o16) hipLaunchKernelGGL((igemm16_kernel<BN_, true, true>), grid, dim3(256), 0, st, p);      \
+    else if (p.src16) hipLaunchKernelGGL((igemm16_kernel<BN_, true, false>), grid, dim3(256), 0, st, p);       \
+    else if (o16) hipLaunchKernelGGL((igemm16_kernel<BN_, false, true>), grid, dim3(256), 0, st, p);           \
+    else hipLaunchKernelGGL((igemm16_kernel<BN_, false, false>), grid, dim3(256), 0, st, p);                  \
+  } while (0)
+  if (bn == 64) SRGAN_IG16(64);
+  else SRGAN_IG16(128);
+#undef SRGAN_IG16
   return check_launch("igemm16_kernel");
 }
 
@@ -1424,6 +1472,7 @@ static int launch_igemm16(IgemmParams p, int phases, hipStream_t st, double flop
 // maps): 64-200 four-wave workgroups walking 64-144 K tiles leave most SIMDs with one wave and nothing to hide its loads
 // behind (22-48 TFLOP/s).  The K range is cut into `ksplit` pieces (grid z), every piece writes raw partial sums into its own
 // destination-shaped slab, and splitk_reduce_kernel adds the slabs in split order (deterministic), the bias and the activation.
+template <bool OUT16 = false>
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int ksplit, long long n4, long long stride,
                                      const float* __restrict__ bias, int Cd, int act, float slope, float* __restrict__ dst) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -1432,7 +1481,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int ksplit,
     if (bias) v += *reinterpret_cast<const f32x4*>(bias + (i * 4) % Cd);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
-    *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+    if constexpr (OUT16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + i * 4) = __builtin_convertvector(v, bf16x4);
+    else *reinterpret_cast<f32x4*>(dst + i * 4) = v;
   }
 }
 
@@ -1482,8 +1532,13 @@ int run_igemm(IgemmParams p, int phases, hipStream_t st, double flops, float* sl
   if (int e = run_igemm_tiles(p, phases, st, flops)) return e;
   if (sk.ksplit > 1) {
     const long long n4 = sk.dst_elems / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(ceil_div(n4, 256), 4096))),
-                       dim3(256), 0, st, (const float*)slab, sk.ksplit, n4, sk.dst_elems, real_bias, p.Cd, real_act, p.slope, real_dst);
+    const dim3 rg((unsigned)std::max<long long>(1, std::min<long long>(ceil_div(n4, 256), 4096)));
+    if (p.dst16)
+      hipLaunchKernelGGL(splitk_reduce_kernel<true>, rg, dim3(256), 0, st, (const float*)slab, sk.ksplit, n4, sk.dst_elems, real_bias,
+                         p.Cd, real_act, p.slope, real_dst);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<false>, rg, dim3(256), 0, st, (const float*)slab, sk.ksplit, n4, sk.dst_elems, real_bias,
+                         p.Cd, real_act, p.slope, real_dst);
     return check_launch("splitk_reduce_kernel");
   }
   return 0;
@@ -1538,8 +1593,11 @@ struct WgradPlan { int BMc, BNn, splits, rows_per_split, Cdpad, NNpad, co_tiles,
 struct WgradVariant { void (*fn)(WgradParams); int threads; };
 
 template <int BMc, int BNn, int WM, int WN>
-static WgradVariant wgrad_variant(bool vec, bool rows) {
+static WgradVariant wgrad_variant(bool vec, bool rows, bool io16 = false) {
   constexpr int NT = (WM * WN > 4 ? WM * WN : 4) * 64;
+  if constexpr (BMc >= 64 && BNn >= 64) {
+    if (io16) return {wgrad_kernel<BMc, BNn, WM, WN, true, false, true, true>, NT};      // (wgrad_io16_ok: vec, not rows, bf16 mode)
+  }
   if constexpr (BMc >= 64 && BNn >= 64) {
     if (vec && rows && compute_bf16()) return {wgrad_kernel<BMc, BNn, WM, WN, true, true, true>, NT};
     if (vec && rows) return {wgrad_kernel<BMc, BNn, WM, WN, true, true>, NT};
@@ -1549,12 +1607,12 @@ static WgradVariant wgrad_variant(bool vec, bool rows) {
   return {wgrad_kernel<BMc, BNn, WM, WN, false>, NT};
 }
 
-static bool wgrad_lookup(int BMc, int BNn, bool vec, bool rows, WgradVariant* k) {
-  if (BMc == 128 && BNn == 128) *k = wgrad_variant<128, 128, 2, 2>(vec, rows);
-  else if (BMc == 128 && BNn == 64) *k = wgrad_variant<128, 64, 2, 2>(vec, rows);
+static bool wgrad_lookup(int BMc, int BNn, bool vec, bool rows, WgradVariant* k, bool io16 = false) {
+  if (BMc == 128 && BNn == 128) *k = wgrad_variant<128, 128, 2, 2>(vec, rows, io16);
+  else if (BMc == 128 && BNn == 64) *k = wgrad_variant<128, 64, 2, 2>(vec, rows, io16);
   else if (BMc == 128 && BNn == 32) *k = wgrad_variant<128, 32, 4, 1>(vec, rows);
-  else if (BMc == 64 && BNn == 128) *k = wgrad_variant<64, 128, 2, 2>(vec, rows);
-  else if (BMc == 64 && BNn == 64) *k = wgrad_variant<64, 64, 2, 2>(vec, rows);
+  else if (BMc == 64 && BNn == 128) *k = wgrad_variant<64, 128, 2, 2>(vec, rows, io16);
+  else if (BMc == 64 && BNn == 64) *k = wgrad_variant<64, 64, 2, 2>(vec, rows, io16);
   else if (BMc == 64 && BNn == 32) *k = wgrad_variant<64, 32, 2, 1>(vec, rows);
   else if (BMc == 32 && BNn == 128) *k = wgrad_variant<32, 128, 1, 4>(vec, rows);
   else if (BMc == 32 && BNn == 64) *k = wgrad_variant<32, 64, 1, 2>(vec, rows);
@@ -2079,7 +2137,7 @@ static int dgrad_run_core(const srgan_conv_desc* d, const float* dy, const float
   }
   if (g.reflect) {
     long long n = (long long)d->N * d->Hi * d->Wi * d->I;
-    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 256), 8192)), dim3(256), 0, st,
+    hipLaunchKernelGGL(reflect_fold_kernel<false>, dim3((unsigned)std::min<long long>(ceil_div(n, 256), 8192)), dim3(256), 0, st,
                        (const float*)scratch, dx, d->N, d->Hi, d->Wi, d->I, d->pad);
     return check_launch("reflect_fold_kernel");
   }
@@ -2382,9 +2440,9 @@ extern "C" int srgan_halo16_wgrad(const srgan_conv_desc* d, const void* x, int x
 }
 
 namespace srgan {
-static int launch_wgrad(const WgradParams& p, const WgradPlan& w, hipStream_t st) {
+static int launch_wgrad(const WgradParams& p, const WgradPlan& w, hipStream_t st, bool io16 = false) {
   WgradVariant k{};
-  if (!wgrad_lookup(w.BMc, w.BNn, w.vec, w.rows, &k)) { set_error("wgrad: unsupported tile %dx%d", w.BMc, w.BNn); return -1; }
+  if (!wgrad_lookup(w.BMc, w.BNn, w.vec, w.rows, &k, io16)) { set_error("wgrad: unsupported tile %dx%d", w.BMc, w.BNn); return -1; }
   ProfScope scope(8 + (w.vec ? 1 : 0), 2.0 * p.M * (double)p.Cd * p.NN, st);
   dim3 grid((unsigned)(w.co_tiles * w.nn_tiles * w.splits), 1, 1);
   hipLaunchKernelGGL(k.fn, grid, dim3(k.threads), 0, st, p);
@@ -2523,6 +2581,36 @@ static int finish_wgrad(const srgan_conv_desc* d, const WgradPlan& w, const floa
 }
 }  // namespace srgan
 
+namespace srgan {
+// the implicit-GEMM weight gradient (wgrad_kernel + slab sum); io16: x and dy are bf16 tensors (igemm16_io_ok layers)
+static int generic_wgrad(const srgan_conv_desc* d, const WgradPlan& w, const float* x, const float* dy, float* dw, float* dbias,
+                         void* ws, hipStream_t st, bool io16) {
+  WgradParams p{};
+  p.x = x; p.dy = dy; p.slab = (float*)ws;
+  p.NB = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cs = d->I; p.Hg = d->Ho; p.Wg = d->Wo; p.Cd = d->O;
+  p.stride = d->stride; p.pad = d->pad; p.kw = d->kw; p.reflect = d->pad_mode == SRGAN_PAD_REFLECT;
+  p.NN = d->kh * d->kw * d->I; p.NNpad = w.NNpad; p.Cdpad = w.Cdpad;
+  p.M = d->N * d->Ho * d->Wo; p.rows_per_split = w.rows_per_split;
+  p.co_tiles = w.co_tiles; p.nn_tiles = w.nn_tiles;
+  if (int e = launch_wgrad(p, w, st, io16)) return e;
+  return finish_wgrad(d, w, io16 ? nullptr : dy, dw, dbias, ws, st);
+}
+
+// every direction of the layer on the generic bf16 kernels, with the vector paths their 16-bit loads need
+static bool igemm16_io_ok(const srgan_conv_desc* d, int act) {
+  if (!compute_bf16() || (d->I & 3) || (d->O & 3)) return false;
+  if (fwd_path(d, act) != PATH_IGEMM) return false;
+  IgemmParams p{};
+  fwd_geometry(d, PATH_IGEMM, p);
+  if (!igemm16_ok(p)) return false;
+  const DgradGeom g = dgrad_geometry(d);
+  if (g.wino || g.narrow || g.rgbin || g.narrow_s2 || !igemm16_ok(g.p)) return false;
+  if (wino_wgrad_applicable(d) || rgb_wgrad_kind(d) >= 0 || narrow_applicable(d)) return false;
+  const WgradPlan w = plan_wgrad(d);
+  return w.vec && !w.rows && w.BMc >= 64 && w.BNn >= 64;
+}
+}  // namespace srgan
+
 extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, const float* dy, float* dw,
                                   float* dbias, void* ws, size_t ws_bytes, void* stream) {
   if (int e = validate(d)) return e;
@@ -2547,16 +2635,68 @@ extern "C" int srgan_conv2d_wgrad(const srgan_conv_desc* d, const float* x, cons
     w.splits = n_slabs; w.Cdpad = 4; w.NNpad = d->kh * d->kw * d->I;
     return finish_wgrad(d, w, dy, dw, dbias, ws, st);
   }
-  WgradParams p{};
-  p.x = x; p.dy = dy; p.slab = (float*)ws;
-  p.NB = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cs = d->I; p.Hg = d->Ho; p.Wg = d->Wo; p.Cd = d->O;
-  p.stride = d->stride; p.pad = d->pad; p.kw = d->kw; p.reflect = d->pad_mode == SRGAN_PAD_REFLECT;
-  p.NN = d->kh * d->kw * d->I; p.NNpad = w.NNpad; p.Cdpad = w.Cdpad;
-  p.M = d->N * d->Ho * d->Wo; p.rows_per_split = w.rows_per_split;
-  p.co_tiles = w.co_tiles; p.nn_tiles = w.nn_tiles;
-  int e = launch_wgrad(p, w, st);
-  if (e) return e;
-  return finish_wgrad(d, w, dy, dw, dbias, ws, st);
+  return generic_wgrad(d, w, x, dy, dw, dbias, ws, st, false);
+}
+
+// ---- bf16 mode, the generic layers (igemm16_kernel, wgrad_kernel<BF>) with bf16 TENSORS on either side: the 3x3 reflect-padded
+// convolutions of the style encoder's blocks (pyfiles/model.py:413-437), whose normalised inputs, outputs and the gradients of
+// both live in HBM as bf16 (srgan_amd.ops._ConvIoFn).  `packed`: the ordinary packed operand of (d, kind, act) in bf16 mode.
+extern "C" int srgan_igemm16_io_applicable(const srgan_conv_desc* d, int act) {
+  if (validate(d) != 0) return 0;
+  return igemm16_io_ok(d, act) ? 1 : 0;
+}
+
+extern "C" int srgan_igemm16_conv(const srgan_conv_desc* d, int kind, const void* src, int src_bf16, const void* packed,
+                                  const float* bias, void* dst, int dst_bf16, int act, float slope, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(src && packed && dst, "igemm16_conv: null pointer");
+  SRGAN_REQUIRE(kind == 0 || kind == 1, "igemm16_conv: kind must be 0 (forward) or 1 (input gradient)");
+  SRGAN_REQUIRE(kind == 0 || (!bias && act == SRGAN_ACT_NONE), "igemm16_conv: bias / activation belong to the forward");
+  SRGAN_REQUIRE(igemm16_io_ok(d, kind == 0 ? act : SRGAN_ACT_NONE), "igemm16_conv: layer / compute mode not applicable (srgan_igemm16_io_applicable)");
+  const size_t need = srgan_conv2d_packed_scratch(d, kind);
+  SRGAN_REQUIRE(need == 0 || (ws && ws_bytes >= need), "igemm16_conv: workspace too small (srgan_conv2d_packed_scratch)");
+  hipStream_t st = as_stream(stream);
+  if (kind == 0) {
+    IgemmParams p{};
+    fwd_geometry(d, PATH_IGEMM, p);
+    p.src = static_cast<const float*>(src); p.bias = bias; p.dst = static_cast<float*>(dst); p.act = act; p.slope = slope;
+    p.wp = static_cast<const float*>(packed); p.src16 = src_bf16 != 0; p.dst16 = dst_bf16 != 0;
+    return run_igemm(p, 1, st, conv_flops(d), need ? static_cast<float*>(ws) : nullptr);
+  }
+  DgradGeom g = dgrad_geometry(d);
+  float* scratch = need ? static_cast<float*>(ws) : nullptr;
+  g.p.src = static_cast<const float*>(src); g.p.wp = static_cast<const float*>(packed); g.p.src16 = src_bf16 != 0;
+  // reflect: the gradient with respect to the padded image stays an fp32 temp; the fold writes the tensor's type
+  g.p.dst = g.reflect ? scratch : static_cast<float*>(dst);
+  g.p.dst16 = g.reflect ? 0 : (dst_bf16 != 0);
+  float* slab = scratch ? (g.reflect ? scratch + round_up((long long)d->N * g.Hd * g.Wd * d->I, 64) : scratch) : nullptr;
+  if (int e = run_igemm(g.p, g.phases, st, conv_flops(d), slab)) return e;
+  if (g.reflect) {
+    const long long n = (long long)d->N * d->Hi * d->Wi * d->I;
+    const dim3 fg((unsigned)std::min<long long>(ceil_div(n, 256), 8192));
+    if (dst_bf16)
+      hipLaunchKernelGGL(reflect_fold_kernel<true>, fg, dim3(256), 0, st, (const float*)scratch, static_cast<float*>(dst), d->N, d->Hi,
+                         d->Wi, d->I, d->pad);
+    else
+      hipLaunchKernelGGL(reflect_fold_kernel<false>, fg, dim3(256), 0, st, (const float*)scratch, static_cast<float*>(dst), d->N, d->Hi,
+                         d->Wi, d->I, d->pad);
+    return check_launch("reflect_fold_kernel");
+  }
+  return 0;
+}
+
+// x, dy: bf16 tensors.  Same workspace, gradient sink and deferred slab sum as srgan_conv2d_wgrad.
+extern "C" int srgan_igemm16_wgrad(const srgan_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(x && dy && dw && ws, "igemm16_wgrad: null pointer");
+  SRGAN_REQUIRE(igemm16_io_ok(d, SRGAN_ACT_NONE), "igemm16_wgrad: layer / compute mode not applicable (srgan_igemm16_io_applicable)");
+  SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "igemm16_wgrad: workspace too small (srgan_conv2d_workspace)");
+  hipStream_t st = as_stream(stream);
+  if (int e = defer_take(d, &ws, &ws_bytes, st)) return e;
+  const WgradPlan w = plan_wgrad(d);
+  return generic_wgrad(d, w, static_cast<const float*>(x), static_cast<const float*>(dy), dw, nullptr, ws, st, true);
 }
 
 // A weight used more than once in one backward pass (the generator runs twice inside util_notebook.py:664 and :689) gets its

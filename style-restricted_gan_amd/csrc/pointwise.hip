@@ -108,6 +108,51 @@ __global__ void avgpool2_bwd_kernel(const float* dy, float* dx, int N, int H, in
   }
 }
 
+// AvgPool2d(2, 2) with an fp32 or bf16 tensor on either side (the bf16 mode's 16-bit activations around the style encoder's
+// convolutions, pyfiles/model.py:409-411): 4 channels per thread (C % 4 == 0), the mean in fp32.
+template <bool B16>
+__device__ __forceinline__ f32x4 ld4_io(const void* base, size_t idx) {
+  if constexpr (B16) return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(base) + idx), f32x4);
+  else return *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + idx);
+}
+template <bool B16>
+__device__ __forceinline__ void st4_io(void* base, size_t idx, f32x4 v) {
+  if constexpr (B16) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(base) + idx) = __builtin_convertvector(v, bf16x4);
+  else *reinterpret_cast<f32x4*>(static_cast<float*>(base) + idx) = v;
+}
+template <bool X16, bool Y16>
+__global__ void avgpool2_fwd_io_kernel(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * Ho * Wo * C4;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C4) * 4;
+    long long r = i / C4;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const size_t b = ((size_t)(n * H + oy * 2) * W + ox * 2) * C + c;
+    const f32x4 v = 0.25f * (ld4_io<X16>(x, b) + ld4_io<X16>(x, b + C) + ld4_io<X16>(x, b + (size_t)W * C) +
+                             ld4_io<X16>(x, b + (size_t)W * C + C));
+    st4_io<Y16>(y, (size_t)i * 4, v);
+  }
+}
+template <bool G16, bool D16>
+__global__ void avgpool2_bwd_io_kernel(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * H * W * C4;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C4) * 4;
+    long long r = i / C4;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    const int oy = y >> 1, ox = x >> 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (oy < Ho && ox < Wo) v = 0.25f * ld4_io<G16>(dy, ((size_t)(n * Ho + oy) * Wo + ox) * C + c);
+    st4_io<D16>(dx, (size_t)i * 4, v);
+  }
+}
+
 __global__ void lrelu_gap_fwd_kernel(const float* x, float* y, int N, int HW, int C, float slope) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * C) return;
@@ -359,6 +404,22 @@ extern "C" int srgan_avgpool2_fwd(const float* x, float* y, int N, int H, int W,
 extern "C" int srgan_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
   SRGAN_REQUIRE(dy && dx && N > 0 && H > 1 && W > 1 && C > 0, "avgpool2_bwd: bad argument");
   LAUNCH1D(avgpool2_bwd_kernel, (long long)N * H * W * C, stream, dy, dx, N, H, W, C, H / 2, W / 2);
+}
+extern "C" int srgan_avgpool2_fwd_io(const void* x, int x_bf16, void* y, int y_bf16, int N, int H, int W, int C, void* stream) {
+  SRGAN_REQUIRE(x && y && N > 0 && H > 1 && W > 1 && C > 0 && (C & 3) == 0, "avgpool2_fwd_io: bad argument (C % 4 == 0)");
+  const long long n = (long long)N * (H / 2) * (W / 2) * (C / 4);
+  if (x_bf16 && y_bf16) { LAUNCH1D((avgpool2_fwd_io_kernel<true, true>), n, stream, x, y, N, H, W, C, H / 2, W / 2); }
+  if (x_bf16) { LAUNCH1D((avgpool2_fwd_io_kernel<true, false>), n, stream, x, y, N, H, W, C, H / 2, W / 2); }
+  if (y_bf16) { LAUNCH1D((avgpool2_fwd_io_kernel<false, true>), n, stream, x, y, N, H, W, C, H / 2, W / 2); }
+  LAUNCH1D((avgpool2_fwd_io_kernel<false, false>), n, stream, x, y, N, H, W, C, H / 2, W / 2);
+}
+extern "C" int srgan_avgpool2_bwd_io(const void* dy, int dy_bf16, void* dx, int dx_bf16, int N, int H, int W, int C, void* stream) {
+  SRGAN_REQUIRE(dy && dx && N > 0 && H > 1 && W > 1 && C > 0 && (C & 3) == 0, "avgpool2_bwd_io: bad argument (C % 4 == 0)");
+  const long long n = (long long)N * H * W * (C / 4);
+  if (dy_bf16 && dx_bf16) { LAUNCH1D((avgpool2_bwd_io_kernel<true, true>), n, stream, dy, dx, N, H, W, C, H / 2, W / 2); }
+  if (dy_bf16) { LAUNCH1D((avgpool2_bwd_io_kernel<true, false>), n, stream, dy, dx, N, H, W, C, H / 2, W / 2); }
+  if (dx_bf16) { LAUNCH1D((avgpool2_bwd_io_kernel<false, true>), n, stream, dy, dx, N, H, W, C, H / 2, W / 2); }
+  LAUNCH1D((avgpool2_bwd_io_kernel<false, false>), n, stream, dy, dx, N, H, W, C, H / 2, W / 2);
 }
 extern "C" int srgan_lrelu_gap_fwd(const float* x, float* y, int N, int HW, int C, float slope, void* stream) {
   SRGAN_REQUIRE(x && y && N > 0 && HW > 0 && C > 0, "lrelu_gap_fwd: bad argument");

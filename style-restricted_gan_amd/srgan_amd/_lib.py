@@ -76,6 +76,9 @@ SIGNATURES = {
     "srgan_instnorm_bwd_io": (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "srgan_halo16_conv": (c_int, [_DESC, c_int, P, c_int, P, P, P, c_int, P]),
     "srgan_halo16_wgrad": (c_int, [_DESC, P, c_int, P, c_int, P, P, c_size_t, P]),
+    "srgan_igemm16_io_applicable": (c_int, [_DESC, c_int]),
+    "srgan_igemm16_conv": (c_int, [_DESC, c_int, P, c_int, P, P, P, c_int, c_int, c_float, P, c_size_t, P]),
+    "srgan_igemm16_wgrad": (c_int, [_DESC, P, P, P, P, c_size_t, P]),
     "srgan_instnorm_slab_applicable": (c_int, [c_int, c_int, c_int]),
     "srgan_instnorm_slab_fwd_io": (c_int, [P, c_int, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_float, P]),
     "srgan_instnorm_slab_bwd_io": (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P]),
@@ -106,6 +109,8 @@ SIGNATURES = {
     "srgan_avgpool3s2_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "srgan_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "srgan_avgpool2_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srgan_avgpool2_fwd_io": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "srgan_avgpool2_bwd_io": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "srgan_lrelu_gap_fwd": (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
     "srgan_lrelu_gap_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),
     "srgan_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),

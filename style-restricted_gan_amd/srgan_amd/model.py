@@ -49,6 +49,18 @@ class _Conv2d(nn.Conv2d):
         return (self.bias is None and self.kernel_size == (4, 4) and self.stride == (2, 2) and self.padding == (1, 1)
                 and self.padding_mode == "zeros" and ops.s2_io_applicable(n, ci, hi, wi, self.out_channels, self.weight, False))
 
+    def forward_io(self, x, out_bf16=True):
+        """bf16 mode, io_applicable layers: the input may be a bf16 tensor, the output is written as bf16 / fp32 (the style
+        encoder's blocks, ops.py "16-bit activations around the generic convolutions")."""
+        mode = PAD_REFLECT if self.padding_mode == "reflect" else PAD_ZERO
+        return ops.conv2d_io(x, self.weight, self.padding[0], mode, out_bf16)
+
+    def io_applicable(self, x):
+        n, ci, hi, wi = x.shape
+        mode = PAD_REFLECT if self.padding_mode == "reflect" else PAD_ZERO
+        return (self.bias is None and self.stride == (1, 1) and self.padding[0] == self.padding[1]
+                and ops.conv_io_applicable(n, ci, hi, wi, self.weight, self.padding[0], mode))
+
 
 class _ConvTranspose2d(nn.ConvTranspose2d):
     def forward(self, x, io16=None):
@@ -168,7 +180,17 @@ def _fork_input(x):
 
 class _AvgPool2(nn.Module):
     def forward(self, x):
+        if x.dtype == torch.bfloat16:        # a 16-bit conv output of the bf16 mode: the mean goes back to the fp32 stream
+            return ops.avgpool2_io(x, False)
         return ops.avgpool2(x)
+
+
+def _block_io16(x, conv1, conv2):
+    """Can an encoder block (norm -> conv1 -> norm -> conv2 -> pool) keep its four intermediates in bf16?  Both convolutions and
+    both norms must be served for THIS shape (each by its own geometry)."""
+    n, c, h, w = x.shape
+    return bool(x.is_cuda and (c & 3) == 0 and (conv2.out_channels & 3) == 0 and ops.norm_io_applicable(n, c, h, w)
+                and conv1.io_applicable(x) and conv2.io_applicable(x))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -501,6 +523,10 @@ class BasicBlock_classification(nn.Module):
 
     def forward(self, input):
         x = input
+        if _block_io16(x, self.conv1, self.cmp[0]):
+            h = self.conv1.forward_io(self.norm1(x, ACT_LRELU, self.nl1.negative_slope, out_bf16=True))
+            h = self.cmp[0].forward_io(self.norm2(h, ACT_LRELU, self.nl2.negative_slope, out_bf16=True))
+            return ops.add(self.cmp[1](h), self.shortcut(x))
         h = self.conv1(self.norm1(x, ACT_LRELU, self.nl1.negative_slope))
         h = self.cmp(self.norm2(h, ACT_LRELU, self.nl2.negative_slope))
         return ops.add(h, self.shortcut(x))
@@ -523,6 +549,10 @@ class BasicBlock(nn.Module):
 
     def forward(self, input):
         x, d = input
+        if _block_io16(x, self.conv1, self.cmp[0]):
+            h = self.conv1.forward_io(self.cnorm1(x, d, ACT_LRELU, self.nl1.negative_slope, out_bf16=True))
+            h = self.cmp[0].forward_io(self.cnorm2(h, d, ACT_LRELU, self.nl2.negative_slope, out_bf16=True))
+            return [ops.add(self.cmp[1](h), self.shortcut(x)), d]
         h = self.conv1(self.cnorm1(x, d, ACT_LRELU, self.nl1.negative_slope))
         h = self.cmp(self.cnorm2(h, d, ACT_LRELU, self.nl2.negative_slope))
         return [ops.add(h, self.shortcut(x)), d]

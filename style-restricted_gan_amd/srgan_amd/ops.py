@@ -1236,6 +1236,115 @@ def instance_norm_act_io(x, scale, shift, act=ACT_NONE, slope=0.0, eps=1e-5, out
     return _InstNormIoFn.apply(x, scale, shift, act, slope, eps, bool(out_bf16))
 
 
+# ---- bf16 compute mode: 16-bit activations around the GENERIC convolutions (round 5) --------------------------------------
+# The style encoder's blocks (reference pyfiles/model.py:413-437: norm -> LeakyReLU -> conv3x3 -> norm -> LeakyReLU -> conv3x3 ->
+# AvgPool2d, all reflect-padded, on 62 / 31 / 15 / 7-pixel maps) run on the implicit GEMM with 64-deep K tiles
+# (csrc/conv_igemm.hip: igemm16_kernel) and the vector weight-gradient kernel.  With fp32 tensors those layers are bound by their
+# own result and by the fp32 -> bf16 conversion on the way into LDS (profiles/LOG.md, round 4); here the tensors between the
+# norms, the convolutions and the pool are bf16:
+#     x (fp32, residual stream) -> norm1 (fp32 -> bf16) -> conv1 (bf16 -> bf16) -> norm2 (bf16 -> bf16) -> conv2 (bf16 -> bf16)
+#       -> AvgPool2d (bf16 -> fp32) -> + shortcut (fp32)
+# A bf16 norm OUTPUT changes no product (the convolution rounds its operand anyway), a bf16 conv OUTPUT is what torch.autocast
+# stores; gradients take the types of the tensors they belong to, and both operands of the weight gradient are bf16 tensors.
+
+
+def conv_io_applicable(n, ci, hi, wi, weight, pad, pad_mode):
+    """True when a stride-1 Conv2d without bias (ci -> weight.shape[0], hi x wi) can take and write bf16 tensors in all three
+    directions: bf16 mode, packed-weight scope, every direction on the generic bf16 kernels."""
+    if not (STORAGE_BF16 and _pack_cache_on and get_compute_dtype() == "bf16" and weight.is_cuda):
+        return False
+    co, _, kh, kw = weight.shape
+    ho, wo = hi + 2 * pad - kh + 1, wi + 2 * pad - kw + 1
+    if ho < 1 or wo < 1:
+        return False
+    desc = _conv_desc(n, hi, wi, ci, ho, wo, co, kh, kw, 1, pad, pad_mode, weight)
+    return bool(_lib.load().srgan_igemm16_io_applicable(ctypes.byref(desc), ACT_NONE))
+
+
+def _to16(t):
+    return t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)
+
+
+class _ConvIoFn(Function):
+    """Stride-1 Conv2d without bias in the bf16 mode, input fp32 or bf16, output bf16 or fp32 (see above)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, pad, pad_mode, out_bf16):
+        x = to_nhwc(x)
+        n, i, hi, wi = x.shape
+        o, i2, kh, kw = weight.shape
+        if i != i2:
+            raise _lib.SrganHipError(f"conv2d_io: input has {i} channels, weight expects {i2}")
+        ho, wo = hi + 2 * pad - kh + 1, wi + 2 * pad - kw + 1
+        desc = _conv_desc(n, hi, wi, i, ho, wo, o, kh, kw, 1, pad, pad_mode, weight)
+        hit, scratch = _packed(desc, weight, 0, ACT_NONE)
+        ws = workspace(x.device, scratch) if scratch else None
+        y = nhwc_empty(n, o, ho, wo, x.device, torch.bfloat16 if out_bf16 else torch.float32)
+        _lib.check(_lib.load().srgan_igemm16_conv(ctypes.byref(desc), 0, _ptr(x), _is16(x), _ptr(hit.buf), None, _ptr(y), _is16(y),
+                                                  ACT_NONE, 0.0, _ptr(ws), scratch, _stream()), "igemm16_conv")
+        ctx.desc, ctx.weight = desc, weight
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = to_nhwc(gy)
+        weight = ctx.weight
+        lib = _lib.load()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            hit, scratch = _packed(ctx.desc, weight, 1, ACT_NONE)
+            ws = workspace(gy.device, scratch) if scratch else None
+            dx = torch.empty_like(x)
+            _lib.check(lib.srgan_igemm16_conv(ctypes.byref(ctx.desc), 1, _ptr(gy), _is16(gy), _ptr(hit.buf), None, _ptr(dx), _is16(dx),
+                                              ACT_NONE, 0.0, _ptr(ws), scratch, _stream()), "igemm16_conv")
+        if ctx.needs_input_grad[1]:
+            slots = _sink_slots(weight)
+            (dw,), acc = slots if slots is not None else ([torch.empty(weight.shape, dtype=torch.float32, device=weight.device)], False)
+            dd = ConvDesc.from_buffer_copy(ctx.desc)
+            dd.sO, dd.sI, dd.sH, dd.sW = dw.stride()
+            ws, nb = _conv_ws(dd, gy.device)
+            # both operands as bf16 tensors (the kernel rounds them to bf16 anyway; an fp32 side -- a block boundary -- is
+            # rounded by one elementwise pass here)
+            x16, g16 = _to16(x), _to16(gy)
+            with _wgrad_accumulate(acc, slots is not None):
+                _lib.check(lib.srgan_igemm16_wgrad(ctypes.byref(dd), _ptr(x16), _ptr(g16), _ptr(dw), _ptr(ws), nb, _stream()),
+                           "igemm16_wgrad")
+            if slots is not None:
+                dw = None
+        return dx, dw, None, None, None
+
+
+def conv2d_io(x, weight, padding=0, pad_mode=PAD_ZERO, out_bf16=True):
+    return _ConvIoFn.apply(x, weight, padding, pad_mode, bool(out_bf16))
+
+
+class _AvgPool2IoFn(Function):
+    """AvgPool2d(2, 2) with an fp32 or bf16 input and a bf16 or fp32 output; dx has x's type."""
+
+    @staticmethod
+    def forward(ctx, x, out_bf16):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = nhwc_empty(n, c, h // 2, w // 2, x.device, torch.bfloat16 if out_bf16 else torch.float32)
+        _lib.check(_lib.load().srgan_avgpool2_fwd_io(_ptr(x), _is16(x), _ptr(y), _is16(y), n, h, w, c, _stream()), "avgpool2_fwd_io")
+        ctx.shape, ctx.x_dtype = (n, c, h, w), x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        n, c, h, w = ctx.shape
+        gy = to_nhwc(gy)
+        dx = nhwc_empty(n, c, h, w, gy.device, ctx.x_dtype)
+        _lib.check(_lib.load().srgan_avgpool2_bwd_io(_ptr(gy), _is16(gy), _ptr(dx), _is16(dx), n, h, w, c, _stream()), "avgpool2_bwd_io")
+        return dx, None
+
+
+def avgpool2_io(x, out_bf16=False):
+    return _AvgPool2IoFn.apply(x, bool(out_bf16))
+
+
 RESBLOCK_BF16_STORAGE = True      # tests/test_ops_gpu.py switches the bf16-storage node off to compare it with the unfused chain
 
 

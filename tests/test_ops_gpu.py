@@ -1232,6 +1232,71 @@ def test_generator_bf16_activation_storage_vs_fp32_tensors(ops, hw):
         assert worst[1] <= 0.215, worst      # 1.3 x the largest measured value (0.1653, down_cnorms.0.ConBias.0.weight)
 
 
+def test_encoder_bf16_activation_storage_vs_fp32_tensors(ops):
+    """Round 5: in the bf16 mode the tensors inside the style encoder's blocks (norm -> conv -> norm -> conv -> pool) live in
+    HBM as bf16 (ops.py "16-bit activations around the generic convolutions").  The full-width encoder on 64 x 64 images (30 /
+    15 / 7 / 3-pixel maps: the first three blocks are served, the 3 x 3 map's reflect convolutions too) runs forward + backward
+    with the storage on and off; both are bf16-mode results, so they are held to each other and, for scale, to the fp32-tensor
+    chain's own distance from the exact-fp32 mode and to the exact-fp32 mode with the operands rounded to bf16 once."""
+    from srgan_amd import model
+    torch.manual_seed(0)
+    E = model.Encoder(3, 8, 64, 4, "instance", 4, "cuda").cuda()
+    x = (torch.rand(4, 3, 64, 64) * 2 - 1).cuda()
+    gmu, glv, gcl = rnd(4, 8, seed=6).cuda(), rnd(4, 8, seed=7).cuda(), rnd(4, 4, seed=8).cuda()
+    params = [p for p in E.parameters()]
+
+    def run(mode, storage):
+        ops.set_compute_dtype(mode)
+        ops.STORAGE_BF16 = storage
+        try:
+            for p in params:
+                p.grad = None
+            with ops.pack_cache():
+                if mode == "bf16":
+                    probe = torch.empty((4, 64, 30, 30), device="cuda")
+                    blk = E.layers[0]
+                    assert model._block_io16(probe, blk.conv1, blk.cmp[0]) == storage      # the path under test is really taken
+                _, mu, logvar, cls, _ = E(x)
+                ((mu * gmu).sum() + (logvar * glv).sum() + (cls * gcl).sum()).backward()
+            return torch.cat([mu, logvar, cls], 1).detach().clone(), [p.grad.detach().clone() for p in params]
+        finally:
+            ops.STORAGE_BF16 = True
+            ops.set_compute_dtype("fp32")
+            ops.invalidate_packed()
+
+    y32, g32 = run("fp32", True)
+    yc, gc = run("bf16", False)          # bf16 products, fp32 tensors
+    ys, gs = run("bf16", True)           # bf16 products, bf16 tensors inside the blocks
+
+    def bf16r(t):
+        return t.to(torch.bfloat16).to(torch.float32)
+    keep, x_keep = [p.data.clone() for p in params], x.clone()
+    try:
+        for p in params:
+            p.data.copy_(bf16r(p.data))
+        x.copy_(bf16r(x))
+        yp, gp = run("fp32", True)          # the yardstick of the generator's twin below
+    finally:
+        for p, k in zip(params, keep):
+            p.data.copy_(k)
+        x.copy_(x_keep)
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-12))
+
+    print("encoder output: storage %.3e, fp32 tensors %.3e, rounded-once %.3e" % (rel(ys, y32), rel(yc, y32), rel(yp, y32)))
+    assert rel(ys, y32) <= 1.5 * rel(yc, y32) + 2e-3, (rel(ys, y32), rel(yc, y32))
+    assert rel(ys, y32) <= 2e-2
+    worst = ("", 0.0, 0.0, 0.0)
+    for (name, _), a, b, q, r in zip(E.named_parameters(), gs, gc, gp, g32):
+        e_s, e_c, e_p = rel(a, r), rel(b, r), rel(q, r)
+        if e_s > worst[1]:
+            worst = (name, e_s, e_c, e_p)
+        assert e_s <= 1.6 * e_c + 1e-2, (name, e_s, e_c)
+        assert e_s <= 2.0 * e_p + 5e-3, (name, e_s, e_p)
+    print("encoder gradients, worst tensor:", worst)
+
+
 @pytest.mark.parametrize("in16", [False, True])
 @pytest.mark.parametrize("out16", [False, True])
 def test_stride2_io_functions_every_dtype_pair(ops, in16, out16):
@@ -1279,6 +1344,80 @@ def test_stride2_io_functions_every_dtype_pair(ops, in16, out16):
     finally:
         ops.set_compute_dtype("fp32")
         ops.invalidate_packed()
+
+
+@pytest.mark.parametrize("in16", [False, True])
+@pytest.mark.parametrize("out16", [False, True])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 30, 30, "reflect"), (3, 128, 128, 15, 15, "reflect"), (4, 256, 512, 7, 7, "reflect"),
+                                   (2, 128, 64, 12, 20, "zeros")])
+def test_generic_conv_io_every_dtype_pair(ops, shape, in16, out16):
+    """Round 5: the 3x3 stride-1 layers of the style encoder (reflect-padded, 62 / 31 / 15 / 7-pixel maps; model.py:413-437) with
+    bf16 tensors on either side in the bf16 mode (igemm16_kernel<IN16, OUT16>, its split-K sum, the reflect fold, wgrad_kernel
+    with 16-bit loads): forward + input gradient + weight gradient of every fp32 / bf16 mix against the fp32 convolution of the
+    bf16-rounded operands (a bf16 result is compared after the same rounding of the reference).  The 7 x 7 case runs split-K."""
+    torch.set_num_threads(16)
+    n, ci, co, h, w, pm = shape
+    x = rnd(n, ci, h, w, seed=31)
+    wt = rnd(co, ci, 3, 3, seed=32) / np.sqrt(ci * 9)
+    gy = rnd(n, co, h, w, seed=33)
+
+    def r16(t, on):
+        return _bf16_round(t) if on else t
+
+    iv, wv = _bf16_round(x).clone().requires_grad_(True), _bf16_round(wt).clone().requires_grad_(True)
+    xp = F.pad(iv, (1, 1, 1, 1), mode="reflect") if pm == "reflect" else F.pad(iv, (1, 1, 1, 1))
+    y_ref = F.conv2d(xp, wv)
+    y_ref.backward(_bf16_round(gy))
+    ops.set_compute_dtype("bf16")
+    try:
+        with ops.pack_cache():
+            wd = wt.cuda().requires_grad_(True)
+            mode = ops.PAD_REFLECT if pm == "reflect" else ops.PAD_ZERO
+            if not ops.conv_io_applicable(n, ci, h, w, wd, 1, mode):
+                pytest.skip("generic bf16 kernels do not serve this shape")
+            xd = x.cuda().contiguous(memory_format=torch.channels_last)
+            xd = (xd.to(torch.bfloat16) if in16 else xd).requires_grad_(True)
+            y = ops.conv2d_io(xd, wd, 1, mode, out16)
+            assert y.dtype == (torch.bfloat16 if out16 else torch.float32)
+            y.backward(gy.cuda().contiguous(memory_format=torch.channels_last).to(y.dtype))
+            assert xd.grad.dtype == xd.dtype
+            close(y.float(), r16(y_ref.detach(), out16), 2e-5 if not out16 else 5e-3)
+            close(xd.grad.float(), r16(iv.grad, in16), 2e-5 if not in16 else 5e-3)
+            close(wd.grad, wv.grad, 5e-5)
+            # the same layer through the fp32-tensor entry points of the bf16 mode: same kernels, same sums
+            x2 = _bf16_round(x).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            w2 = wt.cuda().requires_grad_(True)
+            y2 = ops.conv2d(x2, w2, None, 1, 1, mode)
+            y2.backward(_bf16_round(gy).cuda().contiguous(memory_format=torch.channels_last))
+            if out16:
+                assert torch.equal(y, y2.to(torch.bfloat16))
+            else:
+                assert torch.equal(y, y2)
+            assert torch.equal(wd.grad, w2.grad)
+    finally:
+        ops.set_compute_dtype("fp32")
+        ops.invalidate_packed()
+
+
+@pytest.mark.parametrize("in16", [False, True])
+@pytest.mark.parametrize("out16", [False, True])
+def test_avgpool2_io_every_dtype_pair(ops, in16, out16):
+    """AvgPool2d(2, 2) with fp32 / bf16 tensors on either side (odd map: the last row / column is dropped, its gradient zero)."""
+    x = rnd(3, 64, 15, 31, seed=41)
+    g = rnd(3, 64, 7, 15, seed=42)
+    xr = (_bf16_round(x) if in16 else x).clone().requires_grad_(True)
+    y_ref = F.avg_pool2d(xr, 2, 2)
+    y_ref.backward(_bf16_round(g) if out16 else g)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    xd = (xd.to(torch.bfloat16) if in16 else xd).requires_grad_(True)
+    y = ops.avgpool2_io(xd, out16)
+    assert y.dtype == (torch.bfloat16 if out16 else torch.float32)
+    y.backward(g.cuda().contiguous(memory_format=torch.channels_last).to(y.dtype))
+    assert xd.grad.dtype == xd.dtype
+    ref_y = _bf16_round(y_ref.detach()) if out16 else y_ref.detach()
+    ref_g = _bf16_round(xr.grad) if in16 else xr.grad
+    assert torch.equal(y.float().cpu(), ref_y)
+    assert torch.equal(xd.grad.float().cpu(), ref_g)
 
 
 def test_rgb_input_form_bf16_compute_mode(ops):
