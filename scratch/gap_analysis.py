@@ -39,3 +39,12 @@ if gs:
     for lo, hi in buckets:
         sel = [g for g in gs if lo * 1e3 <= g < hi * 1e3]
         print(f"   gaps {lo}-{hi if hi < 1e8 else 'inf'} us: {len(sel)/steps:.0f} per step, {sum(sel)/1e6/steps:.3f} ms per step")
+# consistency of the window: launches per step of a kernel whose count is known (72 + 24 F(4x4,3x3) multiplies per fp32 step),
+# kernel time per stream / queue, and the largest contributors
+import collections
+cnt = collections.Counter(n.split("(")[0][:60] for _, _, n, _ in win)
+print("launches per step:", {k: round(v / steps, 1) for k, v in cnt.most_common(8)})
+per_q = collections.defaultdict(int)
+for s, e, n, q in win:
+    per_q[q] += e - s
+print("kernel time per queue (ms per step):", {k: round(v / 1e6 / steps, 2) for k, v in per_q.items()})

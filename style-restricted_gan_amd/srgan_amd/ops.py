@@ -1248,10 +1248,13 @@ def instance_norm_act_io(x, scale, shift, act=ACT_NONE, slope=0.0, eps=1e-5, out
 # stores; gradients take the types of the tensors they belong to, and both operands of the weight gradient are bf16 tensors.
 
 
+_NO_CONV_IO16 = _lib.ab("SRGAN_NO_CONV_IO16")      # A/B (experiment build only): the encoder's blocks on fp32 tensors
+
+
 def conv_io_applicable(n, ci, hi, wi, weight, pad, pad_mode):
     """True when a stride-1 Conv2d without bias (ci -> weight.shape[0], hi x wi) can take and write bf16 tensors in all three
     directions: bf16 mode, packed-weight scope, every direction on the generic bf16 kernels."""
-    if not (STORAGE_BF16 and _pack_cache_on and get_compute_dtype() == "bf16" and weight.is_cuda):
+    if not (STORAGE_BF16 and _pack_cache_on and get_compute_dtype() == "bf16" and weight.is_cuda) or _NO_CONV_IO16:
         return False
     co, _, kh, kw = weight.shape
     ho, wo = hi + 2 * pad - kh + 1, wi + 2 * pad - kw + 1
