@@ -172,6 +172,18 @@ class _second_scale:
                 t.record_stream(self._main)
 
 
+# The shortcut of an encoder block (model.py:409-411, :427-431: AvgPool2d -> 1x1 conv, 1 / 18 of the block's FLOPs in launches
+# of 8-20 us) shares only the block's input with the main path: the same fork, forward here and backward where autograd
+# replays it.  ``SRGAN_NO_PARALLEL_SHORTCUT=1`` (experiment build) keeps it on the caller's stream.
+_PARALLEL_SHORTCUT = not _lib.ab("SRGAN_NO_PARALLEL_SHORTCUT")
+
+
+class _side_branch(_second_scale):
+    def __init__(self, x):
+        super().__init__(x)
+        self._on = self._on and _PARALLEL_SHORTCUT and x.is_cuda
+
+
 def _fork_input(x):
     """A leaf input that wants a gradient gets it from both scales; behind a view node of the caller's stream the two meet in an
     ordinary input buffer and the leaf's AccumulateGrad node sees one producer on its own stream (no stream-mismatch warning)."""
@@ -523,13 +535,17 @@ class BasicBlock_classification(nn.Module):
 
     def forward(self, input):
         x = input
+        with _side_branch(x) as fork:        # pool + 1x1 conv: a few small launches beside the main path's large ones
+            sc = self.shortcut(x)
         if _block_io16(x, self.conv1, self.cmp[0]):
             h = self.conv1.forward_io(self.norm1(x, ACT_LRELU, self.nl1.negative_slope, out_bf16=True))
             h = self.cmp[0].forward_io(self.norm2(h, ACT_LRELU, self.nl2.negative_slope, out_bf16=True))
-            return ops.add(self.cmp[1](h), self.shortcut(x))
-        h = self.conv1(self.norm1(x, ACT_LRELU, self.nl1.negative_slope))
-        h = self.cmp(self.norm2(h, ACT_LRELU, self.nl2.negative_slope))
-        return ops.add(h, self.shortcut(x))
+            h = self.cmp[1](h)
+        else:
+            h = self.conv1(self.norm1(x, ACT_LRELU, self.nl1.negative_slope))
+            h = self.cmp(self.norm2(h, ACT_LRELU, self.nl2.negative_slope))
+        fork.join(sc)
+        return ops.add(h, sc)
 
 
 class BasicBlock(nn.Module):
@@ -549,13 +565,17 @@ class BasicBlock(nn.Module):
 
     def forward(self, input):
         x, d = input
+        with _side_branch(x) as fork:
+            sc = self.shortcut(x)
         if _block_io16(x, self.conv1, self.cmp[0]):
             h = self.conv1.forward_io(self.cnorm1(x, d, ACT_LRELU, self.nl1.negative_slope, out_bf16=True))
             h = self.cmp[0].forward_io(self.cnorm2(h, d, ACT_LRELU, self.nl2.negative_slope, out_bf16=True))
-            return [ops.add(self.cmp[1](h), self.shortcut(x)), d]
-        h = self.conv1(self.cnorm1(x, d, ACT_LRELU, self.nl1.negative_slope))
-        h = self.cmp(self.cnorm2(h, d, ACT_LRELU, self.nl2.negative_slope))
-        return [ops.add(h, self.shortcut(x)), d]
+            h = self.cmp[1](h)
+        else:
+            h = self.conv1(self.cnorm1(x, d, ACT_LRELU, self.nl1.negative_slope))
+            h = self.cmp(self.cnorm2(h, d, ACT_LRELU, self.nl2.negative_slope))
+        fork.join(sc)
+        return [ops.add(h, sc), d]
 
 
 def host_to_device(t, device):

@@ -191,3 +191,38 @@ def test_second_scale_on_a_side_stream_changes_no_bit(leaf_input):
     for k in runs[False][1]:
         assert torch.equal(runs[False][1][k], runs[True][1][k]), k
     assert model._side_streams                     # the fork really happened
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_encoder_shortcut_on_a_side_stream_changes_no_bit(mode):
+    """model._side_branch (round 5): the shortcut of every encoder block (AvgPool2d -> 1x1 conv, model.py:409-411) runs on the
+    side stream, forward and -- replayed by autograd -- backward.  Same kernels, same operands, the same engine-ordered sum of the
+    block input's two gradients: outputs, input gradient and every parameter gradient bit-identical to the single-stream run,
+    in both compute modes (bf16: with the blocks' 16-bit activations)."""
+    from srgan_amd import model, ops
+    _, _, E = build_hip_nets("F")
+    x0, _ = otrainer.synthetic_batch(8, 128, 4, seed=22)
+    saved = model._PARALLEL_SHORTCUT
+    runs = {}
+    ops.set_compute_dtype(mode)
+    try:
+        for par in (False, True):
+            model._PARALLEL_SHORTCUT = par
+            for p in E.parameters():
+                p.grad = None
+            x = x0.cuda().requires_grad_(True)
+            with ops.pack_cache():
+                _, mu, logvar, cls, _ = E(x * 1.0)
+                ((mu ** 2).mean() + (logvar * 0.5).sum() + (cls * torch.arange(float(cls.shape[1])).cuda()).sum()).backward()
+            torch.cuda.synchronize()
+            runs[par] = ([t.detach().clone() for t in (mu, logvar, cls, x.grad)], {k: p.grad.clone() for k, p in E.named_parameters()})
+            del mu, logvar, cls, x
+    finally:
+        model._PARALLEL_SHORTCUT = saved
+        ops.set_compute_dtype("fp32")
+        ops.invalidate_packed()
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert torch.equal(a, b)
+    for k in runs[False][1]:
+        assert torch.equal(runs[False][1][k], runs[True][1][k]), k
+    assert model._side_streams
