@@ -224,6 +224,11 @@ int srgan_avgpool2_bwd_io(const void* dy, int dy_bf16, void* dx, int dx_bf16, in
 int srgan_lrelu_gap_fwd(const float* x, float* y, int N, int HW, int C, float slope, void* stream);
 int srgan_lrelu_gap_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C, float slope, void* stream);
 
+/* Encoder.reparametrize (model.py:459-463): out = eps * exp(logvar / 2) + mu, stdv = exp(logvar / 2) (kept for the backward);
+ * backward: dmu = g, dlogvar = g * eps * stdv / 2.  n = B * ndim; every operation rounded on its own, as the reference's chain. */
+int srgan_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* out, float* stdv, long long n, void* stream);
+int srgan_reparam_bwd(const float* g, const float* eps, const float* stdv, float* dlogvar, long long n, void* stream);
+
 /* nn.Linear: y[M,N] = x[M,K] W[N,K]^T + b  (model.py:455-457; small M) */
 int srgan_linear_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, void* stream);
 int srgan_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db,

@@ -430,6 +430,31 @@ extern "C" int srgan_lrelu_gap_bwd(const float* x, const float* dy, float* dx, i
   LAUNCH1D(lrelu_gap_bwd_kernel, (long long)N * HW * C, stream, x, dy, dx, N, HW, C, slope);
 }
 
+// Encoder.reparametrize (pyfiles/model.py:459-463): c = eps * exp(logvar / 2) + mu on [B, ndim].  The reference is four
+// elementwise launches forward and three backward on 256 floats; here one each.  Every product and sum is rounded on its own
+// (no FMA contraction): the same values as the chain of separate elementwise passes.
+namespace srgan {
+__global__ void reparam_fwd_kernel(const float* mu, const float* logvar, const float* eps, float* out, float* stdv, long long n) {
+  GRID_STRIDE(i, n) {
+    const float s = expf(__fmul_rn(0.5f, logvar[i]));
+    stdv[i] = s;
+    out[i] = __fadd_rn(__fmul_rn(eps[i], s), mu[i]);
+  }
+}
+__global__ void reparam_bwd_kernel(const float* g, const float* eps, const float* stdv, float* dlogvar, long long n) {
+  GRID_STRIDE(i, n) dlogvar[i] = __fmul_rn(__fmul_rn(__fmul_rn(g[i], eps[i]), stdv[i]), 0.5f);
+}
+}  // namespace srgan
+extern "C" int srgan_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* out, float* stdv, long long n,
+                                 void* stream) {
+  SRGAN_REQUIRE(mu && logvar && eps && out && stdv && n > 0, "reparam_fwd: bad argument");
+  LAUNCH1D(srgan::reparam_fwd_kernel, n, stream, mu, logvar, eps, out, stdv, n);
+}
+extern "C" int srgan_reparam_bwd(const float* g, const float* eps, const float* stdv, float* dlogvar, long long n, void* stream) {
+  SRGAN_REQUIRE(g && eps && stdv && dlogvar && n > 0, "reparam_bwd: bad argument");
+  LAUNCH1D(srgan::reparam_bwd_kernel, n, stream, g, eps, stdv, dlogvar, n);
+}
+
 extern "C" int srgan_linear_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, void* stream) {
   SRGAN_REQUIRE(x && W && y && M > 0 && N > 0 && K > 0, "linear_fwd: bad argument");
   const long long threads = (long long)M * N * 64;

@@ -113,6 +113,8 @@ SIGNATURES = {
     "srgan_avgpool2_bwd_io": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "srgan_lrelu_gap_fwd": (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
     "srgan_lrelu_gap_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),
+    "srgan_reparam_fwd": (c_int, [P, P, P, P, P, c_longlong, P]),
+    "srgan_reparam_bwd": (c_int, [P, P, P, P, c_longlong, P]),
     "srgan_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "srgan_linear_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "srgan_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -595,18 +595,27 @@ def _cpu_normal_like(t):
 
 
 class _ReparamFn(torch.autograd.Function):
-    """eps * exp(logvar/2) + mu on [B, ndim] (tiny; kept on-device, fused value+grads)."""
+    """eps * exp(logvar/2) + mu on [B, ndim]: one launch forward, one backward (``srgan_reparam_fwd / _bwd``; the reference's
+    chain of elementwise passes rounds every product and sum on its own, and so do the kernels)."""
 
     @staticmethod
     def forward(ctx, mu, logvar, eps):
-        std = torch.exp(0.5 * logvar)
+        ops._require_gpu(mu, "reparametrize")
+        mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
+        out, std = torch.empty_like(mu), torch.empty_like(mu)
+        _lib.check(_lib.load().srgan_reparam_fwd(ops._ptr(mu), ops._ptr(logvar), ops._ptr(eps), ops._ptr(out), ops._ptr(std),
+                                                 mu.numel(), ops._stream()), "reparam_fwd")
         ctx.save_for_backward(eps, std)
-        return eps * std + mu
+        return out
 
     @staticmethod
     def backward(ctx, g):
         eps, std = ctx.saved_tensors
-        return g, g * eps * std * 0.5, None
+        g = g.contiguous()
+        dlogvar = torch.empty_like(std)
+        _lib.check(_lib.load().srgan_reparam_bwd(ops._ptr(g), ops._ptr(eps), ops._ptr(std), ops._ptr(dlogvar), g.numel(),
+                                                 ops._stream()), "reparam_bwd")
+        return g, dlogvar, None
 
 
 class _EncoderBase(nn.Module):

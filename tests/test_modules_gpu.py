@@ -193,6 +193,28 @@ def test_second_scale_on_a_side_stream_changes_no_bit(leaf_input):
     assert model._side_streams                     # the fork really happened
 
 
+def test_reparametrize_kernels_equal_the_elementwise_chain():
+    """Encoder.reparametrize (model.py:459-463) as one launch forward and one backward against the reference's chain of
+    elementwise passes (every product and sum rounded on its own in both), value and both gradients."""
+    from srgan_amd import model
+    g0 = torch.Generator().manual_seed(5)
+    mu, logvar, eps, gy = (torch.randn(32, 8, generator=g0).cuda() for _ in range(4))
+    logvar = logvar * 3
+    a, b = mu.clone().requires_grad_(True), logvar.clone().requires_grad_(True)
+    out = model._ReparamFn.apply(a, b, eps)
+    out.backward(gy)
+    ar, br = mu.clone().requires_grad_(True), logvar.clone().requires_grad_(True)
+    std = torch.exp(0.5 * br)
+    ref = eps * std + ar
+    ref.backward(gy)
+    close(out, ref, 1e-6)                 # (expf here, ATen's exp there: an ulp apart at most)
+    assert torch.equal(a.grad, ar.grad)
+    close(b.grad, br.grad, 1e-6)
+    # against float64: not further from the exact value than the chain is
+    exact = eps.double() * torch.exp(0.5 * logvar.double()) + mu.double()
+    assert float((out.detach().double() - exact).abs().max()) <= 1.5 * float((ref.detach().double() - exact).abs().max()) + 1e-12
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_encoder_shortcut_on_a_side_stream_changes_no_bit(mode):
     """model._side_branch (round 5): the shortcut of every encoder block (AvgPool2d -> 1x1 conv, model.py:409-411) runs on the
