@@ -200,9 +200,21 @@ class _AvgPool2(nn.Module):
 def _block_io16(x, conv1, conv2):
     """Can an encoder block (norm -> conv1 -> norm -> conv2 -> pool) keep its four intermediates in bf16?  Both convolutions and
     both norms must be served for THIS shape (each by its own geometry)."""
-    n, c, h, w = x.shape
-    return bool(x.is_cuda and (c & 3) == 0 and (conv2.out_channels & 3) == 0 and ops.norm_io_applicable(n, c, h, w)
-                and conv1.io_applicable(x) and conv2.io_applicable(x))
+    if not x.is_cuda or ops.get_compute_dtype() != "bf16":
+        return False
+    # (asked on every forward: the answer depends on the geometry and the switches only)
+    key = (tuple(x.shape), tuple(conv1.weight.shape), conv1.weight.stride(), tuple(conv2.weight.shape), conv2.weight.stride(),
+           conv1.padding_mode, conv1.padding, conv1.stride, conv2.padding, conv2.stride, conv1.bias is None, conv2.bias is None,
+           ops.STORAGE_BF16, ops.pack_cache_active())
+    hit = _io16_memo.get(key)
+    if hit is None:
+        n, c, h, w = x.shape
+        hit = _io16_memo[key] = bool((c & 3) == 0 and (conv2.out_channels & 3) == 0 and ops.norm_io_applicable(n, c, h, w)
+                                     and conv1.io_applicable(x) and conv2.io_applicable(x))
+    return hit
+
+
+_io16_memo = {}
 
 
 # ------------------------------------------------------------------------------------------------

@@ -256,6 +256,11 @@ def set_compute_dtype(name):
     _tables.clear()
 
 
+def pack_cache_active():
+    """True inside a ``pack_cache()`` scope (the 16-bit activation paths of the bf16 mode live on cached operands)."""
+    return _pack_cache_on
+
+
 def get_compute_dtype():
     return "bf16" if _lib.load().srgan_get_compute_mode() == 1 else "fp32"
 
