@@ -764,6 +764,29 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
     i32x4 ro[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) ro[g] = *reinterpret_cast<const i32x4*>(&row_o[wm * 64 + i * 32 + 8 * g + 4 * lh]);
+    if constexpr (OUT16 && TN == 2) {
+      // A bf16 row of this wave's 64 columns is ONE 128-byte line.  With a column per lane a half-wave store covers 64 bytes of
+      // it (and the other column block another 64 bytes, 16 instructions later): every store is a partial-line write, and the
+      // layer's result took as long to write as the fp32 one (55 us for 63 MB: scratch/io16/bench_io.py).  Lanes are paired
+      // instead: the even lane of a pair takes both lanes' values of column block 0 (columns lr, lr + 1), the odd lane those of
+      // block 1 (columns 32 + lr - 1, 32 + lr) -- one 4-byte store per lane and row, the 32 lanes of a half-wave write the whole
+      // line, half the store instructions.  (a split-K launch writes fp32 slabs: launch_igemm16 takes OUT16 only with ksplit == 1)
+      const int odd = lr & 1;
+      const int n = n0 + wn * 64 + (odd ? 31 + lr : lr);        // first of this lane's two adjacent columns
+      const bool nok = n < p.Cd;                                  // Cd % 4 == 0 (igemm16_io_ok): both columns in or out
+      const float b0 = (nok && p.bias) ? p.bias[n] : 0.f, b1 = (nok && p.bias) ? p.bias[n + 1] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int o = ro[e >> 2][e & 3];
+        const float own = odd ? acc[i][1][e] : acc[i][0][e], give = odd ? acc[i][0][e] : acc[i][1][e];
+        const float got = __shfl_xor(give, 1, 64);
+        const float v0 = (odd ? got : own) + b0, v1 = (odd ? own : got) + b1;
+        const float r0 = v0 > 0.f ? v0 : (relu ? 0.f : v0 * neg), r1 = v1 > 0.f ? v1 : (relu ? 0.f : v1 * neg);
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 pk = {(__bf16)r0, (__bf16)r1};
+        if (nok && o >= 0) *reinterpret_cast<bf16x2*>(reinterpret_cast<__bf16*>(dst_base) + (size_t)o * p.Cd + n) = pk;
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (BN / 2) + j * 32 + lr;
@@ -780,6 +803,7 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
           if (nok && o >= 0) dst_base[(size_t)o * p.Cd + n] = r;
         }
       }
+    }
     }
   }
   __syncthreads();        // row_o and the operand buffers are rewritten by the next tile
