@@ -41,6 +41,24 @@ def test_invalid_arguments_are_reported_without_a_gpu(built_lib):
     assert lib.srgan_allgather_rows(None, None, None, 8, None) == -1 and b"no communicator" in lib.srgan_last_error()
     assert lib.srgan_comm_init(None, 2, 0, None) == -1 and lib.srgan_comm_destroy(None) == 0
     assert lib.srgan_comm_available() in (0, 1)
+    # round 5: the 16-bit generic-layer entry points, the pools with 16-bit I/O, the reparametrisation kernels
+    buf = (ctypes.c_char * 4096)()
+    good = built_lib.ConvDesc(2, 8, 8, 64, 8, 8, 64, 3, 3, 1, 1, 1, 64 * 9, 9, 3, 1)
+    assert lib.srgan_igemm16_io_applicable(ctypes.byref(d), 0) == 0                # a descriptor that fails validation is "not served"
+    assert lib.srgan_igemm16_io_applicable(ctypes.byref(good), 0) == 0             # fp32 compute mode: not served either
+    assert lib.srgan_igemm16_conv(ctypes.byref(good), 0, None, 1, None, None, None, 1, 0, 0.0, None, 0, None) != 0
+    assert b"null pointer" in lib.srgan_last_error()
+    assert lib.srgan_igemm16_conv(ctypes.byref(good), 2, buf, 1, buf, None, buf, 1, 0, 0.0, None, 0, None) != 0
+    assert b"kind" in lib.srgan_last_error()
+    assert lib.srgan_igemm16_conv(ctypes.byref(good), 0, buf, 1, buf, None, buf, 1, 0, 0.0, None, 0, None) != 0
+    assert b"not applicable" in lib.srgan_last_error()                             # (the bf16 mode is off in this process)
+    assert lib.srgan_igemm16_wgrad(ctypes.byref(good), None, None, None, None, 0, None) != 0
+    assert lib.srgan_avgpool2_fwd_io(buf, 1, buf, 0, 1, 4, 4, 6, None) != 0        # C % 4 != 0
+    assert b"C % 4" in lib.srgan_last_error()
+    assert lib.srgan_avgpool2_bwd_io(None, 1, buf, 0, 1, 4, 4, 8, None) != 0
+    assert lib.srgan_reparam_fwd(None, buf, buf, buf, buf, 256, None) != 0
+    assert b"reparam_fwd" in lib.srgan_last_error()
+    assert lib.srgan_reparam_bwd(buf, buf, buf, buf, 0, None) != 0
 
 
 def test_product_refuses_cpu_tensors(built_lib):
