@@ -30,6 +30,7 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  int version = 0;                                          // ncclGetVersion: major * 10000 + minor * 100 + patch
   bool ok = false;
 };
 
@@ -37,12 +38,24 @@ Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    // first the copy the process has ALREADY mapped (torch.distributed's nccl backend links librccl: a second copy
+    // of the library would be a second set of communicator state beside it), only then a fresh load
+    static const char* const names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* name : names) {
+      r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
       if (r.handle) break;
+    }
+    for (const char* name : names) {
+      if (r.handle) break;
+      r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     }
     if (!r.handle) return;
     auto sym = [&](const char* n) { return dlsym(r.handle, n); };
+    // the hand-copied ABI slice above is NCCL 2.x's (enum values, the by-value 128-byte id): refuse any other major version
+    auto get_version = reinterpret_cast<ncclResult_t (*)(int*)>(sym("ncclGetVersion"));
+    int version = 0;
+    if (!get_version || get_version(&version) != 0 || version < 20000 || version >= 30000) { r.version = version; return; }
+    r.version = version;
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
@@ -57,7 +70,8 @@ Rccl& rccl() {
 
 int need_rccl(const char* what) {
   if (rccl().ok) return 0;
-  set_error("%s: librccl.so could not be loaded (%s)", what, rccl().handle ? "missing symbols" : "dlopen failed");
+  set_error("%s: librccl.so could not be loaded (%s, ncclGetVersion %d)", what,
+            rccl().handle ? "missing symbols or an ABI this file was not written against" : "dlopen failed", rccl().version);
   return -1;
 }
 

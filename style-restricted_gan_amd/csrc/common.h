@@ -81,7 +81,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // The activation as one select: `act` is uniform, and written as `if (act == ...)` the compiler keeps a scalar branch per
 // ELEMENT of an unrolled epilogue (~30 instructions and two taken branches around each 16-byte store: the row pass + stores of
 // wino42_kernel's epilogue took 7000 cycles, round 5).  Negative-side slope: 1 (none), 0 (ReLU), slope (LeakyReLU); the
-// `+ 0.f` keeps ReLU's zero positive.  Same values as the branch form for every input (a NaN stays a NaN).
+// `+ 0.f` keeps ReLU's zero positive.  Same values as the branch form for every FINITE input and for NaN (a NaN stays a NaN, as
+// in torch.relu); the one difference: ReLU of -inf is fma(-inf, 0, 0) = NaN here where the branch form and
+// torch.relu give 0 -- an overflowed activation now poisons what follows instead of being clamped.  Accepted: an infinite
+// pre-activation means the step has already diverged, and bench.py / the trainer tests check the losses for finiteness.
 __device__ __forceinline__ float act_neg_slope(int act, float slope) {
   return act == SRGAN_ACT_LRELU ? slope : (act == SRGAN_ACT_RELU ? 0.f : 1.f);
 }

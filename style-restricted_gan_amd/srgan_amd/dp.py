@@ -160,6 +160,8 @@ def _abi_comm():
         with _stdout_to_stderr():
             _lib.check(lib.srgan_comm_init(ident, dist.get_world_size(), dist.get_rank(), ctypes.byref(comm)), "srgan_comm_init")
         _abi = (comm, lib)
+        import atexit
+        atexit.register(abi_comm_destroy)      # the communicator leaves with the process (idempotent; explicit calls are fine)
     return _abi
 
 
@@ -325,6 +327,18 @@ class _Bucket:
 _slot_of = {}                 # id(parameter) -> (weakref to its GradReducer, bucket index, index in the bucket)
 
 
+def _forget_slots(ref, pids):
+    for pid in pids:
+        hit = _slot_of.get(pid)
+        if hit is not None and hit[0] is ref:
+            del _slot_of[pid]
+    if not _slot_of:
+        import sys
+        ops = sys.modules.get(__name__.rsplit(".", 1)[0] + ".ops")      # (a finaliser may run at interpreter shutdown)
+        if ops is not None and getattr(ops, "_sink_alloc", None) is grad_slot:
+            ops._sink_alloc = None
+
+
 def grad_slot(p):
     """The slice of ``p``'s gradient bucket, for the weight-gradient kernels to write into (``ops.fused_param_grads`` asks when
     it needs a buffer for a parameter's first contribution of a pass): the bucket then IS the gradients and ``_launch`` has
@@ -340,7 +354,9 @@ def grad_slot(p):
     bk = red._buckets_cache[hit[1]]
     if bk.params[hit[2]] is not p:
         return None
-    bk.materialise(bucket_dtype(True) == "bf16")
+    # the wire type of an exchange is the owning reducer's (resolved once in _reset()); asking the compute mode here
+    # could create or drop the bf16 message buffer between arm() and the backward and split the exchange again
+    bk.materialise(red._wire16 if red._wire16 is not None else bucket_dtype(True) == "bf16")
     return bk.views[hit[2]]
 
 
@@ -372,6 +388,7 @@ class GradReducer:
         self._comm_stream = None
         self._armed = False
         self._waited = False           # recording: the wait for this reducer's buckets already rides in the cut that started them
+        self._wire16 = None            # resolved by _reset() (arm() / start()); grad_slot() follows it
         self._buckets_cache = [_Bucket(b) for b in self._buckets()]
         self._where = {}
         for b, bucket in enumerate(self._buckets_cache):
@@ -382,6 +399,9 @@ class GradReducer:
         me = weakref.ref(self)
         for pid, (b, j) in self._where.items():
             _slot_of[pid] = (me, b, j)
+        # the registry is keyed by id(parameter): entries leave with their reducer, and the sink allocator of
+        # ops.fused_param_grads is dropped when the last reducer of the process has gone
+        weakref.finalize(self, _forget_slots, me, list(self._where))
         if hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
             for p in self.params:
                 if p.requires_grad:

@@ -588,8 +588,19 @@ def _sink_slots(*params):
             for p in params:                     # seeded scope: add into the gradient an earlier scope left
                 _grad_sink[id(p)] = (p, p.grad)
             return [p.grad for p in params], True
-        for p in params:
-            buf = _sink_alloc(p) if _sink_alloc is not None else None      # data parallel: the parameter's bucket slice
+        bufs = [_sink_alloc(p) if _sink_alloc is not None else None for p in params]   # data parallel: the bucket slices
+        # a bucket slice is the SAME storage an earlier pass bound to p.grad (GradReducer.finish / a previous
+        # scope's exit).  Without a zero_grad in between (gradient accumulation, two backward calls) that gradient is still
+        # live: writing this pass's first contribution over it would lose it, and the exit's `p.grad is not buf` test would
+        # skip the add.  Such a slot is a seeded one -- the kernels add into it; all or none, since one launch serves the group.
+        live = [b is not None and p.grad is not None and p.grad.data_ptr() == b.data_ptr() for p, b in zip(params, bufs)]
+        if any(live):
+            if all(live) and all(p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in params):
+                for p in params:
+                    _grad_sink[id(p)] = (p, p.grad)
+                return [p.grad for p in params], True
+            bufs = [None] * len(params)          # mixed: fresh buffers, added to p.grad at the exit like any unseeded slot
+        for p, buf in zip(params, bufs):
             if buf is None:
                 buf = torch.empty(p.shape, dtype=torch.float32, device=p.device)
             _grad_sink[id(p)] = (p, buf)

@@ -766,7 +766,8 @@ class _StepGraph:
             hook("before")
         ops.mark_singles_stale()          # their pack launches belong to the recording (ops.refresh_packed)
         g = _Recording(self.x.device)
-        sg._g_active = True
+        epoch0 = ops.structure_epoch()    # a buffer replaced DURING the recording (the weight-gradient arena grown
+        sg._g_active = True               # between two segments) would leave earlier segments pointing at freed memory
         self._noise_i, self._onehot = 0, {}
         sg.source_image = self.x
         try:
@@ -780,6 +781,9 @@ class _StepGraph:
             sg._g_active = False
         if self._noise_i != self.noise.shape[0]:
             raise RuntimeError(f"captured step consumed {self._noise_i} noise draws, staged {self.noise.shape[0]}")
+        if ops.structure_epoch() != epoch0:
+            raise RuntimeError("a workspace the step points at was replaced while the step was being recorded "
+                               "(ops.structure_epoch moved): the recording is dropped")
         self.graph = g
         self.terms = dict(sg.loss_terms)
         self._epoch = ops.structure_epoch()

@@ -83,3 +83,29 @@ def test_no_experiment_switch_ships_in_the_product_library(built_lib):
     r = subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "--offload-arch=gfx950", "-DWINO_EXP=5", "-I" + os.path.join(ROOT, "include"),
                         "-I" + src, "-E", "-x", "hip", os.path.join(src, "common.h"), "-o", os.devnull], capture_output=True, text=True)
     assert r.returncode != 0 and "experiment builds" in r.stderr
+
+
+def test_no_buffer_store_with_a_scalar_register_offset_in_the_product_isa(built_lib):
+    """VERDICT r5 item 3 / DESIGN.md section 8 (toolchain rules).  On gfx950 with ROCm 7.2 a 16-byte `buffer_store` whose
+    soffset operand is an SGPR misplaced data in `wino42_kernel`'s epilogue (profiles/LOG.md, round 5): the compiler's hazard
+    recognizer treats a register soffset as "no store-data hazard" and lets the data registers be rewritten right behind the
+    store.  The product keeps every buffer store on `soffset = 0` (offsets go into the vector offset); this test disassembles
+    every gfx950 code object of the library and fails if a buffer store with any other soffset operand appears.  Loads with an
+    SGPR soffset (the gathers, the filter fragments) are unaffected and allowed."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import isa_tools
+    isa = isa_tools.disassemble(built_lib.LIB_PATH)
+    stores = re.findall(r"^\s*(buffer_(?:store|atomic)\w*)\s+(.*?)(?://.*)?$", isa, flags=re.M)
+    assert len(stores) >= 50, len(stores)                       # the F(4x4,2x2) epilogues alone hold ~100
+    bad = []
+    for op, operands in stores:
+        ops = [o.strip() for o in operands.split(",")]
+        assert len(ops) >= 4, (op, operands)                    # vdata, vaddr, srsrc, soffset [modifiers]
+        soffset = ops[3].split()[0]
+        if soffset not in ("0", "off"):
+            bad.append((op, operands.strip()))
+    assert not bad, bad[:5]
+    # the loads are there and do use scalar offsets: the pattern above is looking at the right operand
+    loads = re.findall(r"^\s*buffer_load\w*\s+(.*?)(?://.*)?$", isa, flags=re.M)
+    assert sum(1 for o in loads if re.match(r"s\d+", o.split(",")[3].strip().split()[0])) > 100
