@@ -240,6 +240,13 @@ def golden_train():
     golden_train_256()
 
 
+def golden_train_long():
+    """a REFERENCE trajectory longer than three steps (10 steps, tier T, k = 2; losses only + final
+    parameters), so that the oracle -- whose own 20-step runs are the yardstick of the bf16 trajectory tests -- is pinned to
+    the reference over more optimiser steps than the other fixtures cover (20 generator, 20 discriminator, 10 encoder)."""
+    np.savez_compressed(os.path.join(HERE, "train_T_b4_k2_s10.npz"), **run_train("T", 4, 2, 10, seed=0))
+
+
 def golden_train_256():
     np.savez_compressed(os.path.join(HERE, "train_T256_b2_k2.npz"), **run_train("T256", 2, 2, 2, seed=0, size=256))
 
@@ -394,6 +401,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "plot":
         golden_plot()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "trainlong":
+        golden_train_long()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "train256":
         golden_train_256()
         sys.exit(0)
@@ -401,6 +411,7 @@ if __name__ == "__main__":
     golden_modules()
     golden_losses()
     golden_train()
+    golden_train_long()
     golden_singlegan()
     golden_pretrain()
     golden_facedataset()

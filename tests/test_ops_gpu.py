@@ -1295,6 +1295,9 @@ def test_encoder_bf16_activation_storage_vs_fp32_tensors(ops):
         assert e_s <= 1.6 * e_c + 1e-2, (name, e_s, e_c)
         assert e_s <= 2.0 * e_p + 5e-3, (name, e_s, e_p)
     print("encoder gradients, worst tensor:", worst)
+    # an absolute cap beside the relative ones, as the generator's twin has -- 1.3 x the largest measured
+    # value (0.28 on this shape; its rounded-once yardstick is 0.26)
+    assert worst[1] <= 0.365, worst
 
 
 @pytest.mark.parametrize("in16", [False, True])

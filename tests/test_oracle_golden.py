@@ -155,12 +155,21 @@ def _run_oracle(tier, batch, k, steps, seed, pretrained_e=False, size=128):
 
 
 @pytest.mark.parametrize("name,k,steps,pre", [("train_T_b4_k2", 2, 3, False), ("train_T_b4_k5", 5, 2, False),
-                                              ("train_T_b4_k2_pretrainedE", 2, 2, True)])
+                                              ("train_T_b4_k2_pretrainedE", 2, 2, True),
+                                              ("train_T_b4_k2_s10", 2, 10, False)])      # 10 reference steps
 def test_train_step_trajectory_tier_T(golden_dir, name, k, steps, pre):
     gold = np.load(os.path.join(golden_dir, name + ".npz"))
     orc, traj = _run_oracle("T", 4, k, steps, seed=0, pretrained_e=pre)
     close(orc.hi.target, gold["hist_target"], 1e-6)
     np.testing.assert_allclose(traj, gold["losses"], rtol=2e-4)
+    if steps > 3:
+        # ten steps: parameters are compared the way the GPU trajectories are (tests/common.py::close_params): an element whose
+        # gradient sits at rounding level may take the other sign of an Adam step; the bulk of every tensor agrees tightly
+        from tests.common import close_params
+        for net, P, n_opt in (("G", orc.G, 2 * steps), ("D", orc.D, k * steps), ("E", orc.E, steps)):
+            for key, p in P.items():
+                close_params(p.detach(), gold[f"{net}.{key}"], 1e-4, n_opt, what=f"{net}.{key}")
+        return
     for net, P in (("G", orc.G), ("D", orc.D), ("E", orc.E)):
         for key, p in P.items():
             close(p.detach(), gold[f"{net}.{key}"], 2e-4, 2e-6)

@@ -43,7 +43,8 @@ def run_hip(tier, batch, k, steps, seed, pretrained_e=False, size=128):
 
 
 @pytest.mark.parametrize("name,k,steps,pre", [("train_T_b4_k2", 2, 3, False), ("train_T_b4_k5", 5, 2, False),
-                                              ("train_T_b4_k2_pretrainedE", 2, 2, True)])
+                                              ("train_T_b4_k2_pretrainedE", 2, 2, True),
+                                              ("train_T_b4_k2_s10", 2, 10, False)])      # 10 reference steps
 def test_train_trajectory_vs_reference_tier_T(golden_dir, name, k, steps, pre):
     gold = np.load(os.path.join(golden_dir, name + ".npz"))
     sg, traj = run_hip("T", 4, k, steps, seed=0, pretrained_e=pre)
