@@ -15,6 +15,19 @@ typedef struct { unsigned x, y, z; } dim3_t;
 typedef int (*launch_fn)(const void*, dim3_t, dim3_t, void**, size_t, void*);
 typedef void (*reg_fn)(void**, const void*, char*, const char*, unsigned, void*, void*, void*, void*, int*);
 
+/* libamdhip64 arrives as a dependency of a dlopen(RTLD_LOCAL)-ed Python extension: RTLD_NEXT does not see it.  Find the copy the
+ * process has mapped. */
+static void* real_sym(const char* name) {
+  void* f = dlvsym(RTLD_NEXT, name, "hip_4.2");
+  if (!f) f = dlsym(RTLD_NEXT, name);
+  static const char* const libs[] = {"libamdhip64.so.7", "libamdhip64.so", "libamdhip64.so.6"};
+  for (unsigned i = 0; !f && i < sizeof(libs) / sizeof(libs[0]); ++i) {
+    void* h = dlopen(libs[i], RTLD_NOW | RTLD_NOLOAD);
+    if (h) f = dlsym(h, name);
+  }
+  return f;
+}
+
 static const void** g_host = NULL;
 static const char** g_name = NULL;
 static int g_n = 0, g_cap = 0;
@@ -24,8 +37,7 @@ static unsigned long g_seq = 0;
 void __hipRegisterFunction(void** modules, const void* hostFunction, char* deviceFunction, const char* deviceName,
                            unsigned threadLimit, void* tid, void* bid, void* blockDim, void* gridDim, int* wSize) {
   static reg_fn real = NULL;
-  if (!real) real = (reg_fn)dlvsym(RTLD_NEXT, "__hipRegisterFunction", "hip_4.2");
-  if (!real) real = (reg_fn)dlsym(RTLD_NEXT, "__hipRegisterFunction");
+  if (!real) real = (reg_fn)real_sym("__hipRegisterFunction");
   if (g_n == g_cap) {
     g_cap = g_cap ? 2 * g_cap : 8192;
     g_host = (const void**)realloc((void*)g_host, sizeof(void*) * (size_t)g_cap);
@@ -37,8 +49,8 @@ void __hipRegisterFunction(void** modules, const void* hostFunction, char* devic
 
 int hipLaunchKernel(const void* func, dim3_t grid, dim3_t block, void** args, size_t shmem, void* stream) {
   static launch_fn real = NULL;
-  if (!real) real = (launch_fn)dlvsym(RTLD_NEXT, "hipLaunchKernel", "hip_4.2");
-  if (!real) real = (launch_fn)dlsym(RTLD_NEXT, "hipLaunchKernel");
+  if (!real) real = (launch_fn)real_sym("hipLaunchKernel");
+  if (!real) { fprintf(stderr, "launch_log: the HIP runtime's hipLaunchKernel was not found\n"); abort(); }
   if (!g_log) { const char* p = getenv("SRGAN_LAUNCH_LOG"); g_log = p ? fopen(p, "w") : stderr; }
   const char* name = "?";
   for (int i = g_n - 1; i >= 0; --i) if (g_host[i] == func) { name = g_name[i]; break; }

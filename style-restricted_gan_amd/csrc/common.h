@@ -33,8 +33,8 @@ inline int check_launch(const char* what) {
   } while (0)
 
 // Timing ablations (wrong results) and phase stamps are compile-time variants of the kernels: never in the product library.
-#if !defined(SRGAN_EXPERIMENTS) && (defined(WINO_EXP) || defined(WINO42_EXP) || defined(RGBOUT_EXP) || defined(W43_DIAG))
-#error "WINO_EXP / WINO42_EXP / RGBOUT_EXP / W43_DIAG are experiment builds: make exp EXPFLAGS=-DWINO_EXP=n (writes scratch/libsrgan_exp.so)"
+#if !defined(SRGAN_EXPERIMENTS) && (defined(WINO_EXP) || defined(WINO42_EXP) || defined(RGBOUT_EXP) || defined(W43_DIAG) || defined(H16R_EXP))
+#error "WINO_EXP / WINO42_EXP / RGBOUT_EXP / W43_DIAG / H16R_EXP are experiment builds: make exp EXPFLAGS=-DWINO_EXP=n (writes scratch/libsrgan_exp.so)"
 #endif
 
 // A/B switches of the measurement scripts under scratch/: only `make exp` (-DSRGAN_EXPERIMENTS, which writes

@@ -246,6 +246,180 @@ __global__ __launch_bounds__(256) void halo16_kernel(Halo16Params p) {
   }
 }
 
+// ---- round 6: the 256-channel trunk layers with the FILTER operand fed global -> registers (VERDICT r5 item 1 i) ----
+// halo16_kernel above moves every 16 KB filter tile global -> registers -> LDS -> registers and synchronises its four waves once
+// per tile: with the stream and the fragment reads removed its loop still ran at half the matrix rate (profiles/LOG.md, round 2:
+// 29 us of skeleton per round against 15.4 us of MFMAs) -- one wave per SIMD, in-order issue, a barrier every 16 MFMAs.  Here:
+//   * the four waves split the OUTPUT CHANNELS (wave w: channels 64 w .. 64 w + 63, all 128 pixels of the patch: 4 pixel rows x
+//     2 channel blocks = 8 MFMAs per 16-deep K step, 128 accumulator registers), so a B (filter) fragment belongs to ONE wave:
+//     it is loaded straight from the packed register image (pack_device.h, variant 4 with N = 256: 1 KB contiguous per wave
+//     and fragment) into a ring of registers five K steps ahead -- no LDS stores, no LDS reads, no swizzle for the filter
+//     operand, and the kernel has one wave per SIMD and 512 registers to spend on the ring;
+//   * the A (activation) fragments come from the LDS-resident halo exactly as before, 4 ds_read_b128 per 8 MFMAs = 512 bytes of
+//     LDS reads per MFMA (was 768 + the tile stores);
+//   * nothing in the K loop is shared between waves any more, so there is NO barrier inside a 64-channel quarter: the waves
+//     drift apart and fill each other's stalls; one barrier per quarter publishes the next quarter of the halo, which streams
+//     in under the products as before.
+// Every workgroup still reads the whole 1.18 MB filter image from L2 (32 bytes per clock and CU at the full matrix rate).
+#ifndef H16R_EXP
+#define H16R_EXP 0          // timing ablations (wrong results): experiment builds only (common.h refuses the flag otherwise)
+#endif
+template <bool RES, bool IN16, bool OUT16>
+__global__ __launch_bounds__(256) void halo16r_kernel(Halo16Params p) {
+  static_assert(!(RES && OUT16), "the skip gradient is added to an fp32 result");
+  constexpr int C = 256, N = 256;
+  constexpr int ISZ = IN16 ? 2 : 4;
+  constexpr int PS = C * 2 + 16;               // bytes per halo pixel (16-byte pad: conflict-free fragment reads)
+  constexpr int NQ = C / 64;                   // 64-channel quarters
+  constexpr int QS = 36;                       // K steps of 16 per quarter: 9 taps x 4
+  constexpr int NKS = NQ * QS;                 // 144
+  constexpr int RING = 6, PF = RING - 1;       // B fragments are requested PF K steps ahead (QS % RING == 0)
+  constexpr int HP = 7;                        // passes of 32 pixels over the 204 halo pixels of one quarter
+  __shared__ __attribute__((aligned(16))) unsigned char halo[HPX * PS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);      // neighbouring patches (shared halo rows) on one XCD
+  int r = bid;
+  const int tx = r % p.tiles_x; r /= p.tiles_x;
+  const int ty = r % p.tiles_y;
+  const int nb = r / p.tiles_y;
+  const int Y0 = ty * 4, X0 = tx * 32;
+
+  const auto rs_x = uniform_rsrc(p.src, (unsigned)((size_t)p.NB * p.H * p.W * C * ISZ));
+  const auto rs_w = uniform_rsrc(p.wp, (unsigned)(NKS * 4 * 2 * 1024));      // past the image: zeros (the ring's last requests)
+
+  // ---- B ring: fragment (K step kg, channel block j) of this wave = 1 KB at ((kg * 4 + wave) * 2 + j) * 1024 ----
+  bf16x8 fb[RING][2];
+  const int w_lane = lane * 16, w_wave = wave * 2048;
+  auto load_b = [&](int slot, int kg) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      fb[slot][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, kg * 8192 + w_wave + j * 1024, 0));
+  };
+#pragma unroll
+  for (int s = 0; s < PF; ++s) load_b(s, s);
+
+  // ---- halo: one 64-channel quarter at a time; thread = (pixel of the pass, 8 channels), 32 pixels per pass ----
+  const int hcg = tid & 7, hpl = tid >> 3;
+  constexpr unsigned kOutside = 0x80000000u;
+  auto halo_off = [&](int quarter, int pass) __attribute__((always_inline)) -> unsigned {
+    const int hp = pass * 32 + hpl;
+    const int hr = hp / 34, hc = hp - hr * 34;
+    const int y = Y0 - 1 + hr, x = X0 - 1 + hc;
+    const bool ok = hp < HPX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    return ok ? (unsigned)((((nb * p.H + y) * p.W + x) * C + quarter * 64 + hcg * 8) * ISZ) : kOutside;
+  };
+  auto halo_put = [&](int quarter, int pass, f32x4 lo, f32x4 hi) __attribute__((always_inline)) {
+    const int hp = pass * 32 + hpl;
+    if (hp < HPX) {
+      if constexpr (IN16) {                      // lo already holds the 8 bf16 channels
+        *reinterpret_cast<f32x4*>(&halo[hp * PS + quarter * 128 + hcg * 16]) = lo;
+      } else {
+        const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+        bf16x8 v;
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        *reinterpret_cast<bf16x8*>(&halo[hp * PS + quarter * 128 + hcg * 16]) = v;
+      }
+    }
+  };
+  {
+    f32x4 lo[HP], hi[HP];
+#pragma unroll
+    for (int g = 0; g < HP; ++g) {
+      const unsigned off = halo_off(0, g);
+      lo[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+      if constexpr (!IN16) hi[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+      else hi[g] = lo[g];
+    }
+#pragma unroll
+    for (int g = 0; g < HP; ++g) halo_put(0, g, lo[g], hi[g]);
+  }
+  __syncthreads();
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // lane's A address: pixel (row 0, column lr) of the patch at tap (0, 0) = halo pixel lr, channels 8 lh .. of the K step
+  const unsigned char* a_lane = halo + lr * PS + lh * 16;
+  bf16x8 fa[2][4];
+  auto read_a = [&](int slot, const unsigned char* a) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[slot][i] = *reinterpret_cast<const bf16x8*>(a + i * 34 * PS);
+  };
+  auto mma = [&](int sa, int sb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sa][i], fb[sb][j], acc[i][j], 0, 0, 0);
+  };
+
+  f32x4 hlo = {0.f, 0.f, 0.f, 0.f}, hhi = {0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < NQ; ++q) {
+    const unsigned char* a_q = a_lane + q * 128;
+    read_a(0, a_q);                                    // (tap 0, step 0) of this quarter: published by the barrier just passed
+#pragma unroll
+    for (int t = 0; t < QS; ++t) {
+      const int tap = t >> 2, s = t & 3;
+      // the next quarter of the halo streams in under this quarter's products: pass `tap` is requested at the tap's first K
+      // step and parked in LDS one tap later; the barrier at the end of the quarter publishes it
+      if (s == 0 && q + 1 < NQ && !(H16R_EXP & 16)) {
+        if (tap >= 1 && tap <= HP) halo_put(q + 1, tap - 1, hlo, hhi);
+        if (tap < HP) {
+          const unsigned off = halo_off(q + 1, tap);
+          hlo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+          if constexpr (!IN16) hhi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 16, 0));
+        }
+      }
+      // request: the A fragments of the next K step of this quarter, the B fragments PF steps ahead (past the image: zeros)
+      if (t + 1 < QS && !(H16R_EXP & 4)) {
+        const int t2 = t + 1, tap2 = t2 >> 2, s2 = t2 & 3;
+        read_a(t2 & 1, a_q + ((tap2 / 3) * 34 + tap2 % 3) * PS + s2 * 32);
+      }
+      if (!(H16R_EXP & 2)) load_b((t + PF) % RING, q * QS + t + PF);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(H16R_EXP & 8)) mma(t & 1, t % RING);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q + 1 < NQ) __syncthreads();
+  }
+
+  // ---- epilogue: lane = output channel; register e of acc[i][j] = pixel column (e % 4) + 8 (e / 4) + 4 lh of image row
+  // Y0 + i; the 32 lanes of a half-wave store one whole 128-byte line (fp32) ----
+  if ((H16R_EXP & 1) && acc[0][0][0] != 12345.678f) return;          // (ablation: no result stores)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const size_t row = ((size_t)(nb * p.H + Y0 + i) * p.W + X0) * N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = wave * 64 + j * 32 + lr;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+      float rv[16];
+      if constexpr (RES) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = p.res[row + (size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * N + n];
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = apply_act(acc[i][j][e] + bv, p.act, p.slope);
+        if constexpr (RES) v += rv[e];
+        const size_t o = row + (size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * N + n;
+        if constexpr (OUT16) static_cast<__bf16*>(p.dst)[o] = (__bf16)v;
+        else static_cast<float*>(p.dst)[o] = v;
+      }
+    }
+  }
+}
+
 // ---- weight gradient of the same layers:  dW[o][c][ty][tx] = sum_pixels dy[pixel][o] * x[pixel + (ty-1, tx-1)][c]  ----
 // A workgroup owns a 64 (o) x 64 (c) block of ALL NINE taps (9 x 16 accumulator registers per lane: wave (wo, wc) holds the
 // 32 x 32 sub-block of every tap) over a range of 4 x 32 pixel patches.  Per patch the 64-channel slices of dy (128 pixels)
@@ -981,6 +1155,23 @@ __global__ __launch_bounds__(256) void halo16s_kernel(Halo16SParams p) {
   }
 }
 
+// C = 256: halo16r_kernel (filter operand from the register image)
+int launch_r(const Halo16Params& p, bool in16, bool out16, long long grid, hipStream_t st) {
+  const dim3 g((unsigned)grid), b(256);
+  if (!in16 && !out16) {
+    if (p.res) hipLaunchKernelGGL((halo16r_kernel<true, false, false>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((halo16r_kernel<false, false, false>), g, b, 0, st, p);
+  } else if (!in16 && out16) {
+    hipLaunchKernelGGL((halo16r_kernel<false, false, true>), g, b, 0, st, p);
+  } else if (in16 && out16) {
+    hipLaunchKernelGGL((halo16r_kernel<false, true, true>), g, b, 0, st, p);
+  } else {
+    if (p.res) hipLaunchKernelGGL((halo16r_kernel<true, true, false>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((halo16r_kernel<false, true, false>), g, b, 0, st, p);
+  }
+  return 0;
+}
+
 template <int C>
 int launch_c(const Halo16Params& p, bool in16, bool out16, long long grid, hipStream_t st) {
   const dim3 g((unsigned)grid), b(256);
@@ -1024,7 +1215,7 @@ int halo16_run(const srgan_conv_desc* d, int kind, const void* src, const void* 
   const long long grid = (long long)p.NB * p.tiles_y * p.tiles_x * p.n_tiles;
   SRGAN_REQUIRE(grid > 0 && grid < (1LL << 31), "halo16: grid");
   ProfToken tok = prof_begin(24, flops, st);
-  if (d->I == 256) launch_c<256>(p, in16, out16, grid, st);
+  if (d->I == 256) launch_r(p, in16, out16, grid, st);
   else if (d->I == 128) launch_c<128>(p, in16, out16, grid, st);
   else launch_c<64>(p, in16, out16, grid, st);
   prof_end(tok, st);

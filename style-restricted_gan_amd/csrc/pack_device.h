@@ -228,7 +228,7 @@ __device__ __forceinline__ void wino43_pack_block(const WinoPackParams& p, long 
 }
 
 // variant 4 (conv_halo16.hip, bf16 mode -- no transform): bf16 [64-channel quarter][tap][32-chunk of the quarter][N][32], rounded
-// to nearest even (K tile kt = (quarter * 9 + tap) * 2 + chunk & 1).
+// to nearest even (K tile kt = (quarter * 9 + tap) * 2 + chunk & 1); N = 256: the register image of halo16r_kernel (below).
 // kind 0: B[n][k] = w[n][k][ky][kx];  kind 1: B[n][k] = w[k][n][2-ky][2-kx].
 // One item = (output channel n, 8 reduce channels) for ALL NINE taps: with dense OIHW weights its 72 source values are 288
 // contiguous bytes (kind 0) or eight 36-byte runs (kind 1); an item per tap would walk the whole weight tensor nine times with
@@ -255,6 +255,15 @@ __device__ __forceinline__ void halo16_pack_item(const WinoPackParams& p, long l
     const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
     bf16x8 o;
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+    if (p.N == 256) {
+      // round 6, halo16r_kernel (the 256-channel trunk): the REGISTER image of the filter operand -- one 16-byte piece per lane
+      // and B fragment, [K step ks = (quarter * 9 + tap) * 4 + s (16 reduce channels)][wave = n / 64][n block of 32][lane = 32 h
+      // + n % 32][8 channels 16 s + 8 h ..], so that a wave's fragment load is 1 KB of contiguous global memory
+      const int s4 = (chunk & 1) * 2 + (part >> 1), h = part & 1;
+      const size_t ks = (size_t)(quarter * 9 + tap) * 4 + s4;
+      *reinterpret_cast<bf16x8*>(dst + ((((ks * 4 + (n >> 6)) * 2 + ((n >> 5) & 1)) * 64 + h * 32 + (n & 31)) * 8)) = o;
+      continue;
+    }
     const int kt = (quarter * 9 + tap) * 2 + (chunk & 1);
     *reinterpret_cast<bf16x8*>(dst + ((size_t)kt * p.N + n) * 32 + part * 8) = o;
   }
