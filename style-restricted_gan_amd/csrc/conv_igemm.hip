@@ -512,16 +512,41 @@ constexpr int BK16 = 64;
 constexpr int LDH16 = BK16 + 8;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int BN, bool IN16 = false, bool OUT16 = false>
+// one 16-byte LDS-DMA piece per lane: lane L's bytes land at `lds` (wave-uniform) + 16 L; an out-of-range `voff` (>= bytes)
+// writes zeros.  `base` / `bytes` are wave-uniform (made so here: a descriptor the compiler cannot prove uniform gets a
+// waterfall loop).  A __device__ helper on raw pointers: with the builtin, or a buffer-resource VALUE, in the __global__
+// template itself the HOST pass of hipcc (ROCm 7.2) drops the instantiation without a diagnostic (undefined kernel stub at load).
+__device__ __forceinline__ void lds_dma16(const void* base, unsigned bytes, unsigned char* lds, unsigned voff) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
+}
+
+// DMA (round 6, VERDICT r5 item 1 ii; bf16 source tensors only): both operand tiles go global -> LDS by LDS-DMA
+// (`buffer_load_dwordx4 ... lds`: lane L's 16 bytes land at the wave's LDS base + 16 L), no registers, no ds_write -- the store
+// path (~80 B/clk per CU, shared by the two resident workgroups) was what bounded the loop.  The LDS image is then lane-linear:
+// rows of 128 bytes WITHOUT padding, so the bank spread comes from an XOR swizzle applied on the SOURCE side -- slot s of row r
+// holds the 16-byte piece s ^ ((r >> 1) & 7) (the 16 rows of a ds_read_b128 lane group hit 16 different 16-byte columns of the
+// 256-byte bank row).  A masked row (zero padding, rows past M) is an out-of-range buffer offset: the DMA writes zeros
+// (scratch/dma_test).  Tile kt + 1 is requested when tile kt - 1's buffer is released, one barrier per tile; the wait for a
+// tile's own pieces is a counted vmcnt in front of that barrier (which then publishes every wave's pieces).
+template <int BN, bool IN16 = false, bool OUT16 = false, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
   constexpr int BM = 128;
   constexpr int ESZ = IN16 ? 2 : 4;         // bytes per source element
   constexpr int TN = BN / 64;               // 32-wide column blocks per wave (2 waves across N)
   constexpr int A_IT = BM / 32, B_IT = BN / 32;
   static_assert(BN == 128 || BN == 64, "BN");
-  __shared__ __attribute__((aligned(16))) unsigned short Ah2[2][BM * LDH16];
-  __shared__ __attribute__((aligned(16))) unsigned short Bh2[2][BN * LDH16];
-  __shared__ __attribute__((aligned(16))) int row_o[BM];
+  static_assert(!DMA || IN16, "LDS-DMA moves bf16 source rows as they are");
+  constexpr int LDR = DMA ? BK16 : LDH16;   // bf16 elements per LDS row
+  // ONE shared array (a second __shared__ object beside an LDS-DMA target makes hipcc drain vmcnt in front of every fragment read)
+  constexpr int A_BYTES = BM * LDR * 2, B_BYTES = BN * LDR * 2, OFF_B = 2 * A_BYTES, OFF_ROW = OFF_B + 2 * B_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_ROW + BM * 4];
+  int* const row_o = reinterpret_cast<int*>(smem + OFF_ROW);
+  auto Ah_of = [&](int buf) __attribute__((always_inline)) { return reinterpret_cast<unsigned short*>(smem + buf * A_BYTES); };
+  auto Bh_of = [&](int buf) __attribute__((always_inline)) { return reinterpret_cast<unsigned short*>(smem + OFF_B + buf * B_BYTES); };
 
   const int tid = threadIdx.x;
   const int phase = blockIdx.y;
@@ -674,8 +699,8 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
     }
   };
   auto store_tiles = [&](int buf) __attribute__((always_inline)) {
-    unsigned short* Ah = Ah2[buf];
-    unsigned short* Bh = Bh2[buf];
+    unsigned short* Ah = Ah_of(buf);
+    unsigned short* Bh = Bh_of(buf);
     const int seg = tid & 7;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -711,12 +736,14 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
 
   bf16x8 ah[2][2], bh[2][TN];
   auto read_frags = [&](int buf, int q, int slot) __attribute__((always_inline)) {
-    const unsigned short* Ah = Ah2[buf];
-    const unsigned short* Bh = Bh2[buf];
+    const unsigned short* Ah = Ah_of(buf);
+    const unsigned short* Bh = Bh_of(buf);
+    // DMA image: piece 2 q + lh of a row sits in slot (2 q + lh) ^ ((row >> 1) & 7); the row bases are multiples of 16
+    const int col = DMA ? (((2 * q + lh) ^ ((lr >> 1) & 7)) * 8) : (q * 16 + lh * 8);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ah[slot][i] = *reinterpret_cast<const bf16x8*>(&Ah[(wm * 64 + i * 32 + lr) * LDH16 + q * 16 + lh * 8]);
+    for (int i = 0; i < 2; ++i) ah[slot][i] = *reinterpret_cast<const bf16x8*>(&Ah[(wm * 64 + i * 32 + lr) * LDR + col]);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bh[slot][j] = *reinterpret_cast<const bf16x8*>(&Bh[(wn * (BN / 2) + j * 32 + lr) * LDH16 + q * 16 + lh * 8]);
+    for (int j = 0; j < TN; ++j) bh[slot][j] = *reinterpret_cast<const bf16x8*>(&Bh[(wn * (BN / 2) + j * 32 + lr) * LDR + col]);
   };
   auto mma = [&](int slot) __attribute__((always_inline)) {
 #ifdef SRGAN_EXPERIMENTS
@@ -728,6 +755,68 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot][i], bh[slot][j], acc[i][j], 0, 0, 0);
   };
 
+  if constexpr (DMA) {
+    // ---- LDS-DMA tiles: per thread 4 source rows (A) and B_IT weight rows, one 16-byte piece each, slot = tid & 7 ----
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned key = (tid >> 4) & 7, piece16 = ((tid & 7) ^ key) * 16;       // the piece this lane's slot holds
+    const unsigned a_bytes = (unsigned)((size_t)p.NB * p.Hs * p.Ws * p.Cs * 2), b_bytes = (unsigned)((size_t)p.Npad * p.Kpad * 2);
+    constexpr unsigned kOutside = 0x80000000u;
+    int abase[A_IT];                      // byte offset of the row's window origin (tap (0, 0), channel 0) + this lane's piece
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) abase[i] = (int)voff[i] - (int)(bias * ESZ) - (int)seg16 + (int)piece16;
+    unsigned wbase[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) wbase[i] = woff[i] - seg16 + piece16;
+    auto dma_tile = [&](int buf, int kt_rel) __attribute__((always_inline)) {
+      const int k0 = (kt0 + kt_rel) * BK16;
+      const int tap_off = ((p.reflect ? 0 : sgn * (tap_y * p.Ws + tap_x)) * p.Cs + tap_c) * 2;    // wave-uniform
+      unsigned char* const lds_a = smem + buf * A_BYTES + wave_u * 1024;
+      unsigned char* const lds_b = smem + OFF_B + buf * B_BYTES + wave_u * 1024;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const bool ok = ((vmask[i] >> tap_y) & (vmask[i] >> (8 + tap_x)) & 1u) != 0;
+        const unsigned dyv = (mapy[i] >> (4 * tap_y)) & 15u, dxv = (mapx[i] >> (4 * tap_x)) & 15u;
+        const unsigned off = (unsigned)(abase[i] + tap_off + (int)((dyv * p.Ws + dxv) * p.Cs * 2));
+        lds_dma16(p.src, a_bytes, lds_a + i * 4096, ok ? off : kOutside);
+      }
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i)
+        lds_dma16(wp, b_bytes, lds_b + i * 4096, wbase[i] + (unsigned)(k0 * 2));
+      tap_c += BK16;
+      const int wc = tap_c == p.Cs;
+      tap_c = wc ? 0 : tap_c;
+      tap_x += wc;
+      const int wx = tap_x == p.Tx;
+      tap_x = wx ? 0 : tap_x;
+      tap_y += wx;
+    };
+    if (nk > 0) {
+      dma_tile(0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                   // tile 0 and row_o are visible
+      if (nk > 1) dma_tile(1, 1);
+      for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        read_frags(cur, 0, 0);
+        read_frags(cur, 1, 1);
+        mma(0);
+        read_frags(cur, 2, 0);
+        mma(1);
+        read_frags(cur, 3, 1);
+        mma(0);
+        mma(1);
+        if (kt + 1 < nk) {
+          // this wave's pieces of tile kt + 1 have landed; behind the barrier so have everyone's, and nobody reads buffer
+          // `cur` any more: tile kt + 2 may overwrite it
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (kt + 2 < nk) dma_tile(cur, kt + 2);
+        }
+      }
+    }
+    __syncthreads();
+  } else {
   if (nk > 0) {
     load_tiles(0);
     store_tiles(0);
@@ -749,6 +838,7 @@ __global__ __launch_bounds__(256, 2) void igemm16_kernel(IgemmParams p) {
     }
   } else {
     __syncthreads();
+  }
   }
 
   // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -1479,9 +1569,13 @@ static int launch_igemm16(IgemmParams p, int phases, hipStream_t st, double flop
   const long long gx = std::min<long long>(tiles, std::max<long long>(8, (512 / planes) & ~7LL));
   dim3 grid((unsigned)gx, (unsigned)phases, (unsigned)std::max(p.ksplit, 1));
   const bool o16 = p.dst16 != 0 && p.ksplit <= 1;
+  static const bool no_dma = SRGAN_AB_SET("SRGAN_NO_IG16_DMA");       // (A/B, experiment builds only)
+  const bool dma = !no_dma;
 #define SRGAN_IG16(BN_)                                                                                      \
   do {                                                                                                        \
-    if (p.src16 && o16) hipLaunchKernelGGL((igemm16_kernel<BN_, true, true>), grid, dim3(256), 0, st, p);      \
+    if (p.src16 && o16 && dma) hipLaunchKernelGGL((igemm16_kernel<BN_, true, true, true>), grid, dim3(256), 0, st, p);      \
+    else if (p.src16 && dma) hipLaunchKernelGGL((igemm16_kernel<BN_, true, false, true>), grid, dim3(256), 0, st, p);       \
+    else if (p.src16 && o16) hipLaunchKernelGGL((igemm16_kernel<BN_, true, true>), grid, dim3(256), 0, st, p);      \
     else if (p.src16) hipLaunchKernelGGL((igemm16_kernel<BN_, true, false>), grid, dim3(256), 0, st, p);       \
     else if (o16) hipLaunchKernelGGL((igemm16_kernel<BN_, false, true>), grid, dim3(256), 0, st, p);           \
     else hipLaunchKernelGGL((igemm16_kernel<BN_, false, false>), grid, dim3(256), 0, st, p);                  \
