@@ -264,6 +264,18 @@ int srgan_igemm16_io_applicable(const srgan_conv_desc* d, int act);
 int srgan_igemm16_conv(const srgan_conv_desc* d, int kind, const void* src, int src_bf16, const void* packed, const float* bias,
                        void* dst, int dst_bf16, int act, float slope, void* ws, size_t ws_bytes, void* stream);
 int srgan_igemm16_wgrad(const srgan_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, void* stream);
+/* bf16 mode, round 6: the 4x4 / stride-2 / pad-1 layers of the discriminator trunks (pyfiles/model.py:302-309: conv without bias
+ * -> LeakyReLU(0.01), no norm between the layers) with bf16 tensors on either side: forward with the bias / activation epilogue
+ * (halo16s_kernel, or igemm16_kernel with LDS-DMA tiles), input gradient (halo16t_kernel or igemm16_kernel); the weight gradient is
+ * srgan_halo16_wgrad.  `packed`: the ordinary packed operand of (d, kind, act).  ws: srgan_conv2d_packed_scratch(d, kind) bytes. */
+int srgan_conv2d_io_applicable(const srgan_conv_desc* d, int act);
+int srgan_conv2d_io_fwd(const srgan_conv_desc* d, const void* x, int x_bf16, const void* packed, const float* bias, void* y, int y_bf16,
+                        int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int srgan_conv2d_io_dgrad(const srgan_conv_desc* d, const void* dy, int dy_bf16, const void* packed, void* dx, int dx_bf16, void* ws,
+                          size_t ws_bytes, void* stream);
+/* LeakyReLU / ReLU backward dx = dy * f'(y) over n elements (n % 8 == 0), every tensor fp32 or bf16 (nn.LeakyReLU, model.py:303,310). */
+int srgan_act_bwd_io(const void* y, int y_bf16, const void* dy, int dy_bf16, void* dx, int dx_bf16, long long n, int act, float slope,
+                     void* stream);
 /* Single-pass instance norm (+ per-sample scale / shift, activation, optional fp32 skip tensor) of maps with <= 1024 pixels with
  * bf16 tensors on either side; statistics, sums, scale / shift gradients in fp32.  Backward: x = the normalised tensor's INPUT
  * (fp32 or bf16), dy fp32 or bf16, dx of x's type.  srgan_instnorm_slab_applicable: the shape is served (C % 32 == 0, HW <= 1024, enough slabs). */

@@ -2546,8 +2546,10 @@ extern "C" int srgan_halo16_wgrad(const srgan_conv_desc* d, const void* x, int x
                                   void* ws, size_t ws_bytes, void* stream) {
   if (int e = validate(d)) return e;
   SRGAN_REQUIRE(x && dy && dw && ws, "halo16_wgrad: null pointer");
-  SRGAN_REQUIRE(srgan_halo16_applicable(d) || srgan_halo16s2_applicable(d),
-                "halo16_wgrad: layer / compute mode not applicable (srgan_halo16_applicable / srgan_halo16s2_applicable)");
+  // (round 6: also the stride-2 layers no patch kernel serves forward -- the discriminators' 16- and 8-pixel maps,
+  //  srgan_conv2d_io_applicable -- whose weight gradient halo16s2_wgrad_kernel takes all the same)
+  SRGAN_REQUIRE(compute_bf16() && halo16_wgrad_applicable(d),
+                "halo16_wgrad: layer / compute mode not applicable (srgan_halo16_applicable / srgan_halo16s2_applicable / srgan_conv2d_io_applicable)");
   SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "halo16_wgrad: workspace too small (srgan_conv2d_workspace)");
   hipStream_t st = as_stream(stream);
   if (int e = defer_take(d, &ws, &ws_bytes, st)) return e;
@@ -2815,6 +2817,73 @@ extern "C" int srgan_igemm16_wgrad(const srgan_conv_desc* d, const void* x, cons
   if (int e = defer_take(d, &ws, &ws_bytes, st)) return e;
   const WgradPlan w = plan_wgrad(d);
   return generic_wgrad(d, w, static_cast<const float*>(x), static_cast<const float*>(dy), dw, nullptr, ws, st, true);
+}
+
+// ---- bf16 mode, round 6: 16-bit activations in the discriminator trunks (VERDICT r5 item 1 iii) ----
+// SingleDiscriminator_solo (pyfiles/model.py:294-316) is [conv 4x4 / stride 2 / pad 1, no bias -> LeakyReLU(0.01)] x num_cls with
+// no norm between: the tensors between the layers are written by one convolution's epilogue and read by the next one's gather.
+// These entry points run such a layer with bf16 tensors on either side on whatever kernel serves the direction in the bf16 mode
+// -- forward: halo16s_kernel or igemm16_kernel (bias / activation in the epilogue, LDS-DMA tiles from a bf16 source); input
+// gradient: halo16t_kernel or igemm16_kernel; weight gradient: srgan_halo16_wgrad (halo16s2_wgrad_kernel takes bf16 x / dy).
+// `packed`: the ordinary packed operand of (d, kind, act) in the bf16 mode (srgan_conv2d_pack / the pack cache).
+namespace srgan {
+static bool conv_io_dirs(const srgan_conv_desc* d, int act, int* fwd, int* bwd) {      // 1: patch kernel, 2: igemm16_kernel
+  if (!compute_bf16() || d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 1 || d->pad_mode != SRGAN_PAD_ZERO) return false;
+  if ((d->I & 7) || (d->O & 7)) return false;
+  const FwdPath path = fwd_path(d, act);
+  if (path == PATH_WINO && halo16s_applicable(d)) *fwd = 1;
+  else if (path == PATH_IGEMM) {
+    IgemmParams p{};
+    fwd_geometry(d, PATH_IGEMM, p);
+    if (!igemm16_ok(p)) return false;
+    *fwd = 2;
+  } else return false;
+  const DgradGeom g = dgrad_geometry(d);
+  if (g.wino && halo16t_applicable(d)) *bwd = 1;
+  else if (!g.wino && !g.narrow && !g.rgbin && !g.narrow_s2 && !g.reflect && igemm16_ok(g.p)) *bwd = 2;
+  else return false;
+  return halo16_wgrad_applicable(d);
+}
+}  // namespace srgan
+
+extern "C" int srgan_conv2d_io_applicable(const srgan_conv_desc* d, int act) {
+  if (validate(d) != 0) return 0;
+  int f = 0, b = 0;
+  return conv_io_dirs(d, act, &f, &b) ? 1 : 0;
+}
+
+extern "C" int srgan_conv2d_io_fwd(const srgan_conv_desc* d, const void* x, int x_bf16, const void* packed, const float* bias, void* y,
+                                   int y_bf16, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(x && packed && y, "conv2d_io_fwd: null pointer");
+  int f = 0, b = 0;
+  SRGAN_REQUIRE(conv_io_dirs(d, act, &f, &b), "conv2d_io_fwd: layer / compute mode not applicable (srgan_conv2d_io_applicable)");
+  hipStream_t st = as_stream(stream);
+  if (f == 1) return halo16s_run(d, x, packed, bias, y, act, slope, conv_flops(d), st, x_bf16 != 0, y_bf16 != 0);
+  const size_t need = srgan_conv2d_packed_scratch(d, 0);
+  SRGAN_REQUIRE(need == 0 || (ws && ws_bytes >= need), "conv2d_io_fwd: workspace too small (srgan_conv2d_packed_scratch)");
+  IgemmParams p{};
+  fwd_geometry(d, PATH_IGEMM, p);
+  p.src = static_cast<const float*>(x); p.bias = bias; p.dst = static_cast<float*>(y); p.act = act; p.slope = slope;
+  p.wp = static_cast<const float*>(packed); p.src16 = x_bf16 != 0; p.dst16 = y_bf16 != 0;
+  return run_igemm(p, 1, st, conv_flops(d), need ? static_cast<float*>(ws) : nullptr);
+}
+
+extern "C" int srgan_conv2d_io_dgrad(const srgan_conv_desc* d, const void* dy, int dy_bf16, const void* packed, void* dx, int dx_bf16,
+                                     void* ws, size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SRGAN_REQUIRE(dy && packed && dx, "conv2d_io_dgrad: null pointer");
+  int f = 0, b = 0;
+  SRGAN_REQUIRE(conv_io_dirs(d, SRGAN_ACT_NONE, &f, &b) || conv_io_dirs(d, SRGAN_ACT_LRELU, &f, &b),
+                "conv2d_io_dgrad: layer / compute mode not applicable (srgan_conv2d_io_applicable)");
+  hipStream_t st = as_stream(stream);
+  if (b == 1) return halo16t_run(d, dy, packed, dx, conv_flops(d), st, dy_bf16 != 0, dx_bf16 != 0);
+  const size_t need = srgan_conv2d_packed_scratch(d, 1);
+  SRGAN_REQUIRE(need == 0 || (ws && ws_bytes >= need), "conv2d_io_dgrad: workspace too small (srgan_conv2d_packed_scratch)");
+  DgradGeom g = dgrad_geometry(d);
+  g.p.src = static_cast<const float*>(dy); g.p.wp = static_cast<const float*>(packed); g.p.src16 = dy_bf16 != 0;
+  g.p.dst = static_cast<float*>(dx); g.p.dst16 = dx_bf16 != 0;
+  return run_igemm(g.p, g.phases, st, conv_flops(d), need ? static_cast<float*>(ws) : nullptr);
 }
 
 // A weight used more than once in one backward pass (the generator runs twice inside util_notebook.py:664 and :689) gets its

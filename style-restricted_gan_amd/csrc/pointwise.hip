@@ -21,6 +21,43 @@ __global__ void act_fwd_kernel(const float* x, float* y, long long n, int act, f
 __global__ void act_bwd_kernel(const float* y, const float* dy, float* dx, long long n, int act, float slope) {
   GRID_STRIDE(i, n) dx[i] = dy[i] * act_grad(y[i], act, slope);
 }
+// 16-bit I/O (round 6: the discriminator trunks' bf16 activations): 8 elements per thread, any mix of fp32 / bf16 tensors
+template <bool Y16, bool D16, bool X16>
+__global__ __launch_bounds__(256) void act_bwd_io_kernel(const void* y, const void* dy, void* dx, long long n8, int act, float slope) {
+  const float neg = act_neg_slope(act, slope);
+  GRID_STRIDE(i, n8) {
+    float yv[8], dv[8];
+    if constexpr (Y16) {
+      const bf16x8 t = reinterpret_cast<const bf16x8*>(y)[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) yv[e] = (float)t[e];
+    } else {
+      const f32x4 a = reinterpret_cast<const f32x4*>(y)[2 * i], b = reinterpret_cast<const f32x4*>(y)[2 * i + 1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { yv[e] = a[e]; yv[4 + e] = b[e]; }
+    }
+    if constexpr (D16) {
+      const bf16x8 t = reinterpret_cast<const bf16x8*>(dy)[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dv[e] = (float)t[e];
+    } else {
+      const f32x4 a = reinterpret_cast<const f32x4*>(dy)[2 * i], b = reinterpret_cast<const f32x4*>(dy)[2 * i + 1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dv[e] = a[e]; dv[4 + e] = b[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dv[e] = dv[e] * (yv[e] > 0.f ? 1.f : neg);
+    if constexpr (X16) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)dv[e];
+      reinterpret_cast<bf16x8*>(dx)[i] = o;
+    } else {
+      reinterpret_cast<f32x4*>(dx)[2 * i] = f32x4{dv[0], dv[1], dv[2], dv[3]};
+      reinterpret_cast<f32x4*>(dx)[2 * i + 1] = f32x4{dv[4], dv[5], dv[6], dv[7]};
+    }
+  }
+}
 __global__ void tanh_fwd_kernel(const float* x, float* y, long long n) {
   GRID_STRIDE(i, n) y[i] = tanhf(x[i]);
 }
@@ -370,6 +407,24 @@ extern "C" int srgan_act_bwd(const float* y, const float* dy, float* dx, long lo
   SRGAN_REQUIRE(y && dy && dx && n >= 0, "act_bwd: bad argument");
   if (n == 0) return 0;
   LAUNCH1D(act_bwd_kernel, n, stream, y, dy, dx, n, act, slope);
+}
+extern "C" int srgan_act_bwd_io(const void* y, int y_bf16, const void* dy, int dy_bf16, void* dx, int dx_bf16, long long n, int act,
+                                float slope, void* stream) {
+  SRGAN_REQUIRE(y && dy && dx && n >= 0, "act_bwd_io: bad argument");
+  SRGAN_REQUIRE((n & 7) == 0, "act_bwd_io: n %% 8 != 0");
+  if (n == 0) return 0;
+  const long long n8 = n / 8;
+  const int sel = (y_bf16 ? 4 : 0) | (dy_bf16 ? 2 : 0) | (dx_bf16 ? 1 : 0);
+  switch (sel) {
+    case 0: LAUNCH1D((act_bwd_io_kernel<false, false, false>), n8, stream, y, dy, dx, n8, act, slope);
+    case 1: LAUNCH1D((act_bwd_io_kernel<false, false, true>), n8, stream, y, dy, dx, n8, act, slope);
+    case 2: LAUNCH1D((act_bwd_io_kernel<false, true, false>), n8, stream, y, dy, dx, n8, act, slope);
+    case 3: LAUNCH1D((act_bwd_io_kernel<false, true, true>), n8, stream, y, dy, dx, n8, act, slope);
+    case 4: LAUNCH1D((act_bwd_io_kernel<true, false, false>), n8, stream, y, dy, dx, n8, act, slope);
+    case 5: LAUNCH1D((act_bwd_io_kernel<true, false, true>), n8, stream, y, dy, dx, n8, act, slope);
+    case 6: LAUNCH1D((act_bwd_io_kernel<true, true, false>), n8, stream, y, dy, dx, n8, act, slope);
+    default: LAUNCH1D((act_bwd_io_kernel<true, true, true>), n8, stream, y, dy, dx, n8, act, slope);
+  }
 }
 extern "C" int srgan_tanh_fwd(const float* x, float* y, long long n, void* stream) {
   SRGAN_REQUIRE(x && y && n >= 0, "tanh_fwd: bad argument");

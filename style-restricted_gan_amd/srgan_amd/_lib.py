@@ -76,6 +76,10 @@ SIGNATURES = {
     "srgan_instnorm_bwd_io": (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "srgan_halo16_conv": (c_int, [_DESC, c_int, P, c_int, P, P, P, c_int, P]),
     "srgan_halo16_wgrad": (c_int, [_DESC, P, c_int, P, c_int, P, P, c_size_t, P]),
+    "srgan_conv2d_io_applicable": (c_int, [_DESC, c_int]),
+    "srgan_conv2d_io_fwd": (c_int, [_DESC, P, c_int, P, P, P, c_int, c_int, c_float, P, c_size_t, P]),
+    "srgan_conv2d_io_dgrad": (c_int, [_DESC, P, c_int, P, P, c_int, P, c_size_t, P]),
+    "srgan_act_bwd_io": (c_int, [P, c_int, P, c_int, P, c_int, c_longlong, c_int, c_float, P]),
     "srgan_igemm16_io_applicable": (c_int, [_DESC, c_int]),
     "srgan_igemm16_conv": (c_int, [_DESC, c_int, P, c_int, P, P, P, c_int, c_int, c_float, P, c_size_t, P]),
     "srgan_igemm16_wgrad": (c_int, [_DESC, P, P, P, P, c_size_t, P]),

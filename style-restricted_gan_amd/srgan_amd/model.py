@@ -49,6 +49,15 @@ class _Conv2d(nn.Conv2d):
         return (self.bias is None and self.kernel_size == (4, 4) and self.stride == (2, 2) and self.padding == (1, 1)
                 and self.padding_mode == "zeros" and ops.s2_io_applicable(n, ci, hi, wi, self.out_channels, self.weight, False))
 
+    def act_io_applicable_shape(self, n, ci, hi, wi, act):
+        return (self.bias is None and self.kernel_size == (4, 4) and self.stride == (2, 2) and self.padding == (1, 1)
+                and self.padding_mode == "zeros" and ci == self.in_channels and ops.conv_act_io_applicable(n, ci, hi, wi, self.weight, act))
+
+    def act_io_applicable(self, x, act):
+        """bf16 mode: this 4x4 / stride-2 layer + activation runs with 16-bit tensors (ops.conv2d_act_io; the discriminator trunks)."""
+        n, ci, hi, wi = x.shape
+        return self.act_io_applicable_shape(n, ci, hi, wi, act)
+
     def forward_io(self, x, out_bf16=True):
         """bf16 mode, io_applicable layers: the input may be a bf16 tensor, the output is written as bf16 / fp32 (the style
         encoder's blocks, ops.py "16-bit activations around the generic convolutions")."""
@@ -409,6 +418,11 @@ def _d_trunk_layers(nch_in, nch, reduce, num_cls):
 _CHAIN_ACT_BWD = not _lib.ab("SRGAN_NO_CHAIN_ACT_BWD")
 
 
+def _conv_out_hw(m, x):
+    kh, kw = m.kernel_size
+    return ((x.shape[2] + 2 * m.padding[0] - kh) // m.stride[0] + 1, (x.shape[3] + 2 * m.padding[1] - kw) // m.stride[1] + 1)
+
+
 def _run_trunk(seq, x):
     """conv + LeakyReLU pairs run as one fused kernel each; a trailing bias conv runs plain.  Inside the chain a pair's
     LeakyReLU backward is done by the NEXT conv's input-gradient kernel (ops._Conv2dFn: the intermediate tensors have no other
@@ -425,8 +439,19 @@ def _run_trunk(seq, x):
             i += 1
     prev_slope = None                            # slope of the previous pair when its backward was handed to this conv
     for j, (m, slope) in enumerate(steps):
+        # bf16 mode, round 6: a conv 4x4 / stride 2 + LeakyReLU pair whose three directions take bf16 tensors runs on them
+        # (ops.conv2d_act_io); its output is bf16 when the next pair reads it the same way (the heads take fp32)
+        if slope is not None and prev_slope is None and isinstance(m, _Conv2d) and m.act_io_applicable(x, ACT_LRELU):
+            nxt = steps[j + 1] if j + 1 < len(steps) else None
+            out16 = bool(nxt is not None and nxt[1] is not None and isinstance(nxt[0], _Conv2d)
+                         and nxt[0].act_io_applicable_shape(x.shape[0], m.out_channels, x.shape[2] // 2, x.shape[3] // 2, ACT_LRELU))
+            x = ops.conv2d_act_io(x, m.weight, ACT_LRELU, slope, out16)
+            prev_slope = None
+            continue
         hand_on = (_CHAIN_ACT_BWD and slope is not None and j + 1 < len(steps) and isinstance(m, _Conv2d)
-                   and isinstance(steps[j + 1][0], _Conv2d) and torch.is_grad_enabled())
+                   and isinstance(steps[j + 1][0], _Conv2d) and torch.is_grad_enabled()
+                   and not (steps[j + 1][1] is not None
+                            and steps[j + 1][0].act_io_applicable_shape(x.shape[0], m.out_channels, *_conv_out_hw(m, x), ACT_LRELU)))
         if isinstance(m, _Conv2d):
             x = m(x, ACT_LRELU if slope is not None else ACT_NONE, slope or 0.0, prev_slope, hand_on)
         elif slope is not None:

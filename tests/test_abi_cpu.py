@@ -108,4 +108,8 @@ def test_no_buffer_store_with_a_scalar_register_offset_in_the_product_isa(built_
     assert not bad, bad[:5]
     # the loads are there and do use scalar offsets: the pattern above is looking at the right operand
     loads = re.findall(r"^\s*buffer_load\w*\s+(.*?)(?://.*)?$", isa, flags=re.M)
-    assert sum(1 for o in loads if re.match(r"s\d+", o.split(",")[3].strip().split()[0])) > 100
+    # (the LDS-DMA form `buffer_load_dwordx4 vaddr, srsrc, soffset offen lds` has no data operand)
+    def soffset(o):
+        ops = [t.strip() for t in o.split(",")]
+        return (ops[2] if " lds" in " " + ops[-1] else ops[3]).split()[0]
+    assert sum(1 for o in loads if re.match(r"s\d+", soffset(o))) > 100

@@ -1351,6 +1351,111 @@ def test_stride2_io_functions_every_dtype_pair(ops, in16, out16):
 
 @pytest.mark.parametrize("in16", [False, True])
 @pytest.mark.parametrize("out16", [False, True])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 64, 64), (3, 128, 256, 32, 32), (4, 256, 512, 16, 16), (2, 64, 128, 16, 16),
+                                   (2, 512, 512, 16, 16)])
+def test_conv_act_io_every_dtype_pair(ops, shape, in16, out16):
+    """Round 6 (VERDICT r5 item 1 iii): the discriminator trunks' conv 4x4 / stride 2 / pad 1 (no bias) + LeakyReLU(0.01) layers
+    (pyfiles/model.py:302-309; d1: 64 -> 128 @ 64, 128 -> 256 @ 32, 256 -> 512 @ 16, at 256 x 256 also 512 -> 512; d2: 64 -> 128
+    @ 16) with bf16 tensors on either side in the bf16 mode (ops.conv2d_act_io: halo16s_kernel / igemm16_kernel with LDS-DMA tiles
+    forward, halo16t_kernel / igemm16_kernel backward, halo16s2_wgrad_kernel): forward + input gradient + weight gradient of
+    every fp32 / bf16 mix against the fp32 convolution of the bf16-rounded operands.  The LeakyReLU derivative is applied to the
+    incoming gradient and the product rounded to bf16 (what the device's act_bwd_io writes) before the reference's backward."""
+    torch.set_num_threads(16)
+    n, ci, co, h, w = shape
+    slope = 0.01
+    x = rnd(n, ci, h, w, seed=41)
+    wt = rnd(co, ci, 4, 4, seed=42) / np.sqrt(ci * 16)
+    gy = rnd(n, co, h // 2, w // 2, seed=43)
+
+    def r16(t, on):
+        return _bf16_round(t) if on else t
+
+    ops.set_compute_dtype("bf16")
+    try:
+        with ops.pack_cache():
+            wd = wt.cuda().requires_grad_(True)
+            if not ops.conv_act_io_applicable(n, ci, h, w, wd, ops.ACT_LRELU):
+                pytest.skip("no 16-bit path for this shape")
+            xd = x.cuda().contiguous(memory_format=torch.channels_last)
+            xd = (xd.to(torch.bfloat16) if in16 else xd).requires_grad_(True)
+            y = ops.conv2d_act_io(xd, wd, ops.ACT_LRELU, slope, out16)
+            assert y.dtype == (torch.bfloat16 if out16 else torch.float32)
+            g_dev = gy.cuda().contiguous(memory_format=torch.channels_last).to(y.dtype)
+            y.backward(g_dev)
+            # reference: operands as the kernels see them
+            xr, wr = _bf16_round(x).clone().requires_grad_(True), _bf16_round(wt).clone().requires_grad_(True)
+            z = F.conv2d(xr, wr, None, 2, 1)
+            y_ref = F.leaky_relu(z, slope)
+            close(y.float().cpu(), r16(y_ref.detach(), out16), 2e-5 if not out16 else 5e-3)
+            # the device multiplies the gradient it received (of y's type) by the derivative taken from the y it STORED and rounds
+            # the product to bf16
+            y_seen = y.detach().float().cpu()
+            g = _bf16_round(r16(gy, out16) * torch.where(y_seen > 0, torch.ones_like(y_seen), torch.full_like(y_seen, slope)))
+            z.backward(g)
+            close(xd.grad.float().cpu(), r16(xr.grad, in16), 2e-5 if not in16 else 5e-3)
+            close(wd.grad.cpu(), wr.grad, 5e-5)
+    finally:
+        ops.set_compute_dtype("fp32")
+        ops.invalidate_packed()
+
+
+def test_discriminator_bf16_activation_storage_vs_fp32_tensors(ops):
+    """Round 6: the full-width discriminator (both scales, heads) forward + backward in the bf16 mode with the trunks' 16-bit
+    activations on and off: both are bf16-mode results (same products; the storage adds one rounding per stored activation and
+    gradient), held to each other and to the fp32-tensor chain's own distance from the exact-fp32 mode."""
+    from srgan_amd import model
+    torch.manual_seed(0)
+    D = model.SingleDiscriminator_solo_multi(3, 64, 2, 4, "instance", 4).cuda()
+    x = (torch.rand(4, 3, 128, 128) * 2 - 1).cuda()
+    params = [p for p in D.parameters()]
+
+    def run(mode, storage):
+        ops.set_compute_dtype(mode)
+        ops.STORAGE_BF16 = storage
+        try:
+            for p in params:
+                p.grad = None
+            xg = x.clone().requires_grad_(True)
+            with ops.pack_cache():
+                if mode == "bf16":
+                    probe = torch.empty((4, 64, 64, 64), device="cuda")
+                    assert D.discriminator1.down_convs[2].act_io_applicable(probe, ops.ACT_LRELU) == storage
+                outs, logits = D.forward_logits(xg)
+                loss = sum((o ** 2).mean() for o in outs) + sum((z * torch.linspace(-1, 1, z.numel(), device=z.device).view_as(z)).sum()
+                                                                for z in logits)
+                loss.backward()
+            return ([o.detach().clone() for o in outs] + [z.detach().clone() for z in logits], xg.grad.detach().clone(),
+                    [p.grad.detach().clone() for p in params])
+        finally:
+            ops.STORAGE_BF16 = True
+            ops.set_compute_dtype("fp32")
+            ops.invalidate_packed()
+
+    o32, dx32, g32 = run("fp32", True)
+    oc, dxc, gc = run("bf16", False)
+    os_, dxs, gs = run("bf16", True)
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-12))
+
+    for a, b, r in zip(os_, oc, o32):
+        assert rel(a, r) <= 1.5 * rel(b, r) + 3e-3, (rel(a, r), rel(b, r))
+        assert rel(a, r) <= 2e-2
+    assert rel(dxs, dx32) <= 1.5 * rel(dxc, dx32) + 5e-3, (rel(dxs, dx32), rel(dxc, dx32))
+    worst = ("", 0.0, 0.0)
+    for (name, _), a, b, r in zip(D.named_parameters(), gs, gc, g32):
+        e_s, e_c = rel(a, r), rel(b, r)
+        if e_s > worst[1]:
+            worst = (name, e_s, e_c)
+        assert e_s <= 1.6 * e_c + 1e-2, (name, e_s, e_c)
+    print("discriminator gradients, worst tensor:", worst, "input gradient:", rel(dxs, dx32), rel(dxc, dx32))
+    # measured: 0.0789 with the storage on and 0.0789 with it off (discriminator1.down_convs.2.weight): the distance is the bf16
+    # mode's, not the storage's; 1.3 x as the absolute cap
+    assert worst[1] <= 0.103, worst
+
+
+@pytest.mark.parametrize("in16", [False, True])
+@pytest.mark.parametrize("out16", [False, True])
 @pytest.mark.parametrize("shape", [(2, 64, 128, 30, 30, "reflect"), (3, 128, 128, 15, 15, "reflect"), (4, 256, 512, 7, 7, "reflect"),
                                    (2, 128, 64, 12, 20, "zeros")])
 def test_generic_conv_io_every_dtype_pair(ops, shape, in16, out16):
