@@ -488,6 +488,9 @@ def main():
         log(f"warm-up step {s} done")
     graphed = bool(use_graph and getattr(sg, "graph_active", False))
     graph_fallback = bool(use_graph and not graphed)
+    _rec = getattr(getattr(sg, "_graph", None), "graph", None) if graphed else None
+    graph_segments = len(_rec.segments) if _rec is not None else None
+    graph_single = bool(_rec is not None and getattr(_rec, "single", False))
     if graph_fallback and (world == 1 or args.graph == "on"):
         # enable_graph() was accepted but the step is not replaying a recording after the warm-up: the line would silently
         # describe another execution mode -- refuse instead of warning.  (Under a process group with --graph auto the ranks'
@@ -598,14 +601,19 @@ def main():
                                    (", E trunk frozen (BASELINE configs[2])" if args.pretrained_e else ", E trainable (BASELINE configs[1])"),
                        "global_batch": B * world, "unrolled_k": args.k, "parallelism": f"dp{world}",
                        "graph_fallback": graph_fallback,
-                       "backend": (dist.get_backend() if world > 1 else None),
-                       "ranks_seen": (dist.get_world_size() if world > 1 else 1), "devices": devices,
-                       "gradient_message_dtype": (dp.bucket_dtype() if world > 1 else None),
+                       # (keyed on the data-parallel CODE PATH, not on the rank count: SRGAN_DP_FORCE=1 drives it with one rank)
+                       "backend": (dist.get_backend() if dp.is_distributed() else None),
+                       "collectives": (dp.transport() if dp.is_distributed() else None),
+                       "graph_segments": graph_segments,
+                       "ranks_seen": (dist.get_world_size() if dp.is_distributed() else 1), "devices": devices,
+                       "gradient_message_dtype": (dp.bucket_dtype() if dp.is_distributed() else None),
                        "kernel_source_sha": kernel_source_sha(),
                        "experiment_switches": switches,
                        "execution": ("eager launches (hipGraph recording FAILED on some rank: all ranks fell back)" if graph_fallback else
-                                     "eager launches" if not graphed else "hipGraph replay of the captured step" if world == 1 else
-                                     f"hipGraph segments replayed with the {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} "
+                                     "eager launches" if not graphed else "hipGraph replay of the captured step" if not dp.is_distributed() else
+                                     ("ONE hipGraph per step with the RCCL collectives (C ABI: srgan_allreduce_bucket / srgan_allgather_rows) "
+                                      "captured on the communication stream, no host-side vote per step") if graph_single else
+                                     f"{graph_segments} hipGraph segments replayed with the {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} "
                                      "all-reduces started on the communication stream between them (running under the next segment)"),
                        "gflop_per_image_algorithmic": gflop_img,
                        "step_tflops_algorithmic": round(value * (gflop_img or 0) / 1e3, 2),

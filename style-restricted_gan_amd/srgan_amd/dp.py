@@ -628,8 +628,11 @@ def control_group():
         if dist.get_backend() == "gloo":
             _control = dist.group.WORLD
         else:
+            # (a bounded wait: a rank that reaches a vote its peers never join -- see trainer._StepGraph.accepts -- raises
+            #  after this instead of sitting in it for the default half hour)
+            import datetime
             with _stdout_to_stderr():
-                _control = dist.new_group(backend="gloo")
+                _control = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=5))
     return _control
 
 

@@ -72,8 +72,14 @@ def _run(rank, world, out_q=None, kl=0.0, graph=False, recipe=None):
         # data parallel: the recording is cut where a collective starts and where its result is needed -- K x (start, wait) for
         # the discriminator, the mu all-gather, start(E) inside phase 1's backward (round 4), start(G) with wait(E), wait(G),
         # start(G) with its wait: 2K + 6 graph segments
-        assert sg.graph_active and len(sg._graph.graph.segments) == (2 * K + 6 if dp.is_distributed() else 1)
-        if dp.is_distributed():
+        # round 6: with the C-ABI collectives (SRGAN_DP_COMM=abi) they are captured and the step is ONE graph; the kinds of the
+        # captured collectives, in enqueue order, are the cuts of the segmented form
+        single = dp.is_distributed() and getattr(sg._graph.graph, "single", False)
+        assert single == (dp.is_distributed() and dp.transport() == "abi" and os.environ.get("SRGAN_DP_SINGLE_GRAPH") != "0")
+        assert sg.graph_active and len(sg._graph.graph.segments) == (2 * K + 6 if dp.is_distributed() and not single else 1)
+        if single:
+            assert sg._graph.graph.inline == ["all_reduce", "wait"] * K + ["all_gather", "all_reduce", "all_reduce", "wait", "all_reduce"]
+        elif dp.is_distributed():
             _check_overlap_order(sg._graph.graph.trace)
     state = {f"{n}.{k}": v.detach().cpu().numpy().copy() for n, net in (("G", sg.G), ("D", sg.D), ("E", sg.E)) for k, v in net.state_dict().items()}
     terms = {k: float(v) for k, v in sg.loss_terms.items()}
@@ -218,6 +224,30 @@ def test_rccl_path_one_rank_equals_plain_step(graph, transport):
     for key, v in state.items():
         d = float(np.abs(v - ref_state[key]).max())
         assert d <= 1e-6, (key, d)
+
+
+def test_single_graph_step_equals_segmented_step_bit_for_bit():
+    """Round 6: with the C-ABI collectives the recorded data-parallel step is ONE hipGraph -- the bucket
+    all-reduces and the mu all-gather are captured on the communication stream (forked / joined by the buckets' events) -- and a
+    replay is a single launch with no host-side vote.  One rank over RCCL on the test box's GPU: the parameters after the steps
+    are BIT-identical to the segmented form (SRGAN_DP_SINGLE_GRAPH=0: the same kernels and collectives, launched as 2k + 6 graphs
+    with host callables between them), and both reproduce the plain single-process step."""
+    ref_losses, ref_state, _ = _run(0, 1)
+    out = {}
+    for single in ("1", "0"):
+        os.environ["SRGAN_DP_COMM"] = "abi"
+        os.environ["SRGAN_DP_SINGLE_GRAPH"] = single
+        try:
+            (rank, losses, state, terms), = _spawn(1, lambda r, port, q: (0, 1, port, q, 0.0, "nccl", True, True))
+        finally:
+            os.environ.pop("SRGAN_DP_COMM", None)
+            os.environ.pop("SRGAN_DP_SINGLE_GRAPH", None)
+        out[single] = (losses, state)
+    assert out["1"][0] == out["0"][0], (out["1"][0], out["0"][0])
+    for key, v in out["1"][1].items():
+        assert np.array_equal(v, out["0"][1][key]), key
+        assert float(np.abs(v - ref_state[key]).max()) <= 1e-6, key
+    np.testing.assert_allclose(np.array(out["1"][0]), np.array(ref_losses), rtol=1e-4)
 
 
 @pytest.mark.parametrize("graph,messages", [(False, "fp32"), (True, "fp32"), (True, "bf16")])
