@@ -545,6 +545,14 @@ __global__ __launch_bounds__(256) void halo16_wgrad_kernel(Halo16WgradParams p) 
     xf[0] = frag(X);                                  // tap (0,0), K step 0
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
+      // round 6: the next patch's slices (requested at the top of this patch) are parked in LDS UNDER the last three taps'
+      // products instead of behind all of them -- the 11 16-byte stores per thread and their wait no longer sit between the
+      // last product of a patch and its barrier (the compiler schedules freely on either side of the fence)
+      if (t == 6) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (pt + 1 < p_end) park(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int g = t * 8 + ks;
@@ -555,7 +563,6 @@ __global__ __launch_bounds__(256) void halo16_wgrad_kernel(Halo16WgradParams p) 
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[ks], xf[g & 1], acc[t], 0, 0, 0);
       }
     }
-    if (pt + 1 < p_end) park(buf ^ 1);
     __syncthreads();
   }
 
@@ -713,6 +720,15 @@ __global__ __launch_bounds__(512) void halo16s2_wgrad_kernel(Halo16S2WgradParams
     xf[0] = xfrag(X + x_off(0, 0));
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
+      // (round 6: the next patch is parked under the last three taps' products, as above -- in the all-bf16 instantiation; with an
+      //  fp32 side the staging registers beside the fence spill at this kernel's 256-register limit)
+      if constexpr (X16 && D16) {
+        if (t == 5) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (pt + 1 < p_end) park(buf ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int g = t * 4 + ks;
@@ -720,7 +736,9 @@ __global__ __launch_bounds__(512) void halo16s2_wgrad_kernel(Halo16S2WgradParams
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[ks], xf[g & 1], acc[t], 0, 0, 0);
       }
     }
-    if (pt + 1 < p_end) park(buf ^ 1);
+    if constexpr (!(X16 && D16)) {
+      if (pt + 1 < p_end) park(buf ^ 1);
+    }
     __syncthreads();
   }
 

@@ -30,10 +30,13 @@ struct RgbinParams {
   float slope;
 };
 
-template <int KH, int KW, int CI>
+// S (round 6): stride 1 or 2 -- the discriminator's first layer (nn.Conv2d(3, 64, 4, 2, 1), model.py:302) and the encoder's
+// (nn.Conv2d(3, 64, 7, 2, 1), model.py:445) ran on the scalar-gather implicit GEMM at ~1 TB/s of their own OUTPUT (70 us for a
+// result that takes 20 us to write); the same tile with a (S TR + KH - S) x (S TC + KW - S) halo and pixels S entries apart
+template <int KH, int KW, int CI, int S = 1>
 __global__ __launch_bounds__(512) void rgbin_conv_kernel(RgbinParams p) {
   constexpr int TR = 16, TC = 32;
-  constexpr int HR = TR + KH - 1, HC = TC + KW - 1, HW = HC * CI;      // halo rows, columns, floats per halo row
+  constexpr int HR = S * (TR - 1) + KH, HC = S * (TC - 1) + KW, HW = HC * CI;      // halo rows, columns, floats per halo row
   constexpr int KR = (KW * CI + 1) & ~1, KP = KH * KR;                 // K entries per filter row (even), in total
   __shared__ float halo[HR * HW + 8];
   __shared__ float wl[KP * 64];
@@ -48,10 +51,10 @@ __global__ __launch_bounds__(512) void rgbin_conv_kernel(RgbinParams p) {
   for (int e = tid; e < KP * 64; e += 512) wl[e] = p.wp[(size_t)(e >> 6) * p.O + ob * 64 + (e & 63)];
   {
     const float* img = p.x + (size_t)n * p.H * p.W * CI;
-    const int gx0 = (X0 - p.pad) * CI;
+    const int gx0 = (S * X0 - p.pad) * CI;
     for (int e = tid; e < HR * HW + 8; e += 512) {
       const int r = e / HW, j = e - r * HW;
-      const int gy = Y0 - p.pad + r, gx = gx0 + j;
+      const int gy = S * Y0 - p.pad + r, gx = gx0 + j;
       float v = 0.f;
       if (r < HR && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)(p.W * CI)) v = img[(size_t)gy * p.W * CI + gx];
       halo[e] = v;
@@ -67,8 +70,8 @@ __global__ __launch_bounds__(512) void rgbin_conv_kernel(RgbinParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   // A: lane (lr, lh) = pixel column lr, k parity lh;  B: lane = output channel lr, k parity lh
-  const float* a0 = halo + (2 * wave) * HW + lr * CI + lh;
-  const float* a1 = a0 + HW;
+  const float* a0 = halo + (S * 2 * wave) * HW + lr * (S * CI) + lh;
+  const float* a1 = a0 + S * HW;
   const float* bw = wl + lh * 64 + lr;
 #pragma unroll
   for (int ky = 0; ky < KH; ++ky)
@@ -411,7 +414,11 @@ int rgb_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, flo
 bool rgbin_applicable(const srgan_conv_desc* d) {
   static const bool off = SRGAN_AB_SET("SRGAN_NO_RGBIN");
   if (off) return false;
-  return d->I == 3 && d->kh == 7 && d->kw == 7 && d->stride == 1 && d->pad_mode == SRGAN_PAD_ZERO && d->O % 64 == 0 &&
+  const bool k7s1 = d->kh == 7 && d->kw == 7 && d->stride == 1;
+  // round 6: the strided 3-channel layers (D's first conv 4x4 / 2 / pad 1, E's first conv 7x7 / 2 / pad 1)
+  static const bool no_s2 = SRGAN_AB_SET("SRGAN_NO_RGBIN_S2");
+  const bool s2 = !no_s2 && d->stride == 2 && ((d->kh == 4 && d->kw == 4) || (d->kh == 7 && d->kw == 7));
+  return d->I == 3 && (k7s1 || s2) && d->pad_mode == SRGAN_PAD_ZERO && d->O % 64 == 0 &&
          d->Wo >= 32 && d->Ho >= 16 && (long long)d->N * d->Ho * d->Wo * d->O < (1LL << 31);
 }
 
@@ -421,7 +428,7 @@ size_t rgbin_packed_elems(const srgan_conv_desc* d) { return (size_t)d->kh * ((d
 // kernel's allocation of 7 x 22 x O floats)
 static bool rgbin16_mode(const srgan_conv_desc* d) {
   static const bool off = SRGAN_AB_SET("SRGAN_NO_RGBIN16");
-  return !off && compute_bf16() && d->I == 3 && d->kh == 7 && d->kw == 7 && d->pad == 3;
+  return !off && compute_bf16() && d->I == 3 && d->kh == 7 && d->kw == 7 && d->pad == 3 && d->stride == 1;
 }
 
 int rgbin_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st) {
@@ -457,7 +464,9 @@ int rgbin_run(const srgan_conv_desc* d, const float* x, const float* packed, con
     prof_end(tok, st);
     return check_launch("rgbin16_conv_kernel");
   }
-  hipLaunchKernelGGL((rgbin_conv_kernel<7, 7, 3>), dim3((unsigned)grid), dim3(512), 0, st, p);
+  if (d->stride == 2 && d->kh == 4) hipLaunchKernelGGL((rgbin_conv_kernel<4, 4, 3, 2>), dim3((unsigned)grid), dim3(512), 0, st, p);
+  else if (d->stride == 2) hipLaunchKernelGGL((rgbin_conv_kernel<7, 7, 3, 2>), dim3((unsigned)grid), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((rgbin_conv_kernel<7, 7, 3>), dim3((unsigned)grid), dim3(512), 0, st, p);
   prof_end(tok, st);
   return check_launch("rgbin_conv_kernel");
 }

@@ -98,6 +98,10 @@ CONV_CASES = [
     (16, 64, 66, 66, 64, 3, 1, 1, True, False),   # bf16 mode: 545 pixel tiles of igemm16_kernel on <= 512 persistent workgroups (reflect, 64 couts)
     (9, 256, 64, 16, 64, 4, 2, 1, False, False),  # round 5: 256 input channels keep the strided 4x4 / stride-2 form OFF F(4x4,2x2) (1024 reduce terms: 2.07e-5 there); its input gradient (64 reduce channels) takes it
     (4, 128, 32, 48, 192, 4, 2, 1, False, True),  # round 5: F(4x4,2x2) both directions, 3 channel blocks forward, 24 tiles per image (ragged 32-tile blocks), bias
+    (3, 3, 128, 128, 64, 4, 2, 1, False, False),  # round 6: D's first layer at full size on the LDS-halo MFMA kernel, stride 2 (rgbin_conv_kernel<4, 4, 3, 2>)
+    (2, 3, 70, 90, 128, 4, 2, 1, False, True),    # same kernel: ragged 16 x 32 output tiles (35 x 45 map), two channel blocks, bias
+    (3, 3, 128, 128, 64, 7, 2, 1, False, True),   # round 6: E's first layer at full size (7x7 / stride 2 / pad 1 -> 62 x 62), bias (rgbin_conv_kernel<7, 7, 3, 2>)
+    (2, 3, 71, 77, 64, 7, 2, 1, False, False),    # same kernel, odd sizes (33 x 36 map)
     (40, 64, 16, 16, 64, 4, 2, 1, False, False),  # round 5: F(4x4,2x2) transposed form on 160 tiles x 4 phases = 20 items over persistent workgroups
 ]
 
