@@ -28,3 +28,6 @@ dp1() {
 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-micro > $O/c1_fp32_plain.json 2> $O/c1_fp32_plain.err && python3 -c "import json; d=json.loads(open('$O/c1_fp32_plain.json').read().strip().splitlines()[-1]); print('%-12s %8.1f images/s %7.2f ms/step' % ('c1 plain', d['value'], d['ms_per_step']))"
 dp1 dp1_graph env
 dp1 dp1_eager env SRGAN_DP_GRAPH=0
+# round 6: the C-ABI collectives -- ONE graph per step with the collectives captured, and the same transport with segments
+dp1 dp1_abi_single env SRGAN_DP_COMM=abi
+dp1 dp1_abi_segments env SRGAN_DP_COMM=abi SRGAN_DP_SINGLE_GRAPH=0

@@ -54,7 +54,7 @@ def prof_name(n):
         return "halo16s_kernel"
     if "halo16_wgrad_kernel" in n:
         return "halo16_wgrad_kernel"
-    if "halo16_kernel" in n:
+    if "halo16_kernel" in n or "halo16r_kernel" in n:      # (round 6: the 256-channel layers run halo16r_kernel; one profile name)
         return "halo16_kernel"
     return None
 
