@@ -143,6 +143,7 @@ int in_bwd_slab_vz_launch(const float* x, const float* gup, const float* scale, 
 bool wino43_dgrad_applicable(const srgan_conv_desc* d);    // the input gradient of d runs on F(4x4,3x3)
 // conv_wino.hip: Winograd F(2x2,3x3) for 3x3 stride-1 pad-1 layers; kind 0 = forward, 1 = input gradient
 bool wino_applicable(const srgan_conv_desc* d, int kind);
+double wino_threshold_scale();     // test hook SRGAN_WINOGRAD_THRESHOLD_SCALE: scales the minimum-workgroup thresholds of the dispatch
 size_t wino_packed_bytes(const srgan_conv_desc* d, int kind);
 int wino_pack(const srgan_conv_desc* d, int kind, const float* w, float* dst, hipStream_t st);
 size_t wino_scratch_bytes(const srgan_conv_desc* d, int kind);
@@ -170,6 +171,25 @@ bool halo16_wgrad_applicable(const srgan_conv_desc* d);
 void halo16_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad);
 int halo16_wgrad_run(const srgan_conv_desc* d, const void* x, const void* dy, float* slab, double flops, hipStream_t st,
                      bool x16 = false, bool d16 = false);
+
+// conv_halo16e.hip (round 6): the style encoder's 3x3 / stride-1 layers on 62- and 31-pixel maps in the bf16 mode -- LDS-resident
+// halo of a ragged destination patch, filter operand from the packed register image (PackParams::regimg).  Geometry as the
+// implicit GEMM states it (IgemmParams): source map Hs x Ws x Cs, destination map Hd x Wd x N, halo origin = patch origin +
+// (oy0, ox0), `flip`: the filter image holds tap 8 - t at halo tap t (input gradient), `reflect`: mirrored halo coordinates.
+struct Halo16eParams {
+  const void* src;             // [NB][Hs][Ws][Cs] fp32, or bf16 (src16)
+  const unsigned short* wp;    // register image, bf16
+  const float* bias;           // [N] or null
+  void* dst;                   // [NB][Hd][Wd][N] fp32, or bf16 (dst16)
+  int NB, Hs, Ws, Cs, Hd, Wd, N;
+  int oy0, ox0, flip, reflect, act;
+  float slope;
+  int src16, dst16;
+  int tiles_y, tiles_x, n_tiles;       // set by halo16e_run
+};
+bool halo16e_shape_ok(int Cs, int N);
+int halo16e_patch_rows(int Cs, int N);
+int halo16e_run(Halo16eParams p, double flops, hipStream_t st);
 
 // conv_rgbin.hip: 3-channel-input 7x7 stride-1 layers on the MFMA (LDS-staged halo)
 // conv_rgbout.hip: 7x7 / stride-1 / pad-3 layers with <= 4 OUTPUT channels on the 4x4x1 MFMA (direct, LDS-resident halo and filter)

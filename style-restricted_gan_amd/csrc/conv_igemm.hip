@@ -1556,6 +1556,32 @@ static bool igemm16_ok(const IgemmParams& p) {
 }
 static int igemm16_bn(const IgemmParams& p) { return p.Cd <= 64 ? 64 : 128; }
 
+// Round 6: of igemm16's layers, the 3x3 / stride-1 ones on maps large enough to fill the device run on halo16e_kernel
+// (conv_halo16e.hip) -- the style encoder's convolutions on its 62- and 31-pixel maps and their input gradients.  Geometry only
+// (the packed operand is laid out for the kernel that will read it, whatever the tensors' types turn out to be).
+static bool halo16e_ok(const IgemmParams& p) {
+  if (!igemm16_ok(p) || p.stride != 1 || p.Ty != 3 || p.Tx != 3 || p.xpad_off != 0) return false;
+  if (!halo16e_shape_ok(p.Cs, p.Cd) || p.Npad != p.Cd || p.K != 9 * p.Cs) return false;
+  if (p.mode == 0 && p.reflect && (p.pad != 1 || p.Hs < 2 || p.Ws < 2)) return false;
+  if (p.mode == 1 && p.reflect) return false;
+  // enough workgroups for about half a device round (tests: SRGAN_WINOGRAD_THRESHOLD_SCALE=0 drives small shapes through it)
+  const long long wgs = (long long)p.NB * ceil_div(p.Hd, halo16e_patch_rows(p.Cs, p.Cd)) * ceil_div(p.Wd, 32);
+  return wgs >= 120 * wino_threshold_scale() && (long long)p.NB * p.Hd * p.Wd * p.Cd < (1LL << 30);
+}
+
+static int launch_halo16e(const IgemmParams& p, hipStream_t st, double flops) {
+  Halo16eParams q{};
+  q.src = p.src; q.wp = reinterpret_cast<const unsigned short*>(p.wp); q.bias = p.bias; q.dst = p.dst;
+  q.NB = p.NB; q.Hs = p.Hs; q.Ws = p.Ws; q.Cs = p.Cs; q.Hd = p.Hd; q.Wd = p.Wd; q.N = p.Cd;
+  if (p.mode == 0) {            // destination row a reads source rows a - pad + ty
+    q.oy0 = -p.pad; q.ox0 = -p.pad; q.flip = 0;
+  } else {                      // destination row a reads source rows a + pad - ty = (a + pad - 2) + (2 - ty)
+    q.oy0 = p.pad - 2; q.ox0 = p.pad - 2; q.flip = 1;
+  }
+  q.reflect = p.reflect; q.act = p.act; q.slope = p.slope; q.src16 = p.src16; q.dst16 = p.dst16;
+  return halo16e_run(q, flops, st);
+}
+
 static int launch_igemm16(IgemmParams p, int phases, hipStream_t st, double flops) {
   const int bn = igemm16_bn(p);
 #ifdef SRGAN_EXPERIMENTS
@@ -1618,6 +1644,7 @@ static SplitKPlan plan_splitk(const IgemmParams& p, int phases) {
   static const bool off = SRGAN_AB_SET("SRGAN_NO_SPLITK");
   static const int target = SRGAN_AB_INT("SRGAN_SPLITK_TARGET", 768);
   const bool k16 = igemm16_ok(p);
+  if (phases == 1 && halo16e_ok(p)) return s;      // served by halo16e_kernel (its packed operand is the register image)
   const TileChoice tc = k16 ? TileChoice{128, igemm16_bn(p)} : final_tile(p);
   if (off || tc.BM == 256 || (p.Cd & 3) != 0 || s.dst_elems >= (1LL << 28)) return s;
   const long long wgs = ceil_div(p.M, tc.BM) * ceil_div(p.Cd, tc.BN) * phases;
@@ -1663,6 +1690,7 @@ int run_igemm(IgemmParams p, int phases, hipStream_t st, double flops, float* sl
 }
 
 int run_igemm_tiles(IgemmParams p, int phases, hipStream_t st, double flops) {
+  if (phases == 1 && p.ksplit <= 1 && halo16e_ok(p)) return launch_halo16e(p, st, flops);
   if (igemm16_ok(p)) return launch_igemm16(p, phases, st, flops);
   TileChoice tc = choose_tile(p.M, p.Cd);
   p.m_tiles = (int)ceil_div(p.M, tc.BM);
@@ -1971,6 +1999,7 @@ static PackParams fwd_pack_params(const srgan_conv_desc* d, FwdPath path, const 
   q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 0; q.stride = d->stride; q.pad = d->pad;
   q.Ty = d->kh; q.Tx = d->kw; q.Cs = d->I; q.N = d->O; q.K = p.K; q.Kpad = p.Kpad; q.Npad = p.Npad; q.phases = 1;
   q.out16 = (path == PATH_IGEMM && igemm16_ok(p)) ? 1 : 0;
+  q.regimg = (q.out16 && halo16e_ok(p)) ? 1 : 0;
   return q;
 }
 
@@ -2133,6 +2162,7 @@ static PackParams dgrad_pack_params(const srgan_conv_desc* d, const DgradGeom& g
   q.O = d->O; q.I = d->I; q.kh = d->kh; q.kw = d->kw; q.mode = 1; q.stride = d->stride; q.pad = g.p.pad;
   q.Ty = g.p.Ty; q.Tx = g.p.Tx; q.Cs = d->O; q.N = d->I; q.K = g.p.K; q.Kpad = g.p.Kpad; q.Npad = g.p.Npad; q.phases = g.phases;
   q.out16 = (!g.wino && !g.narrow && !g.rgbin && !g.narrow_s2 && igemm16_ok(g.p)) ? 1 : 0;
+  q.regimg = (q.out16 && g.phases == 1 && halo16e_ok(g.p)) ? 1 : 0;
   return q;
 }
 

@@ -790,7 +790,7 @@ static bool wino_disabled() {
 }
 // Dispatch thresholds scale with this factor (default 1; 0 = take every geometrically valid layer).  Read on every call so
 // that the unit tests can drive small shapes through the Winograd kernels and through the default dispatch in one process.
-static double wino_threshold_scale() {
+double wino_threshold_scale() {
   const char* e = std::getenv("SRGAN_WINOGRAD_THRESHOLD_SCALE");
   return e ? std::atof(e) : 1.0;
 }

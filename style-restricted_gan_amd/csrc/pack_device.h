@@ -14,9 +14,20 @@ struct PackParams {
   long long sO, sI, sH, sW;
   int O, I, kh, kw, mode, stride, pad, Ty, Tx, Cs, N, K, Kpad, Npad, phases;
   int out16;           // 1: the operand is written as bf16 (RNE) at the same element index (igemm16_kernel's layers, bf16 mode)
+  int regimg;          // round 6, with out16: the register image of halo16e_kernel instead of [n][k] (3x3 taps, Cs % 64 == 0,
+                       // N % 64 == 0, one phase): element (n, k = tap * Cs + c) -> [K step (c / 64 * 9 + tap) * 4 + c / 16 % 4]
+                       // [64-channel block n / 64][32-channel half][lane = 32 (c / 8 % 2) + n % 32][c % 8]
 };
 
 __device__ __forceinline__ void pack_weights_store(const PackParams& p, long long idx, float v) {
+  if (p.regimg) {
+    const int k = (int)(idx % p.Kpad), n = (int)(idx / p.Kpad);
+    const int t = k / p.Cs, c = k - t * p.Cs;
+    const long long ks = (long long)((c >> 6) * 9 + t) * 4 + ((c >> 4) & 3);
+    const long long e = (((ks * (p.Npad >> 6) + (n >> 6)) * 2 + ((n >> 5) & 1)) * 64 + ((c >> 3) & 1) * 32 + (n & 31)) * 8 + (c & 7);
+    reinterpret_cast<__bf16*>(p.dst)[e] = (__bf16)v;
+    return;
+  }
   if (p.out16) reinterpret_cast<__bf16*>(p.dst)[idx] = (__bf16)v;
   else p.dst[idx] = v;
 }

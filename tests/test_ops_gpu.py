@@ -2,6 +2,7 @@
 restatement of the same op.  Tolerance: 2e-5 relative to the tensor's max magnitude for fp32 kernels
 (exact-fp32 MFMA, different summation order), stated per test."""
 import contextlib
+import os
 
 import numpy as np
 import pytest
@@ -1461,14 +1462,25 @@ def test_discriminator_bf16_activation_storage_vs_fp32_tensors(ops):
 @pytest.mark.parametrize("in16", [False, True])
 @pytest.mark.parametrize("out16", [False, True])
 @pytest.mark.parametrize("shape", [(2, 64, 128, 30, 30, "reflect"), (3, 128, 128, 15, 15, "reflect"), (4, 256, 512, 7, 7, "reflect"),
-                                   (2, 128, 64, 12, 20, "zeros")])
+                                   (2, 128, 64, 12, 20, "zeros"),
+                                   # round 6: the same Functions with the encoder's large-map layers on halo16e_kernel (the
+                                   # dispatch threshold switched off so that these small batches take it): every (Cin, Cout) it
+                                   # is instantiated for, ragged patches in both directions, reflect (input gradient = padded
+                                   # gradient + fold) and zero padding (input gradient straight into the tensor)
+                                   (2, 64, 64, 30, 30, "reflect", "halo"), (2, 64, 128, 62, 62, "reflect", "halo"),
+                                   (3, 128, 128, 31, 31, "reflect", "halo"), (2, 128, 256, 31, 31, "reflect", "halo"),
+                                   (2, 64, 128, 20, 40, "zeros", "halo"), (1, 128, 128, 9, 33, "zeros", "halo"),
+                                   (2, 128, 256, 8, 64, "zeros", "halo"), (1, 64, 64, 33, 5, "reflect", "halo")])
 def test_generic_conv_io_every_dtype_pair(ops, shape, in16, out16):
     """Round 5: the 3x3 stride-1 layers of the style encoder (reflect-padded, 62 / 31 / 15 / 7-pixel maps; model.py:413-437) with
     bf16 tensors on either side in the bf16 mode (igemm16_kernel<IN16, OUT16>, its split-K sum, the reflect fold, wgrad_kernel
     with 16-bit loads): forward + input gradient + weight gradient of every fp32 / bf16 mix against the fp32 convolution of the
     bf16-rounded operands (a bf16 result is compared after the same rounding of the reference).  The 7 x 7 case runs split-K."""
     torch.set_num_threads(16)
-    n, ci, co, h, w, pm = shape
+    n, ci, co, h, w, pm = shape[:6]
+    halo = len(shape) > 6
+    if halo:
+        os.environ["SRGAN_WINOGRAD_THRESHOLD_SCALE"] = "0"
     x = rnd(n, ci, h, w, seed=31)
     wt = rnd(co, ci, 3, 3, seed=32) / np.sqrt(ci * 9)
     gy = rnd(n, co, h, w, seed=33)
@@ -1507,6 +1519,7 @@ def test_generic_conv_io_every_dtype_pair(ops, shape, in16, out16):
                 assert torch.equal(y, y2)
             assert torch.equal(wd.grad, w2.grad)
     finally:
+        os.environ.pop("SRGAN_WINOGRAD_THRESHOLD_SCALE", None)
         ops.set_compute_dtype("fp32")
         ops.invalidate_packed()
 
