@@ -27,8 +27,11 @@ __device__ __forceinline__ auto uniform_rsrc_e(const void* base, unsigned bytes)
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+// <64, 2, 2> (64 -> 128 channels, 49 KB of LDS) is compiled for TWO workgroups per CU (212 registers, no spill): with one
+// 64-channel quarter its 36-step K loop is as short as its halo fill and its result stores, and a second resident workgroup is
+// what runs under them; the other shapes are bound to one by their LDS or accumulators.
 template <int CIN, int WM, int WN, bool IN16, bool OUT16>
-__global__ __launch_bounds__(256) void halo16e_kernel(Halo16eParams p) {
+__global__ __launch_bounds__(256, (CIN == 64 && WM == 2) ? 2 : 1) void halo16e_kernel(Halo16eParams p) {
   static_assert(WM * WN == 4, "four waves");
   constexpr int ISZ = IN16 ? 2 : 4;
   constexpr int PH = 4 * WM;                   // patch rows
@@ -193,24 +196,39 @@ __global__ __launch_bounds__(256) void halo16e_kernel(Halo16eParams p) {
   }
 
   // ---- epilogue: lane = output channel; register e of acc[i][j] = pixel column (e % 4) + 8 (e / 4) + 4 lh of destination row
-  // Y0 + 4 wm + i; stores masked at the map's right / bottom edge ----
+  // Y0 + 4 wm + i; stores masked at the map's right / bottom edge.  A bf16 result: the wave's 64 channels of a pixel are ONE
+  // 128-byte line, so lanes are paired as in igemm16_kernel -- the even lane of a pair stores both lanes' values of channel block
+  // 0 (columns lr, lr + 1), the odd lane those of block 1: 4 bytes per lane, a half-wave writes the whole line, half the store
+  // instructions (with a column per lane every store is a 64-byte partial line) ----
+  const int nb0 = (nt * WN + wn) * 64;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int y = Y0 + 4 * wm + i;
     if (y >= p.Hd) continue;
     const size_t row = ((size_t)(nb * p.Hd + y) * p.Wd) * p.N;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = (nt * WN + wn) * 64 + j * 32 + lr;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+    if constexpr (OUT16) {
+      const int odd = lr & 1;
+      const int n = nb0 + (odd ? 31 + lr : lr);                 // first of this lane's two adjacent columns
+      const float b0 = p.bias ? p.bias[n] : 0.f, b1 = p.bias ? p.bias[n + 1] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int x = X0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (x < p.Wd) {
-          const float v = apply_act(acc[i][j][e] + bv, p.act, p.slope);
-          const size_t o = row + (size_t)x * p.N + n;
-          if constexpr (OUT16) static_cast<__bf16*>(p.dst)[o] = (__bf16)v;
-          else static_cast<float*>(p.dst)[o] = v;
+        const float own = odd ? acc[i][1][e] : acc[i][0][e], give = odd ? acc[i][0][e] : acc[i][1][e];
+        const float got = __shfl_xor(give, 1, 64);
+        const float v0 = apply_act((odd ? got : own) + b0, p.act, p.slope), v1 = apply_act((odd ? own : got) + b1, p.act, p.slope);
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 pk = {(__bf16)v0, (__bf16)v1};
+        if (x < p.Wd) *reinterpret_cast<bf16x2*>(static_cast<__bf16*>(p.dst) + row + (size_t)x * p.N + n) = pk;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = nb0 + j * 32 + lr;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int x = X0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (x < p.Wd) static_cast<float*>(p.dst)[row + (size_t)x * p.N + n] = apply_act(acc[i][j][e] + bv, p.act, p.slope);
         }
       }
     }

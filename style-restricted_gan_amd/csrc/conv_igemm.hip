@@ -1564,6 +1564,9 @@ static bool halo16e_ok(const IgemmParams& p) {
   if (!halo16e_shape_ok(p.Cs, p.Cd) || p.Npad != p.Cd || p.K != 9 * p.Cs) return false;
   if (p.mode == 0 && p.reflect && (p.pad != 1 || p.Hs < 2 || p.Ws < 2)) return false;
   if (p.mode == 1 && p.reflect) return false;
+  // a destination a few pixels wider than a multiple of the 32-column patch wastes most of its last column of patches (the
+  // 33 x 33 padded gradient of a 31 x 31 layer: 73 us against the implicit GEMM's 37): at least 3/4 of the patch columns filled
+  if ((long long)p.Wd * 4 < 3LL * 32 * ceil_div(p.Wd, 32) && wino_threshold_scale() > 0) return false;
   // enough workgroups for about half a device round (tests: SRGAN_WINOGRAD_THRESHOLD_SCALE=0 drives small shapes through it)
   const long long wgs = (long long)p.NB * ceil_div(p.Hd, halo16e_patch_rows(p.Cs, p.Cd)) * ceil_div(p.Wd, 32);
   return wgs >= 120 * wino_threshold_scale() && (long long)p.NB * p.Hd * p.Wd * p.Cd < (1LL << 30);
