@@ -46,6 +46,8 @@ def prof_name(n):
               "in_fwd_slab", "in_bwd_slab"):
         if n.startswith(k):
             return {"in_apply_pow2": "in_apply", "in_bwd_apply_pow2": "in_bwd_apply"}.get(k, k)
+    if "halo16e_kernel" in n:        # (round 6: the encoder's large-map layers in the bf16 mode)
+        return "halo16e_kernel"
     if "halo16t_kernel" in n:
         return "halo16t_kernel"
     if "halo16s2_wgrad_kernel" in n:
