@@ -1237,6 +1237,48 @@ def test_generator_bf16_activation_storage_vs_fp32_tensors(ops, hw):
         assert worst[1] <= 0.215, worst      # 1.3 x the largest measured value (0.1653, down_cnorms.0.ConBias.0.weight)
 
 
+def test_sink_slot_that_aliases_a_live_gradient_accumulates(ops):
+    """under data parallelism the gradient sink hands out a parameter's persistent BUCKET SLICE
+    (`ops._sink_alloc` = `dp.grad_slot`), which is the very tensor an earlier pass bound to `p.grad`.  Two backward passes
+    without `zero_grad` between them (gradient accumulation) must ADD: the first weight-gradient launch of the second pass used
+    to run with accumulate = False over the live gradient, and the scope's exit -- `p.grad is buf` -- skipped the add.  A stand-in
+    allocator plays `dp.grad_slot` here (no process group needed): conv weight + bias, one and two passes."""
+    torch.manual_seed(3)
+    w = (torch.randn(64, 32, 3, 3) / 17).cuda().requires_grad_(True)
+    b = torch.randn(64).cuda().requires_grad_(True)
+    x = torch.randn(4, 32, 20, 20).cuda().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(4, 64, 20, 20).cuda().contiguous(memory_format=torch.channels_last)
+    slots = {}
+
+    def alloc(p):
+        return slots.setdefault(id(p), torch.zeros_like(p))
+
+    def one_pass():
+        y = ops.conv2d(x, w, b, 1, 1)
+        with ops.fused_param_grads():
+            y.backward(gy)
+
+    one_pass()
+    g1w, g1b = w.grad.clone(), b.grad.clone()
+    w.grad = b.grad = None
+    prev = ops._sink_alloc
+    ops._sink_alloc = alloc
+    try:
+        one_pass()
+        assert w.grad.data_ptr() == slots[id(w)].data_ptr()           # the slot IS the gradient now
+        close(w.grad, g1w)
+        one_pass()                                                     # no zero_grad: the slot is live
+        close(w.grad, 2 * g1w)
+        close(b.grad, 2 * g1b)
+        assert w.grad.data_ptr() == slots[id(w)].data_ptr()
+        w.grad = b.grad = None                                         # after zero_grad the slot is overwritten again
+        one_pass()
+        close(w.grad, g1w)
+        close(b.grad, g1b)
+    finally:
+        ops._sink_alloc = prev
+
+
 def test_encoder_bf16_activation_storage_vs_fp32_tensors(ops):
     """Round 5: in the bf16 mode the tensors inside the style encoder's blocks (norm -> conv -> norm -> conv -> pool) live in
     HBM as bf16 (ops.py "16-bit activations around the generic convolutions").  The full-width encoder on 64 x 64 images (30 /
