@@ -15,6 +15,14 @@ for s in range(2):
     x, src, tgt = bench.synthetic_batch(B, 128, 4, seed=s)
     batches.append((x.cuda(), {"source": src.cuda(), "target": tgt}))
 sg.train(*batches[0]); torch.cuda.synchronize()
+_shapes = collections.Counter()
+if os.environ.get("SHAPES"):
+    from srgan_amd import ops as _ops
+    _orig = _ops._conv_desc
+    def _rec(n, hi, wi, i, ho, wo, o, kh, kw, stride, pad, pad_mode, weight):
+        _shapes[(n, hi, wi, i, ho, wo, o, kh, kw, stride, pad)] += 1
+        return _orig(n, hi, wi, i, ho, wo, o, kh, kw, stride, pad, pad_mode, weight)
+    _ops._conv_desc = _rec
 lib.srgan_prof_enable(1)
 sg.train(*batches[1]); torch.cuda.synchronize()
 lib.srgan_prof_enable(0)
@@ -28,3 +36,7 @@ tot = sum(sum(v) for v in agg.values())
 print(f"GEMM launches total {tot:.2f} ms")
 for (name, gf), v in rows[:int(os.environ.get("ROWS", "60"))]:
     print(f"{name:32s} {gf:8.2f} GF x{len(v):3d}  avg {1e3*sum(v)/len(v):8.1f} us  {gf/ (sum(v)/len(v)):7.1f} TF   total {sum(v):6.2f} ms")
+
+for k, c in sorted(_shapes.items(), key=lambda kv: -kv[1]):
+    n, hi, wi, i, ho, wo, o, kh, kw, st, pad = k
+    print(f"desc x{c:3d}  n {n} in {hi}x{wi}x{i} out {ho}x{wo}x{o} k {kh}x{kw} s{st} p{pad}  {2e-9*n*ho*wo*o*kh*kw*i:8.2f} GF")
