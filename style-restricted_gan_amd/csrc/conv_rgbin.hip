@@ -374,6 +374,186 @@ __global__ __launch_bounds__(512) void rgb_wgrad_kernel(RgbWgradParams p) {
   }
 }
 
+// ---- the same weight gradient on the bf16 MFMA (bf16 compute mode; round 6) ----
+// In the bf16 mode the two kernels above were the last exact-fp32 products of the 7x7 RGB layers: 8 launches x 124 us per train
+// step for a GEMM whose bf16 matrix time is a few us -- what bounds it then is reading the 64-channel tensor once (134 MB at
+// batch 32).  Same GEMM (M = 64 channels, N = 154 -> 160 taps, K = pixels), same slab layout, on v_mfma_f32_32x32x16_bf16:
+//   * a workgroup (4 waves) walks a range of 4 x 32 pixel patches; per patch the 64-channel tensor's 128 pixels are read ONCE as
+//     fp32 (8 x 16 bytes per thread, in flight under the previous patch's products), rounded to bf16 (RNE) and parked in LDS as
+//     [pixel][64 channels + pad] (192-byte rows, as halo16_wgrad_kernel); the K index is the pixel, so the A fragment -- 32 channels
+//     of 16 pixels -- is two transposing reads (ds_read_b64_tr_b16);
+//   * the 3-channel tensor's (4 + 6) x (32 + 6) pixel halo is parked as bf16 [row][column][3]; the B fragment of (tap, 16 pixels) is
+//     eight 2-byte reads at  pixel base + tap offset + 3 j  (a lane = a tap, as in the fp32 kernel);
+//   * wave w owns patch row w: 2 K steps x (2 x 5) products per patch, all 2 x 5 output tiles in 160 accumulator registers; at the
+//     end the four partial results meet in LDS and one slab per workgroup goes to the split-K sum of conv_igemm.hip.
+struct RgbWgrad16Params {
+  const float* c64;   // [NB][H][W][64]
+  const float* t3;    // [NB][H][W][3]
+  float* slab;        // [gridDim.x][Cdpad][NNpad]
+  int NB, H, W, tiles_x, tiles_y, patches, per_split;
+};
+
+template <int SWAP>
+__global__ __launch_bounds__(256, 2) void rgb_wgrad16_kernel(RgbWgrad16Params p) {
+  constexpr int KH = 7, KW = 7, CI = 3, PR = 4, PC = 32;
+  constexpr int HR = PR + KH - 1, HC = PC + KW - 1, HWE = HC * CI, HEL = HR * HWE;      // 10 x 38 pixels, 114 entries per row, 1140
+  constexpr int KR = 22, KP = KH * KR;      // 154 taps, padded to 5 x 32
+  constexpr int GPS = 192;                  // bytes per pixel row of the 64-channel bf16 tile
+  constexpr int CT = PR * PC * GPS, HT = (HEL * 2 + 15) & ~15;
+  static_assert(2 * CT + 2 * HT >= 4 * 1024 * 4, "the final reduction reuses the operand buffers");
+  typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * CT + 2 * HT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int li = lane & 15, q4 = li >> 2, pq = li & 3, g1 = (lane >> 4) & 1;
+  const int p_begin = blockIdx.x * p.per_split, p_end = min(p_begin + p.per_split, p.patches);
+
+  const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.c64), 0, (unsigned)((size_t)p.NB * p.H * p.W * 64 * 4), 0x00020000);
+  const auto rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t3), 0, (unsigned)((size_t)p.NB * p.H * p.W * CI * 4), 0x00020000);
+  constexpr unsigned kOutside = 0x80000000u;
+  const int hcg = tid & 7, hpl = tid >> 3;           // 8 channels of one of the 32 pixels of a patch row
+
+  f32x4 cl[PR], ch[PR];
+  float tv[5];
+  auto issue = [&](int patch) __attribute__((always_inline)) {
+    int r = patch;
+    const int tx = r % p.tiles_x; r /= p.tiles_x;
+    const int ty = r % p.tiles_y;
+    const int nb = r / p.tiles_y;
+    const int Y0 = ty * PR, X0 = tx * PC;
+#pragma unroll
+    for (int g = 0; g < PR; ++g) {
+      const unsigned off = (unsigned)((((nb * p.H + Y0 + g) * p.W + X0 + hpl) * 64 + hcg * 8) * 4);
+      cl[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_c, off, 0, 0));
+      ch[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_c, off, 16, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = tid + 256 * i;
+      const int rr = e / HWE, j = e - rr * HWE;
+      const int gy = Y0 - 3 + rr, gx = (X0 - 3) * CI + j;
+      const bool ok = e < HEL && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W * CI;
+      const unsigned off = ok ? (unsigned)(((nb * p.H + gy) * p.W * CI + gx) * 4) : kOutside;
+      tv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_t, off, 0, 0));
+    }
+  };
+  auto park = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < PR; ++g) {
+      const bf16x4 a = __builtin_convertvector(cl[g], bf16x4), b = __builtin_convertvector(ch[g], bf16x4);
+      bf16x8 v;
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+      *reinterpret_cast<bf16x8*>(&smem[buf * CT + (g * PC + hpl) * GPS + hcg * 16]) = v;
+    }
+    __bf16* h = reinterpret_cast<__bf16*>(&smem[2 * CT + buf * HT]);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = tid + 256 * i;
+      if (e < HEL) h[e] = (__bf16)tv[i];
+    }
+  };
+
+  // B role: lane = tap 32 nt + lr, pixels 8 lh .. 8 lh + 7 of the K step
+  int tapoff[5];
+#pragma unroll
+  for (int nt = 0; nt < 5; ++nt) {
+    const int k = nt * 32 + lr;
+    const int ky = k / KR, j = k - ky * KR;
+    tapoff[nt] = ((k < KP && j < KW * CI) ? ky * HWE + j : 0) + lh * 8 * CI;     // pad taps read a valid slot, their column is dropped
+  }
+  // A role: transposing read of pixels 8 lh + q4 (+ 4), channels 16 g1 + 4 pq .. + 3 of a 32-channel half
+  const int a_lane = (wave * PC + 8 * lh + q4) * GPS + (16 * g1 + 4 * pq) * 2;
+
+  f32x16 acc[2][5];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (p_begin < p_end) {
+    issue(p_begin);
+    park(0);
+    __syncthreads();
+  }
+  for (int pt = p_begin; pt < p_end; ++pt) {
+    const int buf = (pt - p_begin) & 1;
+    if (pt + 1 < p_end) issue(pt + 1);
+    const unsigned char* A = smem + buf * CT + a_lane;
+    const unsigned short* hb = reinterpret_cast<const unsigned short*>(smem + 2 * CT + buf * HT) + wave * HWE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const unsigned char* a = A + (16 * s) * GPS + it * 64;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(a));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(a + 4 * GPS));
+        af[it] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt) {
+        const unsigned short* b = hb + 16 * s * CI + tapoff[nt];
+        unsigned w4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w4[j] = (unsigned)b[(2 * j) * CI] | ((unsigned)b[(2 * j + 1) * CI] << 16);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 wv;
+        wv[0] = w4[0]; wv[1] = w4[1]; wv[2] = w4[2]; wv[3] = w4[3];
+        const bf16x8 bf = __builtin_bit_cast(bf16x8, wv);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) acc[it][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[it], bf, acc[it][nt], 0, 0, 0);
+      }
+    }
+    if (pt + 1 < p_end) park(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- the four partial results meet in LDS, one 32 x 32 output tile at a time ----
+  float* red = reinterpret_cast<float*>(smem);
+  float* slab = p.slab + (size_t)blockIdx.x * (SWAP ? 4 * (KH * KW * 64) : 64 * (KH * KW * CI));
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+      __syncthreads();
+      // D[i = channel][j = tap]: lane = tap lr, register e = channel 8 * (e / 4) + 4 * lh + e % 4
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[wave * 1024 + (8 * (e >> 2) + 4 * lh + (e & 3)) * 32 + lr] = acc[it][nt][e];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int el = tid + 256 * q;                // element (channel, tap) of the 32 x 32 tile
+        const float v = (red[el] + red[1024 + el]) + (red[2048 + el] + red[3072 + el]);
+        const int chn = it * 32 + (el >> 5), k = nt * 32 + (el & 31);
+        const int ky = k / KR, j = k - ky * KR;
+        if (k < KP && j < KW * CI) {
+          const int kx = j / CI, c = j - kx * CI;
+          if (SWAP) slab[(size_t)c * (KH * KW * 64) + ((KH - 1 - ky) * KW + (KW - 1 - kx)) * 64 + chn] = v;
+          else slab[(size_t)chn * (KH * KW * CI) + (ky * KW + kx) * CI + c] = v;
+        }
+      }
+    }
+  if (SWAP) {      // the slab has 4 channel rows (Cdpad of the reduce): row 3 is never written above
+    for (int e = tid; e < KH * KW * 64; e += 256) slab[(size_t)3 * (KH * KW * 64) + e] = 0.f;
+  }
+}
+
+// bf16 mode: patches of 4 x 32 pixels in at most 256 contiguous ranges (one workgroup per CU; measured on the step: 256 ranges
+// 965.0, 512 962.9, 1024 960.2 images/s, fp32 kernels 947.7 -- more ranges only add slab traffic)
+static bool rgb_wgrad16_on() {
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_RGB_WGRAD16");
+  return !off && compute_bf16();
+}
+static void rgb_wgrad16_plan(const srgan_conv_desc* d, int* patches, int* per_split, int* splits) {
+  static const int max_splits = (int)SRGAN_AB_INT("SRGAN_RGB_WGRAD16_SPLITS", 256);
+  *patches = d->N * (d->Hi / 4) * (d->Wi / 32);
+  *per_split = (int)ceil_div(*patches, std::min(*patches, max_splits));
+  *splits = (int)ceil_div(*patches, *per_split);
+}
+
 // kind 0: RGB input layer (I == 3, O == 64); kind 1: RGB output layer (I == 64, O == 3)
 int rgb_wgrad_kind(const srgan_conv_desc* d) {
   static const bool off = SRGAN_AB_SET("SRGAN_NO_RGBIN");
@@ -391,6 +571,10 @@ int rgb_wgrad_kind(const srgan_conv_desc* d) {
 void rgb_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad) {
   const long long tiles = (long long)d->N * (d->Hi / 16) * (d->Wi / 32);
   *splits = (int)std::min<long long>(tiles, 256);
+  if (rgb_wgrad16_on()) {
+    int patches, per;
+    rgb_wgrad16_plan(d, &patches, &per, splits);
+  }
   *Cdpad = rgb_wgrad_kind(d) == 1 ? 4 : 64;
   *NNpad = d->kh * d->kw * d->I;
 }
@@ -405,7 +589,16 @@ int rgb_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, flo
   int splits, cd, nn;
   rgb_wgrad_slab(d, &splits, &cd, &nn);
   ProfToken tok = prof_begin(21, 2.0 * d->N * d->Ho * d->Wo * (double)d->O * d->kh * d->kw * d->I, st);
-  if (kind == 0) hipLaunchKernelGGL(rgb_wgrad_kernel<0>, dim3((unsigned)splits), dim3(512), 0, st, p);
+  if (rgb_wgrad16_on()) {
+    RgbWgrad16Params q{};
+    q.c64 = p.c64; q.t3 = p.t3; q.slab = slab;
+    q.NB = d->N; q.H = d->Hi; q.W = d->Wi; q.tiles_x = d->Wi / 32; q.tiles_y = d->Hi / 4;
+    int s16 = 0;
+    rgb_wgrad16_plan(d, &q.patches, &q.per_split, &s16);
+    SRGAN_REQUIRE(s16 == splits, "rgb weight gradient: split plan changed between sizing and launch");
+    if (kind == 0) hipLaunchKernelGGL(rgb_wgrad16_kernel<0>, dim3((unsigned)splits), dim3(256), 0, st, q);
+    else hipLaunchKernelGGL(rgb_wgrad16_kernel<1>, dim3((unsigned)splits), dim3(256), 0, st, q);
+  } else if (kind == 0) hipLaunchKernelGGL(rgb_wgrad_kernel<0>, dim3((unsigned)splits), dim3(512), 0, st, p);
   else hipLaunchKernelGGL(rgb_wgrad_kernel<1>, dim3((unsigned)splits), dim3(512), 0, st, p);
   prof_end(tok, st);
   return check_launch("rgb_wgrad_kernel");

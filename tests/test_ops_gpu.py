@@ -1587,20 +1587,28 @@ def test_avgpool2_io_every_dtype_pair(ops, in16, out16):
     assert torch.equal(xd.grad.float().cpu(), ref_g)
 
 
-def test_rgb_input_form_bf16_compute_mode(ops):
+@pytest.mark.parametrize("n,hh,ww", [(2, 32, 64), (5, 64, 416)])
+def test_rgb_input_form_bf16_compute_mode(ops, n, hh, ww):
     """Round 4: in the bf16 mode the 3 -> 64 channel 7x7 form -- the generator's RGB input layer forward and the input gradient
     of its RGB output layer -- runs on rgbin16_conv_kernel (bf16 MFMA, halo with 4 channels per pixel) and the 64 -> 3 head's
-    forward on rgbout16_conv_kernel: equal to the fp32 convolution of the bf16-ROUNDED operands; the weight gradients of both
-    layers stay on the exact-fp32 kernels."""
+    forward on rgbout16_conv_kernel: equal to the fp32 convolution of the bf16-ROUNDED operands.  Round 6: so do the weight
+    gradients of both layers (rgb_wgrad16_kernel: dy * x with both rounded to bf16, fp32 accumulation; they were the last
+    exact-fp32 products of these layers in this mode).  The second shape has 1040 patches of 4 x 32 pixels in 347 ranges of
+    3 (the last one 2): the double-buffered patch loop and a ragged last range."""
     torch.set_num_threads(16)
-    x = rnd(2, 3, 32, 64, seed=11)
+    x = rnd(n, 3, hh, ww, seed=11)
     w_in = rnd(64, 3, 7, 7, seed=12) / np.sqrt(147)
-    h = rnd(2, 64, 32, 64, seed=13)
+    h = rnd(n, 64, hh, ww, seed=13)
     w_out = rnd(3, 64, 7, 7, seed=14) / np.sqrt(3136)
-    gy_in, gy_out = rnd(2, 64, 32, 64, seed=15), rnd(2, 3, 32, 64, seed=16)
+    gy_in, gy_out = rnd(n, 64, hh, ww, seed=15), rnd(n, 3, hh, ww, seed=16)
     y_ref = F.conv2d(_bf16_round(x), _bf16_round(w_in), None, 1, 3)
     hr = h.clone().requires_grad_(True)
     F.conv2d(hr, _bf16_round(w_out), None, 1, 3).backward(_bf16_round(gy_out))
+    # weight gradients: dW = wgrad(bf16(x), bf16(dy))
+    wr = w_in.clone().requires_grad_(True)
+    F.conv2d(_bf16_round(x), wr, None, 1, 3).backward(_bf16_round(gy_in))
+    wor = w_out.clone().requires_grad_(True)
+    F.conv2d(_bf16_round(h), wor, None, 1, 3).backward(_bf16_round(gy_out))
     ops.set_compute_dtype("bf16")
     try:
         for cached in (False, True):
@@ -1614,13 +1622,8 @@ def test_rgb_input_form_bf16_compute_mode(ops):
                 yo.backward(gy_out.cuda())
             close(y, y_ref)
             close(hd.grad, hr.grad)
-            # exact-fp32 parts
-            wr = w_in.clone().requires_grad_(True)
-            F.conv2d(x, wr, None, 1, 3).backward(gy_in)
             close(wd.grad, wr.grad)
             close(yo, F.conv2d(_bf16_round(h), _bf16_round(w_out), None, 1, 3))      # rgbout16_conv_kernel
-            wor = w_out.clone().requires_grad_(True)
-            F.conv2d(h, wor, None, 1, 3).backward(gy_out)
             close(wo.grad, wor.grad)
     finally:
         ops.set_compute_dtype("fp32")
