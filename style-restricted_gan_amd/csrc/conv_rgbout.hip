@@ -241,143 +241,149 @@ __global__ __launch_bounds__(512) void rgbout_conv_kernel(RgboutParams p) {
   }
 }
 
-// ---- bf16 compute mode (round 4): the 64 -> 3 channel head on v_mfma_f32_32x32x16_bf16 ----
-// In the bf16 mode this layer used to stay on the fp32 kernel above (148 us per launch at batch 32, 1.5 ms per step).  With bf16
-// products the 4-wide instruction is not needed: D[32 pixels][32 columns] with 3 live columns wastes 90 % of a matrix instruction
-// that is 16x cheaper -- 196 K steps (49 taps x 4 chunks of 16 channels) x 32 cycles per 32 pixels, ~45 us of matrix time per
-// launch.  Workgroup = 8 rows x 32 pixels (one row per wave), the (8 + 6) x (32 + 6) pixel halo parked ONCE as bf16
-// [pixel][64 channels + 8 pad] (77 KB: the A fragment of (tap, chunk) is one conflict-free ds_read_b128), the packed filter
-// [K step][3 couts][16] (19 KB) beside it.  The B fragment is read by the three live lanes of each half-wave only.  Bound by the
-// halo read: fp32 input, every pixel fetched 2.1 times (4-row tiles with two workgroups per CU fetched it 3 times: 119 us
-// against this tile's; with everything but the halo load removed the launch took as long).
-constexpr int RO16_TR = 8, RO16_TC = 32, RO16_HR = RO16_TR + 6, RO16_HC = RO16_TC + 6, RO16_PS = 64 * 2 + 16;
-constexpr int RO16_KSTEPS = 49 * 4;
+// ---- bf16 compute mode: the 64 -> 3 channel head on v_mfma_f32_32x32x16_bf16 ----
+// Round 4 put this layer on the bf16 instruction as D[32 pixels][3 live of 32 columns], one 8 x 32 tile per workgroup with its
+// (8 + 6) x (32 + 6) halo parked once: 196 K steps per 32 pixels (~45 us of matrix time per launch at batch 32) BEHIND a halo read
+// that fetched every fp32 pixel 2.1 times in one exposed round trip per tile (109 us per launch, 1.08 ms per train step).
+// Round 6, two changes:
+//   * the filter ROW is a column index: D[32 pixels of halo row g][(cout, ky)] = sum over (kx, c) halo[g][x + kx][c] w[cout][c][ky][kx]
+//     -- 21 live columns, K = 7 x 64 = 28 steps instead of 196 -- and the output row y is the sum of seven such partial rows,
+//     out[y][x][o] = sum_ky D[g = y + ky - 3][x][(o, ky)], taken from a 16-row ring in LDS in fixed order (deterministic);
+//   * a workgroup walks DOWN a 32-column strip in blocks of 8 halo rows (one row per wave): every halo row is fetched once per strip
+//     (vertical over-fetch 6 rows per strip instead of 6 per 8), and block b + 1 is in flight (10 x 16 bytes per thread) under the
+//     products of block b.  The 28 B fragments (the whole filter) stay in registers for the life of the workgroup.
+constexpr int RO16_TC = 32, RO16_BR = 8, RO16_HC = RO16_TC + 6, RO16_PS = 64 * 2 + 16;
+constexpr int RO16_KSTEPS = 7 * 4;          // (kx, 16-channel chunk)
+constexpr int RO16_PLD = 25;                // floats per pixel of a partial row (21 live columns; odd: conflict-free both ways)
 
 struct Rgbout16Params {
   const float* x;            // [NB][H][W][64]
-  const unsigned short* wp;  // [196 K steps][3][16] bf16
+  const unsigned short* wp;  // [28 K steps][32 columns (cout * 7 + ky; zero from 21)][16] bf16
   const float* bias;         // [O] or null
   float* y;                  // [NB][H][W][O]
-  int NB, H, W, O, tiles_x, tiles_y;
+  int NB, H, W, O, strips_x, vsplit, rows_per;
   int exp;
 };
 
 __global__ __launch_bounds__(512) void rgbout16_conv_kernel(Rgbout16Params p) {
-  __shared__ __attribute__((aligned(16))) unsigned char halo[RO16_HR * RO16_HC * RO16_PS];
-  __shared__ __attribute__((aligned(16))) unsigned char wl[RO16_KSTEPS * 3 * 32];
+  __shared__ __attribute__((aligned(16))) unsigned char halo[RO16_BR * RO16_HC * RO16_PS];
+  __shared__ float ring[16 * RO16_TC * RO16_PLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   int b = blockIdx.x;
-  const int nblk = gridDim.x;
-  if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);      // neighbouring tiles (shared halo rows / columns) on one XCD
-  const int tx = b % p.tiles_x; b /= p.tiles_x;
-  const int ty = b % p.tiles_y;
-  const int n = b / p.tiles_y;
-  const int X0 = tx * RO16_TC, Y0 = ty * RO16_TR;
+  const int vs = b % p.vsplit; b /= p.vsplit;
+  const int tx = b % p.strips_x;
+  const int n = b / p.strips_x;
+  const int X0 = tx * RO16_TC, Ys = vs * p.rows_per, Ye = min(Ys + p.rows_per, p.H);
+  const int n_it = (Ye - Ys + 6 + RO16_BR - 1) / RO16_BR;
 
+  // the filter: B fragment of K step ks = column lr, k = 8 lh .. 8 lh + 7
+  bf16x8 fb[RO16_KSTEPS];
   {
-    // ONE round trip to memory for the whole prologue: every load of the filter copy and of the halo is issued before the first
-    // LDS store (copy loops of the form "load, store, load, store" cost a memory latency per iteration: five of them in the
-    // first version of this prologue, ~10 us per workgroup with one workgroup per CU).
-    // Halo: thread = (pixel of the pass, 16-byte piece of its 256-byte channel row): a wave instruction covers 4 pixels x 256
-    // contiguous bytes.  UNCONDITIONAL loads: an out-of-image pixel reads the image's first pixel (in bounds) and is zeroed when
-    // it is parked (a load under a branch, merged with a zero, made the compiler wait for every load in turn).
-    constexpr int NPX = RO16_HR * RO16_HC, PPP = 512 / 16, NPASS = (NPX + PPP - 1) / PPP;
-    constexpr int NW = (RO16_KSTEPS * 3 * 2 + 511) / 512;
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wp);
-    f32x4 wv[NW];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) wv[i] = wsrc[min(tid + 512 * i, RO16_KSTEPS * 3 * 2 - 1)];
-    const int piece = tid & 15, hpl = tid >> 4;
-    const float* img = p.x + (size_t)n * p.H * p.W * 64 + piece * 4;
-    f32x4 v[NPASS];
-    bool okv[NPASS];
+    for (int ks = 0; ks < RO16_KSTEPS; ++ks) fb[ks] = __builtin_bit_cast(bf16x8, wsrc[(ks * 32 + lr) * 2 + lh]);
+  }
+
+  // Halo block: thread = (pixel of the pass, 16-byte piece of its 256-byte channel row): a wave instruction covers 4 pixels x 256
+  // contiguous bytes.  UNCONDITIONAL loads: an out-of-image pixel reads the image's first pixel (in bounds) and is zeroed when it
+  // is parked (a load under a branch, merged with a zero, made the compiler wait for every load in turn: round 4).
+  constexpr int NPX = RO16_BR * RO16_HC, PPP = 512 / 16, NPASS = (NPX + PPP - 1) / PPP;
+  const int piece = tid & 15, hpl = tid >> 4;
+  const float* img = p.x + (size_t)n * p.H * p.W * 64 + piece * 4;
+  f32x4 v[NPASS];
+  unsigned okm = 0;
+  auto issue = [&](int G0) __attribute__((always_inline)) {
+    okm = 0;
 #pragma unroll
     for (int g = 0; g < NPASS; ++g) {
       const int hp = g * PPP + hpl;
       const int hr = hp / RO16_HC, hc = hp - hr * RO16_HC;
-      const int gy = Y0 - 3 + hr, gx = X0 - 3 + hc;
-      okv[g] = hp < NPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      v[g] = *reinterpret_cast<const f32x4*>(img + (okv[g] ? ((size_t)gy * p.W + gx) * 64 : 0));
+      const int gy = G0 + hr, gx = X0 - 3 + hc;
+      const bool ok = hp < NPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      okm |= ok ? (1u << g) : 0u;
+      v[g] = *reinterpret_cast<const f32x4*>(img + (ok ? ((size_t)gy * p.W + gx) * 64 : 0));
     }
-    f32x4* wdst = reinterpret_cast<f32x4*>(wl);
-#pragma unroll
-    for (int i = 0; i < NW; ++i)
-      if (tid + 512 * i < RO16_KSTEPS * 3 * 2) wdst[tid + 512 * i] = wv[i];
+  };
+  auto park = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < NPASS; ++g) {
       const int hp = g * PPP + hpl;
       if (hp < NPX) {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<bf16x4*>(&halo[hp * RO16_PS + piece * 8]) = __builtin_convertvector(okv[g] ? v[g] : z4, bf16x4);
+        *reinterpret_cast<bf16x4*>(&halo[hp * RO16_PS + piece * 8]) = __builtin_convertvector(((okm >> g) & 1u) ? v[g] : z4, bf16x4);
       }
     }
-  }
-  __syncthreads();
-
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  // A: lane (lr, lh) = pixel column lr of row `wave`, k = 8 lh .. 8 lh + 7 of the step's 16 channels; B: lane = cout lr (< 3 live)
-  const unsigned char* a_lane = halo + (wave * RO16_HC + lr) * RO16_PS + lh * 16;
-  const unsigned char* b_lane = wl + (lr < 3 ? lr : 0) * 32 + lh * 16;
-  const bool live = lr < 3;
-  bf16x8 zero8;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) zero8[e] = (__bf16)0.f;
-  // 49 taps x 4 chunks; the fragments of tap t + 1 are requested before the products of tap t (one wave per SIMD and workgroup:
-  // without the prefetch every tap waited out the LDS latency: 217 us per launch instead of the fp32 kernel's 168)
-  bf16x8 fa[2][4], fb[2][4];
-  auto fetch = [&](int slot, int tap) __attribute__((always_inline)) {
-    const int ky = tap / 7, kx = tap - 7 * ky;
-    const unsigned char* a = a_lane + (ky * RO16_HC + kx) * RO16_PS;
-    const unsigned char* bq = b_lane + tap * 4 * 96;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#ifdef SRGAN_EXPERIMENTS
-      if (!(p.exp & 1) || tap == 0) fa[slot][q] = *reinterpret_cast<const bf16x8*>(a + q * 32);
-      if (!(p.exp & 2) || tap == 0) fb[slot][q] = live ? *reinterpret_cast<const bf16x8*>(bq + q * 96) : zero8;
-#else
-      fa[slot][q] = *reinterpret_cast<const bf16x8*>(a + q * 32);
-      fb[slot][q] = live ? *reinterpret_cast<const bf16x8*>(bq + q * 96) : zero8;
-#endif
-    }
   };
-  fetch(0, 0);
-#pragma unroll
-  for (int tap = 0; tap < 49; ++tap) {
-    if (tap + 1 < 49) fetch((tap + 1) & 1, tap + 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#ifdef SRGAN_EXPERIMENTS
-      if (p.exp & 4) continue;
-#endif
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][q], fb[tap & 1][q], acc, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
 
-  // D[pixel][cout]: lane = cout lr (3 live), register e = pixel column (e % 4) + 8 (e / 4) + 4 lh of row Y0 + wave
-  const int oy = Y0 + wave;
-  if (live && lr < p.O && oy < p.H) {
-    const float bv = p.bias ? p.bias[lr] : 0.f;
-    float* row = p.y + (((size_t)n * p.H + oy) * p.W) * p.O + lr;
+  // A: lane (lr, lh) = pixel column lr of the wave's halo row, k = 8 lh .. 8 lh + 7 of the step's 16 channels
+  const unsigned char* a_lane = halo + (wave * RO16_HC + lr) * RO16_PS + lh * 16;
+  const float bv0 = (p.bias && lh < p.O) ? p.bias[lh] : 0.f, bv2 = (p.bias && 2 < p.O) ? p.bias[2] : 0.f;
+
+  issue(Ys - 3);
+  for (int it = 0; it < n_it; ++it) {
+    const int G0 = Ys - 3 + RO16_BR * it;
+    park();
+    __syncthreads();                       // the block is in LDS; every wave is done with the ring rows of the previous block
+    if (it + 1 < n_it) issue(G0 + RO16_BR);
+
+    f32x16 acc;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int ox = X0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      if (ox < p.W) row[(size_t)ox * p.O] = acc[e] + bv;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    bf16x8 fa[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fa[0][q] = *reinterpret_cast<const bf16x8*>(a_lane + q * 32);
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      if (kx + 1 < 7) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fa[(kx + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(a_lane + (kx + 1) * RO16_PS + q * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#ifdef SRGAN_EXPERIMENTS
+        if (p.exp & 4) continue;
+#endif
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kx & 1][q], fb[kx * 4 + q], acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // D[pixel][column]: lane = column lr (21 live), register e = pixel (e % 4) + 8 (e / 4) + 4 lh of halo row G0 + wave
+    if (lr < 21) {
+      float* pr = ring + (((G0 + wave) & 15) * RO16_TC) * RO16_PLD + lr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) pr[((e & 3) + 8 * (e >> 2) + 4 * lh) * RO16_PLD] = acc[e];
+    }
+    __syncthreads();                       // the partial rows are in the ring; everyone is done with the halo block
+
+    // output row y = G0 - 3 + wave: its seven partial rows g = y - 3 .. y + 3 are all in the ring (g <= G0 + 7)
+    const int y = G0 - 3 + wave;
+    if (y >= Ys && y < Ye) {
+      float s01 = bv0, s2 = bv2;           // lane (x = lr, lh): cout lh, and cout 2 on the lh == 0 half
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const float* pr = ring + (((y + ky - 3) & 15) * RO16_TC + lr) * RO16_PLD;
+        s01 += pr[lh * 7 + ky];
+        s2 += pr[14 + ky];
+      }
+      const int ox = X0 + lr;
+      if (ox < p.W) {
+        float* dst = p.y + (((size_t)n * p.H + y) * p.W + ox) * p.O;
+        if (lh < p.O) dst[lh] = s01;
+        if (lh == 0 && 2 < p.O) dst[2] = s2;
+      }
     }
   }
 }
 
-// bf16 packed filter [K step = (ky * 7 + kx) * 4 + chunk][3 couts][16] = w[cout][16 chunk + k][ky][kx] (zero for cout >= O)
+// bf16 packed filter [K step = kx * 4 + chunk][column = cout * 7 + ky (zero from 21 / for cout >= O)][16] = w[cout][16 chunk + k][ky][kx]
 __global__ void rgbout16_pack_kernel(const float* w, unsigned short* dst, long long sO, long long sI, long long sH, long long sW, int O) {
-  const int total = RO16_KSTEPS * 3 * 16;
+  const int total = RO16_KSTEPS * 32 * 16;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int k = idx & 15, co = (idx >> 4) % 3, step = idx / 48;
-    const int q = step & 3, tap = step >> 2, ky = tap / 7, kx = tap - 7 * ky;
-    const float v = co < O ? w[co * sO + (q * 16 + k) * sI + ky * sH + kx * sW] : 0.f;
+    const int k = idx & 15, col = (idx >> 4) & 31, step = idx >> 9;
+    const int q = step & 3, kx = step >> 2, co = col / 7, ky = col - 7 * co;
+    const float v = (col < 21 && co < O) ? w[co * sO + (q * 16 + k) * sI + ky * sH + kx * sW] : 0.f;
     reinterpret_cast<__bf16*>(dst)[idx] = (__bf16)v;
   }
 }
@@ -407,7 +413,7 @@ bool rgbout_applicable(const srgan_conv_desc* d) {
 
 size_t rgbout_packed_elems(const srgan_conv_desc* d) { return (size_t)RO_K * (d->I / 4) * RO_K * 16; }
 
-// bf16 mode: the 64 -> (<= 3) channel head on rgbout16_conv_kernel (its 19 KB packed filter fits the fp32 kernel's 50 KB allocation)
+// bf16 mode: the 64 -> (<= 3) channel head on rgbout16_conv_kernel (its 28 KB packed filter fits the fp32 kernel's 50 KB allocation)
 static bool rgbout16_mode(const srgan_conv_desc* d) {
   static const bool off = SRGAN_AB_SET("SRGAN_NO_RGBOUT16");
   return !off && compute_bf16() && d->I == 64 && d->O <= 3;
@@ -415,7 +421,7 @@ static bool rgbout16_mode(const srgan_conv_desc* d) {
 
 int rgbout_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st) {
   if (rgbout16_mode(d)) {
-    hipLaunchKernelGGL(rgbout16_pack_kernel, dim3(37), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(dst), d->sO, d->sI, d->sH,
+    hipLaunchKernelGGL(rgbout16_pack_kernel, dim3(56), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(dst), d->sO, d->sI, d->sH,
                        d->sW, d->O);
     return check_launch("rgbout16_pack_kernel");
   }
@@ -438,9 +444,14 @@ int rgbout_run(const srgan_conv_desc* d, const float* x, const float* packed, co
     Rgbout16Params q{};
     q.x = x; q.wp = reinterpret_cast<const unsigned short*>(packed); q.bias = bias; q.y = y;
     q.NB = d->N; q.H = d->Hi; q.W = d->Wi; q.O = d->O;
-    q.tiles_x = (int)ceil_div(d->Wo, RO16_TC); q.tiles_y = (int)ceil_div(d->Ho, RO16_TR);
+    q.strips_x = (int)ceil_div(d->Wo, RO16_TC);
+    // strips are cut across until the grid covers the chip (>= 256 workgroups) or a piece would fall under 16 rows
+    q.vsplit = 1;
+    while ((long long)d->N * q.strips_x * q.vsplit < 256 && ceil_div(d->Hi, q.vsplit * 2) >= 16) q.vsplit *= 2;
+    q.rows_per = (int)ceil_div(d->Hi, q.vsplit);
+    q.vsplit = (int)ceil_div(d->Hi, q.rows_per);
     q.exp = (int)SRGAN_AB_INT("SRGAN_RGBOUT16_EXP", 0);
-    hipLaunchKernelGGL(rgbout16_conv_kernel, dim3((unsigned)(q.tiles_x * q.tiles_y * d->N)), dim3(512), 0, st, q);
+    hipLaunchKernelGGL(rgbout16_conv_kernel, dim3((unsigned)(q.strips_x * q.vsplit * d->N)), dim3(512), 0, st, q);
     prof_end(tok, st);
     return check_launch("rgbout16_conv_kernel");
   }
