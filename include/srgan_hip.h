@@ -268,6 +268,10 @@ int srgan_igemm16_wgrad(const srgan_conv_desc* d, const void* x, const void* dy,
  * -> LeakyReLU(0.01), no norm between the layers) with bf16 tensors on either side: forward with the bias / activation epilogue
  * (halo16s_kernel, or igemm16_kernel with LDS-DMA tiles), input gradient (halo16t_kernel or igemm16_kernel); the weight gradient is
  * srgan_halo16_wgrad.  `packed`: the ordinary packed operand of (d, kind, act).  ws: srgan_conv2d_packed_scratch(d, kind) bytes. */
+/* Also (act = none): the generator's 7x7 / stride-1 / pad-3 layers between a 3-channel and a 64-channel tensor (pyfiles/model.py:212,
+ * 232) with the 64-CHANNEL side in bf16 -- the RGB input layer writes a bf16 y and takes a bf16 dy, the RGB output layer reads a
+ * bf16 x and writes a bf16 dx; the 3-channel side is fp32 (a bf16 flag there is refused).  Their weight gradient is
+ * srgan_halo16_wgrad too (bf16 allowed on the 64-channel tensor only). */
 int srgan_conv2d_io_applicable(const srgan_conv_desc* d, int act);
 int srgan_conv2d_io_fwd(const srgan_conv_desc* d, const void* x, int x_bf16, const void* packed, const float* bias, void* y, int y_bf16,
                         int act, float slope, void* ws, size_t ws_bytes, void* stream);

@@ -196,14 +196,20 @@ int halo16e_run(Halo16eParams p, double flops, hipStream_t st);
 bool rgbout_applicable(const srgan_conv_desc* d);
 size_t rgbout_packed_elems(const srgan_conv_desc* d);
 int rgbout_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st);
-int rgbout_run(const srgan_conv_desc* d, const float* x, const float* packed, const float* bias, float* y, hipStream_t st);
+// src16 (bf16 mode, rgbout16_served layers): x is a bf16 tensor
+int rgbout_run(const srgan_conv_desc* d, const void* x, const float* packed, const float* bias, float* y, hipStream_t st, bool src16 = false);
+bool rgbout16_served(const srgan_conv_desc* d);
 bool rgbin_applicable(const srgan_conv_desc* d);
 size_t rgbin_packed_elems(const srgan_conv_desc* d);
 int rgbin_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t st);
-int rgbin_run(const srgan_conv_desc* d, const float* x, const float* packed, const float* bias, float* y, int act, float slope, hipStream_t st);
+// dst16 (bf16 mode, rgbin16_served layers): y is written as bf16
+int rgbin_run(const srgan_conv_desc* d, const float* x, const float* packed, const float* bias, float* y, int act, float slope, hipStream_t st,
+              bool dst16 = false);
+bool rgbin16_served(const srgan_conv_desc* d);
 int rgb_wgrad_kind(const srgan_conv_desc* d);      // -1: not applicable
 void rgb_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpad);
-int rgb_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, hipStream_t st);
+int rgb_wgrad_run(const srgan_conv_desc* d, const void* x, const void* dy, float* slab, hipStream_t st, bool c64_bf16 = false);
+bool rgb_wgrad16_served(const srgan_conv_desc* d);      // bf16 mode: the bf16-MFMA kernel runs (and takes a bf16 64-channel tensor)
 
 // conv_narrow.hip: direct kernels for Cout <= 4, stride-1, zero-pad layers
 bool narrow_applicable(const srgan_conv_desc* d);

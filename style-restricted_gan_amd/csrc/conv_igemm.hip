@@ -2581,6 +2581,17 @@ extern "C" int srgan_halo16_wgrad(const srgan_conv_desc* d, const void* x, int x
   SRGAN_REQUIRE(x && dy && dw && ws, "halo16_wgrad: null pointer");
   // (round 6: also the stride-2 layers no patch kernel serves forward -- the discriminators' 16- and 8-pixel maps,
   //  srgan_conv2d_io_applicable -- whose weight gradient halo16s2_wgrad_kernel takes all the same)
+  if (compute_bf16() && rgb_wgrad16_served(d)) {      // round 6: the 7x7 RGB layers, 64-channel side fp32 or bf16
+    const int kind = rgb_wgrad_kind(d);
+    SRGAN_REQUIRE(kind == 0 ? !x_bf16 : !dy_bf16, "halo16_wgrad: the 3-channel tensor of an RGB layer is fp32");
+    SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "halo16_wgrad: workspace too small (srgan_conv2d_workspace)");
+    hipStream_t st = as_stream(stream);
+    if (int e = defer_take(d, &ws, &ws_bytes, st)) return e;
+    WgradPlan w = plan_wgrad(d);
+    rgb_wgrad_slab(d, &w.splits, &w.Cdpad, &w.NNpad);
+    if (int e = rgb_wgrad_run(d, x, dy, (float*)ws, st, (kind == 0 ? dy_bf16 : x_bf16) != 0)) return e;
+    return finish_wgrad(d, w, nullptr, dw, nullptr, ws, st);
+  }
   SRGAN_REQUIRE(compute_bf16() && halo16_wgrad_applicable(d),
                 "halo16_wgrad: layer / compute mode not applicable (srgan_halo16_applicable / srgan_halo16s2_applicable / srgan_conv2d_io_applicable)");
   SRGAN_REQUIRE(ws_bytes >= srgan_conv2d_workspace(d), "halo16_wgrad: workspace too small (srgan_conv2d_workspace)");
@@ -2860,7 +2871,27 @@ extern "C" int srgan_igemm16_wgrad(const srgan_conv_desc* d, const void* x, cons
 // gradient: halo16t_kernel or igemm16_kernel; weight gradient: srgan_halo16_wgrad (halo16s2_wgrad_kernel takes bf16 x / dy).
 // `packed`: the ordinary packed operand of (d, kind, act) in the bf16 mode (srgan_conv2d_pack / the pack cache).
 namespace srgan {
+// The 7x7 / stride-1 / pad-3 layers between a 3-channel and a 64-channel tensor (the generator's RGB input and output layers,
+// pyfiles/model.py:212, 232) with the 64-channel side in bf16: 3 = input layer (forward rgbin16 writes bf16, input gradient =
+// rgbout16 form reads bf16 dy, weight gradient takes bf16 dy), 4 = output layer (forward rgbout16 reads bf16, input gradient =
+// rgbin16 form writes bf16, weight gradient takes bf16 x).  The 3-channel side is always fp32.
+static int conv_io_rgb(const srgan_conv_desc* d, int act) {
+  if (!compute_bf16() || act != SRGAN_ACT_NONE || !rgb_wgrad16_served(d)) return 0;
+  const DgradGeom g = dgrad_geometry(d);
+  srgan_conv_desc f;
+  long long w_off;
+  if (d->I == 3) {
+    if (fwd_path(d, act) != PATH_RGBIN || !rgbin16_served(d)) return 0;
+    if (!g.narrow || !narrow_dgrad_desc(d, &f, &w_off) || !rowconv_applicable(&f) || !rgbout16_served(&f)) return 0;
+    return 3;
+  }
+  if (fwd_path(d, act) != PATH_ROWCONV || !rgbout16_served(d)) return 0;
+  if (!g.rgbin || !rgbin_dgrad_desc(d, &f, &w_off) || !rgbin16_served(&f)) return 0;
+  return 4;
+}
+
 static bool conv_io_dirs(const srgan_conv_desc* d, int act, int* fwd, int* bwd) {      // 1: patch kernel, 2: igemm16_kernel
+  if (const int r = conv_io_rgb(d, act)) { *fwd = *bwd = r; return true; }
   if (!compute_bf16() || d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 1 || d->pad_mode != SRGAN_PAD_ZERO) return false;
   if ((d->I & 7) || (d->O & 7)) return false;
   const FwdPath path = fwd_path(d, act);
@@ -2892,6 +2923,14 @@ extern "C" int srgan_conv2d_io_fwd(const srgan_conv_desc* d, const void* x, int 
   int f = 0, b = 0;
   SRGAN_REQUIRE(conv_io_dirs(d, act, &f, &b), "conv2d_io_fwd: layer / compute mode not applicable (srgan_conv2d_io_applicable)");
   hipStream_t st = as_stream(stream);
+  if (f == 3) {
+    SRGAN_REQUIRE(!x_bf16, "conv2d_io_fwd: the 3-channel input of the RGB input layer is fp32");
+    return rgbin_run(d, static_cast<const float*>(x), static_cast<const float*>(packed), bias, static_cast<float*>(y), act, slope, st, y_bf16 != 0);
+  }
+  if (f == 4) {
+    SRGAN_REQUIRE(!y_bf16, "conv2d_io_fwd: the 3-channel result of the RGB output layer is fp32");
+    return rgbout_run(d, x, static_cast<const float*>(packed), bias, static_cast<float*>(y), st, x_bf16 != 0);
+  }
   if (f == 1) return halo16s_run(d, x, packed, bias, y, act, slope, conv_flops(d), st, x_bf16 != 0, y_bf16 != 0);
   const size_t need = srgan_conv2d_packed_scratch(d, 0);
   SRGAN_REQUIRE(need == 0 || (ws && ws_bytes >= need), "conv2d_io_fwd: workspace too small (srgan_conv2d_packed_scratch)");
@@ -2910,6 +2949,19 @@ extern "C" int srgan_conv2d_io_dgrad(const srgan_conv_desc* d, const void* dy, i
   SRGAN_REQUIRE(conv_io_dirs(d, SRGAN_ACT_NONE, &f, &b) || conv_io_dirs(d, SRGAN_ACT_LRELU, &f, &b),
                 "conv2d_io_dgrad: layer / compute mode not applicable (srgan_conv2d_io_applicable)");
   hipStream_t st = as_stream(stream);
+  if (b == 3 || b == 4) {
+    srgan_conv_desc f;
+    long long w_off;
+    if (b == 3) {          // the RGB input layer's input gradient: a 64 -> 3 channel convolution of dy (rgbout16 form)
+      SRGAN_REQUIRE(!dx_bf16, "conv2d_io_dgrad: the 3-channel input gradient of the RGB input layer is fp32");
+      narrow_dgrad_desc(d, &f, &w_off);
+      return rgbout_run(&f, dy, static_cast<const float*>(packed), nullptr, static_cast<float*>(dx), st, dy_bf16 != 0);
+    }
+    SRGAN_REQUIRE(!dy_bf16, "conv2d_io_dgrad: the 3-channel gradient of the RGB output layer's result is fp32");
+    rgbin_dgrad_desc(d, &f, &w_off);
+    return rgbin_run(&f, static_cast<const float*>(dy), static_cast<const float*>(packed), nullptr, static_cast<float*>(dx), SRGAN_ACT_NONE, 0.f, st,
+                     dx_bf16 != 0);
+  }
   if (b == 1) return halo16t_run(d, dy, packed, dx, conv_flops(d), st, dy_bf16 != 0, dx_bf16 != 0);
   const size_t need = srgan_conv2d_packed_scratch(d, 1);
   SRGAN_REQUIRE(need == 0 || (ws && ws_bytes >= need), "conv2d_io_dgrad: workspace too small (srgan_conv2d_packed_scratch)");

@@ -119,13 +119,17 @@ struct Rgbin16Params {
   const float* x;            // [NB][H][W][3]
   const unsigned short* wp;  // [O][R16_KPS] bf16
   const float* bias;         // [O] or null
-  float* y;                  // [NB][Ho][Wo][O]
+  float* y;                  // [NB][Ho][Wo][O] fp32, or bf16 (OUT16)
   int NB, H, W, Ho, Wo, O, pad;
   int tiles_x, tiles_y, o_blocks;
   int act;
   float slope;
 };
 
+// OUT16 (round 6): the 64-channel result is written as bf16 (16-bit activation storage: the generator's first norm reads it, or --
+// the input gradient of the RGB output layer -- its last norm's backward); lanes pair up so that a half-wave writes a pixel's
+// whole 128-byte line (even lane: channels (lr, lr + 1) of block 0, odd lane: (32 + lr - 1, 32 + lr) of block 1).
+template <bool OUT16>
 __global__ __launch_bounds__(512) void rgbin16_conv_kernel(Rgbin16Params p) {
   constexpr int TR = 16, TC = 32, KH = 7, HR = TR + KH - 1;
   __shared__ __attribute__((aligned(16))) unsigned short halo[HR * R16_HC * 4 + 32];
@@ -191,6 +195,23 @@ __global__ __launch_bounds__(512) void rgbin16_conv_kernel(Rgbin16Params p) {
   for (int i = 0; i < 2; ++i) {
     const int oy = Y0 + 2 * wave + i;
     if (oy >= p.Ho) continue;
+    if constexpr (OUT16) {
+      const bool odd = lr & 1;
+      const float bv0 = p.bias ? p.bias[ob * 64 + lr] : 0.f, bv1 = p.bias ? p.bias[ob * 64 + 32 + lr] : 0.f;
+      __bf16* row = reinterpret_cast<__bf16*>(p.y) + ((size_t)(n * p.Ho + oy) * p.Wo) * p.O + ob * 64 + (odd ? 32 + lr - 1 : lr);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v0 = apply_act(acc[i][0][e] + bv0, p.act, p.slope), v1 = apply_act(acc[i][1][e] + bv1, p.act, p.slope);
+        const float got = __shfl_xor(odd ? v0 : v1, 1);
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 pr;
+        pr[0] = (__bf16)(odd ? got : v0);
+        pr[1] = (__bf16)(odd ? v1 : got);
+        const int ox = X0 + 8 * (e >> 2) + 4 * lh + (e & 3);
+        if (ox < p.Wo) *reinterpret_cast<bf16x2*>(row + (size_t)ox * p.O) = pr;
+      }
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int oc = ob * 64 + j * 32 + lr;
@@ -387,13 +408,13 @@ __global__ __launch_bounds__(512) void rgb_wgrad_kernel(RgbWgradParams p) {
 //   * wave w owns patch row w: 2 K steps x (2 x 5) products per patch, all 2 x 5 output tiles in 160 accumulator registers; at the
 //     end the four partial results meet in LDS and one slab per workgroup goes to the split-K sum of conv_igemm.hip.
 struct RgbWgrad16Params {
-  const float* c64;   // [NB][H][W][64]
+  const void* c64;    // [NB][H][W][64] fp32, or bf16 (C16)
   const float* t3;    // [NB][H][W][3]
   float* slab;        // [gridDim.x][Cdpad][NNpad]
   int NB, H, W, tiles_x, tiles_y, patches, per_split;
 };
 
-template <int SWAP>
+template <int SWAP, bool C16>
 __global__ __launch_bounds__(256, 2) void rgb_wgrad16_kernel(RgbWgrad16Params p) {
   constexpr int KH = 7, KW = 7, CI = 3, PR = 4, PC = 32;
   constexpr int HR = PR + KH - 1, HC = PC + KW - 1, HWE = HC * CI, HEL = HR * HWE;      // 10 x 38 pixels, 114 entries per row, 1140
@@ -409,7 +430,8 @@ __global__ __launch_bounds__(256, 2) void rgb_wgrad16_kernel(RgbWgrad16Params p)
   const int li = lane & 15, q4 = li >> 2, pq = li & 3, g1 = (lane >> 4) & 1;
   const int p_begin = blockIdx.x * p.per_split, p_end = min(p_begin + p.per_split, p.patches);
 
-  const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.c64), 0, (unsigned)((size_t)p.NB * p.H * p.W * 64 * 4), 0x00020000);
+  constexpr int CSZ = C16 ? 2 : 4;
+  const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.c64), 0, (unsigned)((size_t)p.NB * p.H * p.W * 64 * CSZ), 0x00020000);
   const auto rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t3), 0, (unsigned)((size_t)p.NB * p.H * p.W * CI * 4), 0x00020000);
   constexpr unsigned kOutside = 0x80000000u;
   const int hcg = tid & 7, hpl = tid >> 3;           // 8 channels of one of the 32 pixels of a patch row
@@ -424,9 +446,9 @@ __global__ __launch_bounds__(256, 2) void rgb_wgrad16_kernel(RgbWgrad16Params p)
     const int Y0 = ty * PR, X0 = tx * PC;
 #pragma unroll
     for (int g = 0; g < PR; ++g) {
-      const unsigned off = (unsigned)((((nb * p.H + Y0 + g) * p.W + X0 + hpl) * 64 + hcg * 8) * 4);
+      const unsigned off = (unsigned)((((nb * p.H + Y0 + g) * p.W + X0 + hpl) * 64 + hcg * 8) * CSZ);
       cl[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_c, off, 0, 0));
-      ch[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_c, off, 16, 0));
+      if constexpr (!C16) ch[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_c, off, 16, 0));
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -441,10 +463,14 @@ __global__ __launch_bounds__(256, 2) void rgb_wgrad16_kernel(RgbWgrad16Params p)
   auto park = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < PR; ++g) {
-      const bf16x4 a = __builtin_convertvector(cl[g], bf16x4), b = __builtin_convertvector(ch[g], bf16x4);
-      bf16x8 v;
-      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-      *reinterpret_cast<bf16x8*>(&smem[buf * CT + (g * PC + hpl) * GPS + hcg * 16]) = v;
+      if constexpr (C16) {
+        *reinterpret_cast<f32x4*>(&smem[buf * CT + (g * PC + hpl) * GPS + hcg * 16]) = cl[g];
+      } else {
+        const bf16x4 a = __builtin_convertvector(cl[g], bf16x4), b = __builtin_convertvector(ch[g], bf16x4);
+        bf16x8 v;
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        *reinterpret_cast<bf16x8*>(&smem[buf * CT + (g * PC + hpl) * GPS + hcg * 16]) = v;
+      }
     }
     __bf16* h = reinterpret_cast<__bf16*>(&smem[2 * CT + buf * HT]);
 #pragma unroll
@@ -579,11 +605,15 @@ void rgb_wgrad_slab(const srgan_conv_desc* d, int* splits, int* Cdpad, int* NNpa
   *NNpad = d->kh * d->kw * d->I;
 }
 
-int rgb_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, float* slab, hipStream_t st) {
+bool rgb_wgrad16_served(const srgan_conv_desc* d) { return rgb_wgrad_kind(d) >= 0 && rgb_wgrad16_on(); }
+
+// c64_bf16: the 64-channel tensor (kind 0: dy, kind 1: x) is bf16 (bf16 mode only)
+int rgb_wgrad_run(const srgan_conv_desc* d, const void* x, const void* dy, float* slab, hipStream_t st, bool c64_bf16) {
   const int kind = rgb_wgrad_kind(d);
   SRGAN_REQUIRE(kind >= 0, "rgb weight gradient: layer not applicable");
+  SRGAN_REQUIRE(!c64_bf16 || rgb_wgrad16_on(), "rgb weight gradient: a bf16 tensor needs the bf16 compute mode's kernel");
   RgbWgradParams p{};
-  p.c64 = kind == 0 ? dy : x; p.t3 = kind == 0 ? x : dy; p.slab = slab;
+  p.c64 = static_cast<const float*>(kind == 0 ? dy : x); p.t3 = static_cast<const float*>(kind == 0 ? x : dy); p.slab = slab;
   p.NB = d->N; p.H = d->Hi; p.W = d->Wi; p.tiles_x = d->Wi / 32; p.tiles_y = d->Hi / 16;
   p.ntiles = p.NB * p.tiles_x * p.tiles_y;
   int splits, cd, nn;
@@ -591,13 +621,15 @@ int rgb_wgrad_run(const srgan_conv_desc* d, const float* x, const float* dy, flo
   ProfToken tok = prof_begin(21, 2.0 * d->N * d->Ho * d->Wo * (double)d->O * d->kh * d->kw * d->I, st);
   if (rgb_wgrad16_on()) {
     RgbWgrad16Params q{};
-    q.c64 = p.c64; q.t3 = p.t3; q.slab = slab;
+    q.c64 = kind == 0 ? dy : x; q.t3 = p.t3; q.slab = slab;
     q.NB = d->N; q.H = d->Hi; q.W = d->Wi; q.tiles_x = d->Wi / 32; q.tiles_y = d->Hi / 4;
     int s16 = 0;
     rgb_wgrad16_plan(d, &q.patches, &q.per_split, &s16);
     SRGAN_REQUIRE(s16 == splits, "rgb weight gradient: split plan changed between sizing and launch");
-    if (kind == 0) hipLaunchKernelGGL(rgb_wgrad16_kernel<0>, dim3((unsigned)splits), dim3(256), 0, st, q);
-    else hipLaunchKernelGGL(rgb_wgrad16_kernel<1>, dim3((unsigned)splits), dim3(256), 0, st, q);
+    if (kind == 0 && c64_bf16) hipLaunchKernelGGL((rgb_wgrad16_kernel<0, true>), dim3((unsigned)splits), dim3(256), 0, st, q);
+    else if (kind == 0) hipLaunchKernelGGL((rgb_wgrad16_kernel<0, false>), dim3((unsigned)splits), dim3(256), 0, st, q);
+    else if (c64_bf16) hipLaunchKernelGGL((rgb_wgrad16_kernel<1, true>), dim3((unsigned)splits), dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((rgb_wgrad16_kernel<1, false>), dim3((unsigned)splits), dim3(256), 0, st, q);
   } else if (kind == 0) hipLaunchKernelGGL(rgb_wgrad_kernel<0>, dim3((unsigned)splits), dim3(512), 0, st, p);
   else hipLaunchKernelGGL(rgb_wgrad_kernel<1>, dim3((unsigned)splits), dim3(512), 0, st, p);
   prof_end(tok, st);
@@ -637,9 +669,12 @@ int rgbin_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_t
   return check_launch("rgbin_pack_kernel");
 }
 
+bool rgbin16_served(const srgan_conv_desc* d) { return rgbin_applicable(d) && rgbin16_mode(d); }
+
 int rgbin_run(const srgan_conv_desc* d, const float* x, const float* packed, const float* bias, float* y, int act, float slope,
-              hipStream_t st) {
+              hipStream_t st, bool dst16) {
   SRGAN_REQUIRE(rgbin_applicable(d), "rgb-input conv: layer not applicable");
+  SRGAN_REQUIRE(!dst16 || rgbin16_mode(d), "rgb-input conv: a bf16 result needs the bf16 compute mode's kernel");
   RgbinParams p{};
   p.x = x; p.wp = packed; p.bias = bias; p.y = y;
   p.NB = d->N; p.H = d->Hi; p.W = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo; p.O = d->O; p.pad = d->pad;
@@ -653,7 +688,8 @@ int rgbin_run(const srgan_conv_desc* d, const float* x, const float* packed, con
     q.x = x; q.wp = reinterpret_cast<const unsigned short*>(packed); q.bias = bias; q.y = y;
     q.NB = p.NB; q.H = p.H; q.W = p.W; q.Ho = p.Ho; q.Wo = p.Wo; q.O = p.O; q.pad = p.pad;
     q.tiles_x = p.tiles_x; q.tiles_y = p.tiles_y; q.o_blocks = p.o_blocks; q.act = act; q.slope = slope;
-    hipLaunchKernelGGL(rgbin16_conv_kernel, dim3((unsigned)grid), dim3(512), 0, st, q);
+    if (dst16) hipLaunchKernelGGL(rgbin16_conv_kernel<true>, dim3((unsigned)grid), dim3(512), 0, st, q);
+    else hipLaunchKernelGGL(rgbin16_conv_kernel<false>, dim3((unsigned)grid), dim3(512), 0, st, q);
     prof_end(tok, st);
     return check_launch("rgbin16_conv_kernel");
   }

@@ -257,7 +257,7 @@ constexpr int RO16_KSTEPS = 7 * 4;          // (kx, 16-channel chunk)
 constexpr int RO16_PLD = 25;                // floats per pixel of a partial row (21 live columns; odd: conflict-free both ways)
 
 struct Rgbout16Params {
-  const float* x;            // [NB][H][W][64]
+  const void* x;             // [NB][H][W][64] fp32, or bf16 (IN16)
   const unsigned short* wp;  // [28 K steps][32 columns (cout * 7 + ky; zero from 21)][16] bf16
   const float* bias;         // [O] or null
   float* y;                  // [NB][H][W][O]
@@ -265,6 +265,9 @@ struct Rgbout16Params {
   int exp;
 };
 
+// IN16: the 64-channel source is bf16 (16-bit activation storage: the generator's last norm writes it; as the input gradient of
+// the RGB input layer, its first norm's backward does) -- a pixel is 8 pieces of 16 bytes that go to LDS as they are.
+template <bool IN16>
 __global__ __launch_bounds__(512) void rgbout16_conv_kernel(Rgbout16Params p) {
   __shared__ __attribute__((aligned(16))) unsigned char halo[RO16_BR * RO16_HC * RO16_PS];
   __shared__ float ring[16 * RO16_TC * RO16_PLD];
@@ -288,9 +291,10 @@ __global__ __launch_bounds__(512) void rgbout16_conv_kernel(Rgbout16Params p) {
   // Halo block: thread = (pixel of the pass, 16-byte piece of its 256-byte channel row): a wave instruction covers 4 pixels x 256
   // contiguous bytes.  UNCONDITIONAL loads: an out-of-image pixel reads the image's first pixel (in bounds) and is zeroed when it
   // is parked (a load under a branch, merged with a zero, made the compiler wait for every load in turn: round 4).
-  constexpr int NPX = RO16_BR * RO16_HC, PPP = 512 / 16, NPASS = (NPX + PPP - 1) / PPP;
-  const int piece = tid & 15, hpl = tid >> 4;
-  const float* img = p.x + (size_t)n * p.H * p.W * 64 + piece * 4;
+  constexpr int PIECES = IN16 ? 8 : 16;               // 16-byte pieces of a pixel's 64 channels
+  constexpr int NPX = RO16_BR * RO16_HC, PPP = 512 / PIECES, NPASS = (NPX + PPP - 1) / PPP;
+  const int piece = tid & (PIECES - 1), hpl = tid / PIECES;
+  const unsigned char* img = static_cast<const unsigned char*>(p.x) + ((size_t)n * p.H * p.W * 64) * (IN16 ? 2 : 4) + piece * 16;
   f32x4 v[NPASS];
   unsigned okm = 0;
   auto issue = [&](int G0) __attribute__((always_inline)) {
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(512) void rgbout16_conv_kernel(Rgbout16Params p) {
       const int gy = G0 + hr, gx = X0 - 3 + hc;
       const bool ok = hp < NPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
       okm |= ok ? (1u << g) : 0u;
-      v[g] = *reinterpret_cast<const f32x4*>(img + (ok ? ((size_t)gy * p.W + gx) * 64 : 0));
+      v[g] = *reinterpret_cast<const f32x4*>(img + (ok ? ((size_t)gy * p.W + gx) * (IN16 ? 128 : 256) : 0));
     }
   };
   auto park = [&]() __attribute__((always_inline)) {
@@ -311,7 +315,8 @@ __global__ __launch_bounds__(512) void rgbout16_conv_kernel(Rgbout16Params p) {
       const int hp = g * PPP + hpl;
       if (hp < NPX) {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<bf16x4*>(&halo[hp * RO16_PS + piece * 8]) = __builtin_convertvector(((okm >> g) & 1u) ? v[g] : z4, bf16x4);
+        if constexpr (IN16) *reinterpret_cast<f32x4*>(&halo[hp * RO16_PS + piece * 16]) = ((okm >> g) & 1u) ? v[g] : z4;
+        else *reinterpret_cast<bf16x4*>(&halo[hp * RO16_PS + piece * 8]) = __builtin_convertvector(((okm >> g) & 1u) ? v[g] : z4, bf16x4);
       }
     }
   };
@@ -431,8 +436,12 @@ int rgbout_pack(const srgan_conv_desc* d, const float* w, float* dst, hipStream_
   return check_launch("rgbout_pack_kernel");
 }
 
-int rgbout_run(const srgan_conv_desc* d, const float* x, const float* packed, const float* bias, float* y, hipStream_t st) {
+bool rgbout16_served(const srgan_conv_desc* d) { return rgbout_applicable(d) && rgbout16_mode(d); }
+
+int rgbout_run(const srgan_conv_desc* d, const void* xv, const float* packed, const float* bias, float* y, hipStream_t st, bool src16) {
   SRGAN_REQUIRE(rgbout_applicable(d), "rgb-output conv: layer not applicable");
+  SRGAN_REQUIRE(!src16 || rgbout16_mode(d), "rgb-output conv: a bf16 source needs the bf16 compute mode's kernel");
+  const float* x = static_cast<const float*>(xv);
   RgboutParams p{};
   p.x = x; p.wp = packed; p.bias = bias; p.y = y;
   p.NB = d->N; p.H = d->Hi; p.W = d->Wi; p.C = d->I; p.Ho = d->Ho; p.Wo = d->Wo; p.O = d->O; p.ncq = d->I / 4;
@@ -442,7 +451,7 @@ int rgbout_run(const srgan_conv_desc* d, const float* x, const float* packed, co
   ProfToken tok = prof_begin(28, 2.0 * d->N * d->Ho * d->Wo * (double)d->O * d->kh * d->kw * d->I, st);
   if (rgbout16_mode(d)) {
     Rgbout16Params q{};
-    q.x = x; q.wp = reinterpret_cast<const unsigned short*>(packed); q.bias = bias; q.y = y;
+    q.x = xv; q.wp = reinterpret_cast<const unsigned short*>(packed); q.bias = bias; q.y = y;
     q.NB = d->N; q.H = d->Hi; q.W = d->Wi; q.O = d->O;
     q.strips_x = (int)ceil_div(d->Wo, RO16_TC);
     // strips are cut across until the grid covers the chip (>= 256 workgroups) or a piece would fall under 16 rows
@@ -451,7 +460,8 @@ int rgbout_run(const srgan_conv_desc* d, const float* x, const float* packed, co
     q.rows_per = (int)ceil_div(d->Hi, q.vsplit);
     q.vsplit = (int)ceil_div(d->Hi, q.rows_per);
     q.exp = (int)SRGAN_AB_INT("SRGAN_RGBOUT16_EXP", 0);
-    hipLaunchKernelGGL(rgbout16_conv_kernel, dim3((unsigned)(q.strips_x * q.vsplit * d->N)), dim3(512), 0, st, q);
+    if (src16) hipLaunchKernelGGL(rgbout16_conv_kernel<true>, dim3((unsigned)(q.strips_x * q.vsplit * d->N)), dim3(512), 0, st, q);
+    else hipLaunchKernelGGL(rgbout16_conv_kernel<false>, dim3((unsigned)(q.strips_x * q.vsplit * d->N)), dim3(512), 0, st, q);
     prof_end(tok, st);
     return check_launch("rgbout16_conv_kernel");
   }

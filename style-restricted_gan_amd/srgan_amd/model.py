@@ -378,8 +378,17 @@ class SingleGenerator(nn.Module):
                 io[i] = (cv.s2_io_applicable(probe) and ops.norm_io_applicable(n, cv.in_channels, hh, ww)
                          and ops.norm_io_applicable(n, cv.out_channels, hh // 2, ww // 2))
                 hh, ww = hh // 2, ww // 2
+        # round 6: the 64-channel side of the two 7x7 RGB layers too -- the first conv writes bf16 for norm 0, the last norm
+        # writes bf16 for the RGB head (ops.conv2d_act_io with (k, stride, pad) = (7, 1, 3); the 3-channel side stays fp32)
+        cv0, cvl = self.down_convs[0], self.up_convs[-1]
+        rgb16 = [x.is_cuda and cv.kernel_size == (7, 7) and cv.bias is None and
+                 ops.conv_act_io_applicable(n, cv.in_channels, h, w, cv.weight, ACT_NONE, 7, 1, 3) and
+                 ops.norm_io_applicable(n, ch, h, w) for cv, ch in ((cv0, cv0.out_channels), (cvl, cvl.in_channels))]
         for i in range(self.num_cls + 1):
-            y = self.down_convs[i](x, io16=True) if io[i] else self.down_convs[i](x)
+            if i == 0 and rgb16[0]:
+                y = ops.conv2d_act_io(x, cv0.weight, ACT_NONE, 0.0, True, 7, 1, 3)
+            else:
+                y = self.down_convs[i](x, io16=True) if io[i] else self.down_convs[i](x)
             x = self.down_cnorms[i](y, c, ACT_RELU, out_bf16=io[i + 1])
         x = self.resBlocks([x, c])[0]
         n, _, h, w = x.shape
@@ -397,7 +406,9 @@ class SingleGenerator(nn.Module):
             y = self.up_convs[i](x, io16=True) if iot[i] else self.up_convs[i](x)
             # norm i writes bf16 for a 16-bit up conv i + 1 only if norm i itself is served (with iot[i] false and iot[i + 1] true
             # -- a 16 x 64 input: the trunk map is 4 x 16 -- the fp32-in / bf16-out norm used to run unchecked)
-            x = self.up_norms[i](y, ACT_RELU, out_bf16=iot[i + 1] and nio[i])
+            x = self.up_norms[i](y, ACT_RELU, out_bf16=(iot[i + 1] and nio[i]) or (i == self.num_cls - 1 and rgb16[1] and nio[i]))
+        if x.dtype == torch.bfloat16:
+            return ops.tanh(ops.conv2d_act_io(x, cvl.weight, ACT_NONE, 0.0, False, 7, 1, 3))
         return ops.tanh(self.up_convs[-1](x))
 
 

@@ -1174,34 +1174,42 @@ class _ConvS2IoFn(Function):
 _NO_D_IO16 = _lib.ab("SRGAN_NO_D_IO16")          # A/B (experiment build only): the discriminators on fp32 tensors
 
 
-def conv_act_io_applicable(n, ci, hi, wi, weight, act):
-    """True when a 4x4 / stride-2 / pad-1 Conv2d without bias followed by `act` can take and write bf16 tensors in all three
-    directions (bf16 mode, packed-weight scope): ``srgan_conv2d_io_applicable``."""
-    if not (STORAGE_BF16 and _pack_cache_on and get_compute_dtype() == "bf16" and weight.is_cuda) or _NO_D_IO16:
+_NO_RGB_IO16 = _lib.ab("SRGAN_NO_RGB_IO16")      # A/B (experiment build only): fp32 tensors around the generator's 7x7 RGB layers
+
+
+def conv_act_io_applicable(n, ci, hi, wi, weight, act, k=4, stride=2, pad=1):
+    """True when a Conv2d without bias followed by `act` can take and write bf16 tensors in all three directions (bf16 mode,
+    packed-weight scope; ``srgan_conv2d_io_applicable``): the 4x4 / stride-2 / pad-1 layers of the discriminator trunks, and --
+    (k, stride, pad) = (7, 1, 3), act none -- the generator's RGB input and output layers, whose 64-channel side may be bf16."""
+    if not (STORAGE_BF16 and _pack_cache_on and get_compute_dtype() == "bf16" and weight.is_cuda):
         return False
-    if tuple(weight.shape[2:]) != (4, 4) or hi % 2 or wi % 2:
+    if (_NO_D_IO16 and k == 4) or (_NO_RGB_IO16 and k == 7):
         return False
-    desc = _conv_desc(n, hi, wi, ci, hi // 2, wi // 2, weight.shape[0], 4, 4, 2, 1, PAD_ZERO, weight)
+    if tuple(weight.shape[2:]) != (k, k) or (stride == 2 and (hi % 2 or wi % 2)):
+        return False
+    ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
+    desc = _conv_desc(n, hi, wi, ci, ho, wo, weight.shape[0], k, k, stride, pad, PAD_ZERO, weight)
     return bool(_lib.load().srgan_conv2d_io_applicable(ctypes.byref(desc), act))
 
 
 class _ConvActIoFn(Function):
-    """4x4 / stride-2 / pad-1 Conv2d without bias + LeakyReLU (fused epilogue) in the bf16 mode: input fp32 or bf16, output bf16
-    or fp32.  Backward: the activation's derivative is applied to the incoming gradient by one 16-bit elementwise pass whose
-    result -- always bf16: both kernels that read it round it to bf16 anyway -- feeds the input-gradient and the weight-gradient
-    kernel; dx has x's type."""
+    """Conv2d without bias + activation (fused epilogue) in the bf16 mode with fp32 or bf16 tensors on either side (the layers of
+    ``conv_act_io_applicable``).  Backward: the activation's derivative is applied to the incoming gradient by one 16-bit
+    elementwise pass whose result -- always bf16: both kernels that read it round it to bf16 anyway -- feeds the input-gradient
+    and the weight-gradient kernel; dx has x's type."""
 
     @staticmethod
-    def forward(ctx, x, weight, act, slope, out_bf16):
+    def forward(ctx, x, weight, act, slope, out_bf16, k, stride, pad):
         x = to_nhwc(x)
         n, i, hi, wi = x.shape
         o, i2 = weight.shape[:2]
         if i != i2:
             raise _lib.SrganHipError(f"conv2d_act_io: input has {i} channels, weight expects {i2}")
-        desc = _conv_desc(n, hi, wi, i, hi // 2, wi // 2, o, 4, 4, 2, 1, PAD_ZERO, weight)
+        ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
+        desc = _conv_desc(n, hi, wi, i, ho, wo, o, k, k, stride, pad, PAD_ZERO, weight)
         hit, scratch = _packed(desc, weight, 0, act)
         ws = workspace(x.device, scratch) if scratch else None
-        y = nhwc_empty(n, o, hi // 2, wi // 2, x.device, torch.bfloat16 if out_bf16 else torch.float32)
+        y = nhwc_empty(n, o, ho, wo, x.device, torch.bfloat16 if out_bf16 else torch.float32)
         _lib.check(_lib.load().srgan_conv2d_io_fwd(ctypes.byref(desc), _ptr(x), _is16(x), _ptr(hit.buf), None, _ptr(y), _is16(y), act,
                                                    float(slope), _ptr(ws), scratch, _stream()), "conv2d_io_fwd")
         ctx.desc, ctx.weight, ctx.act, ctx.slope = desc, weight, act, slope
@@ -1228,11 +1236,11 @@ class _ConvActIoFn(Function):
             _lib.check(lib.srgan_conv2d_io_dgrad(ctypes.byref(ctx.desc), _ptr(g), _is16(g), _ptr(hit.buf), _ptr(dx), _is16(dx), _ptr(ws),
                                                  scratch, _stream()), "conv2d_io_dgrad")
         dw = _s2_wgrad(ctx.desc, weight, x, g, ctx.needs_input_grad[1])
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
-def conv2d_act_io(x, weight, act, slope, out_bf16):
-    return _ConvActIoFn.apply(x, weight, act, slope, bool(out_bf16))
+def conv2d_act_io(x, weight, act, slope, out_bf16, k=4, stride=2, pad=1):
+    return _ConvActIoFn.apply(x, weight, act, slope, bool(out_bf16), k, stride, pad)
 
 
 class _ConvT2IoFn(Function):

@@ -1446,6 +1446,53 @@ def test_conv_act_io_every_dtype_pair(ops, shape, in16, out16):
         ops.invalidate_packed()
 
 
+@pytest.mark.parametrize("wide16", [False, True])
+@pytest.mark.parametrize("layer", ["in", "out"])
+@pytest.mark.parametrize("n,h,w", [(2, 32, 64), (3, 80, 96)])
+def test_rgb_layers_with_a_bf16_64_channel_side(ops, n, h, w, layer, wide16):
+    """Round 6: the generator's 7x7 / pad-3 RGB layers (pyfiles/model.py:212, 232) through ops.conv2d_act_io with their 64-channel
+    side in bf16 (the 3-channel side is always fp32): input layer = rgbin16_conv_kernel<OUT16> forward, rgbout16_conv_kernel<IN16>
+    input gradient, rgb_wgrad16_kernel<0, C16>; output layer = rgbout16<IN16> forward, rgbin16<OUT16> input gradient,
+    rgb_wgrad16_kernel<1, C16>.  Every product against the fp32 convolution of the bf16-rounded operands; the second shape has a
+    ragged last column strip (96 = 3 x 32 but 80 rows = 5 blocks of 16) and 3 images."""
+    torch.set_num_threads(16)
+    ci, co = (3, 64) if layer == "in" else (64, 3)
+    x = rnd(n, ci, h, w, seed=51)
+    wt = rnd(co, ci, 7, 7, seed=52) / np.sqrt(ci * 49)
+    gy = rnd(n, co, h, w, seed=53)
+    in16, out16 = (False, wide16) if layer == "in" else (wide16, False)
+
+    def r16(t, on):
+        return _bf16_round(t) if on else t
+
+    ops.set_compute_dtype("bf16")
+    try:
+        with ops.pack_cache():
+            wd = wt.cuda().requires_grad_(True)
+            assert ops.conv_act_io_applicable(n, ci, h, w, wd, ops.ACT_NONE, 7, 1, 3)
+            xd = x.cuda().contiguous(memory_format=torch.channels_last)
+            xd = (xd.to(torch.bfloat16) if in16 else xd).requires_grad_(True)
+            y = ops.conv2d_act_io(xd, wd, ops.ACT_NONE, 0.0, out16, 7, 1, 3)
+            assert y.dtype == (torch.bfloat16 if out16 else torch.float32)
+            y.backward(gy.cuda().contiguous(memory_format=torch.channels_last).to(y.dtype))
+            xr, wr = _bf16_round(x).clone().requires_grad_(True), _bf16_round(wt).clone().requires_grad_(True)
+            z = F.conv2d(xr, wr, None, 1, 3)
+            close(y.float().cpu(), r16(z.detach(), out16), 2e-5 if not out16 else 5e-3)
+            z.backward(_bf16_round(gy))
+            close(xd.grad.float().cpu(), r16(xr.grad, in16), 2e-5 if not in16 else 5e-3)
+            close(wd.grad.cpu(), wr.grad, 5e-5)
+            # the wrong side in bf16 is refused, not silently converted
+            if layer == "in":
+                with pytest.raises(Exception, match="fp32"):
+                    ops.conv2d_act_io(x.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last), wd, ops.ACT_NONE, 0.0, False, 7, 1, 3)
+            else:
+                with pytest.raises(Exception, match="fp32"):
+                    ops.conv2d_act_io(x.cuda().contiguous(memory_format=torch.channels_last), wd, ops.ACT_NONE, 0.0, True, 7, 1, 3)
+    finally:
+        ops.set_compute_dtype("fp32")
+        ops.invalidate_packed()
+
+
 def test_discriminator_bf16_activation_storage_vs_fp32_tensors(ops):
     """Round 6: the full-width discriminator (both scales, heads) forward + backward in the bf16 mode with the trunks' 16-bit
     activations on and off: both are bf16-mode results (same products; the storage adds one rounding per stored activation and
