@@ -25,11 +25,11 @@ def prof_name(n):
     m = re.match(r"wino_kernel<(\d)(?:, (?:true|false))?>", n)
     if m:
         return "wino_kernel" if m.group(1) == "0" else "wino_kernel<4x4s2>"
-    if n.startswith("rgbin_conv_kernel"):
+    if n.startswith("rgbin_conv_kernel") or n.startswith("rgbin16_conv_kernel"):
         return "rgbin_conv_kernel"
-    if n.startswith("rgb_wgrad_kernel"):
+    if n.startswith("rgb_wgrad_kernel") or n.startswith("rgb_wgrad16_kernel"):      # (round 6: the bf16 mode's kernel; one profile name)
         return "rgb_wgrad_kernel"
-    if "rgbout_conv_kernel" in n:
+    if "rgbout_conv_kernel" in n or "rgbout16_conv_kernel" in n:
         return "rgbout_conv_kernel"
     if n.startswith("wino43_wgrad_kernel"):
         return "wino43_wgrad_kernel"
