@@ -2368,18 +2368,38 @@ extern "C" int srgan_conv2d_pack_multi(const void* entries_dev, int n_entries, v
 // Non-zero when the packed operand of (d, kind, act) does not depend on the batch size or the map size (the Winograd filter
 // images and the RGB-input image depend on the weights and the channel counts only): a caller may then share one packed buffer
 // between descriptors that differ in N / H / W only and return the same signature.  0: the layout follows the geometry.
+// Round 6: the implicit-GEMM operands too.  Their bytes are a function of the weights and of PackParams' layout fields; two
+// descriptors of one weight that differ in N / H / W only often agree in all of them (the discriminators see 64 images in their
+// own update and 32 in the generator's, the encoder 32 and 64: every one of their operands was packed -- and re-packed after
+// every optimiser step -- twice).  The signature is a hash of those fields (bit 62 set: never one of the small values above).
+static unsigned long long pack_layout_signature(const PackParams& q, int kind) {
+  static const bool off = SRGAN_AB_SET("SRGAN_NO_PACK_SHARE");
+  if (off) return 0;
+  unsigned long long h = 1469598103934665603ull;
+  const long long f[] = {q.O, q.I, q.kh, q.kw, q.mode, q.stride, q.pad, q.Ty, q.Tx, q.Cs, q.N, q.K, q.Kpad, q.Npad, q.phases, q.out16,
+                         q.regimg, kind};
+  for (long long v : f)
+    for (int b = 0; b < 8; ++b) {
+      h ^= (unsigned long long)((v >> (8 * b)) & 0xff);
+      h *= 1099511628211ull;
+    }
+  return (h >> 2) | (1ull << 62);
+}
+
 extern "C" unsigned long long srgan_conv2d_pack_signature(const srgan_conv_desc* d, int kind, int act) {
   if (validate(d) != 0) return 0;
   if (kind == 0) {
     const FwdPath path = fwd_path(d, act);
     if (path == PATH_RGBIN) return 100;
     if (path == PATH_WINO) return 10 + (unsigned long long)(wino_packed_bytes(d, 0) % 1000003) * 16 + 1;
-    return 0;
+    if (path == PATH_NARROW || path == PATH_ROWCONV) return 0;      // (their buffers carry per-geometry scratch behind the filter)
+    return pack_layout_signature(fwd_pack_params(d, path, nullptr, nullptr), 0);
   }
   const DgradGeom g = dgrad_geometry(d);
   if (g.rgbin) return 101;
   if (g.wino) return 10 + (unsigned long long)(wino_packed_bytes(d, 1) % 1000003) * 16 + 2;
-  return 0;
+  if (g.narrow || g.narrow_s2) return 0;
+  return pack_layout_signature(dgrad_pack_params(d, g, nullptr, nullptr), 1);
 }
 
 extern "C" size_t srgan_conv2d_packed_scratch(const srgan_conv_desc* d, int kind) {

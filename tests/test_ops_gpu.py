@@ -444,6 +444,48 @@ def test_packed_cache_releases_dead_networks(ops):
     ops.invalidate_packed()
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_implicit_gemm_operands_are_shared_between_batch_sizes(ops, mode):
+    """Round 6: srgan_conv2d_pack_signature also covers the implicit-GEMM operands -- a hash of every layout field of the pack --
+    so a weight used at two batch sizes (the discriminators: 64 images in their own update, 32 in the generator's; the encoder:
+    32 and 64) keeps ONE operand per direction instead of one per geometry, and the per-optimiser-step repack writes it once.
+    An encoder-like 3x3 reflect layer on a 7 x 7 map and a discriminator-like 4x4 / stride-2 layer on a 16 x 16 map, batch 4 and 8:
+    two cached operands per weight (forward, input gradient), and the same bits as calls outside any cache."""
+    torch.manual_seed(11)
+    layers = [((rnd(512, 512, 3, 3, seed=1) / 68).cuda(), 7, 1, 1, True), ((rnd(512, 256, 4, 4, seed=2) / 64).cuda(), 16, 2, 1, False)]
+    ops.set_compute_dtype(mode)
+    try:
+        for wt, hw, stride, pad, reflect in layers:
+            pm = ops.PAD_REFLECT if reflect else ops.PAD_ZERO
+            xs = [rnd(n, wt.shape[1], hw, hw, seed=3 + n).cuda() for n in (4, 8)]
+
+            def run(x):
+                xv, wv = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+                y = ops.conv2d(xv, wv, None, stride, pad, pm)
+                y.backward(torch.ones_like(y))
+                return y.detach(), xv.grad, wv.grad
+
+            plain = [run(x) for x in xs]
+            with ops.pack_cache():
+                wv = wt.clone().requires_grad_(True)
+                before = len(ops._pack_cache)
+                got = []
+                for x in xs:
+                    xv = x.clone().requires_grad_(True)
+                    wv.grad = None
+                    y = ops.conv2d(xv, wv, None, stride, pad, pm)
+                    y.backward(torch.ones_like(y))
+                    got.append((y.detach(), xv.grad, wv.grad.clone()))
+                assert len(ops._pack_cache) - before == 2, [k for k in ops._pack_cache][before:]
+            for a, b in zip(plain, got):
+                for u, v in zip(a, b):
+                    assert torch.equal(u, v)
+            ops.invalidate_packed()
+    finally:
+        ops.set_compute_dtype("fp32")
+        ops.invalidate_packed()
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
