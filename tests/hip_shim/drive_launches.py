@@ -84,6 +84,22 @@ def main():
                             call("igemm16", lib.srgan_igemm16_conv(dref, kind, p, i16, p, None, p, o16, 0, 0.0, p, BIG, None))
                 mark(f"{tag} igemm16 wgrad".encode())
                 call("igemm16_wgrad", lib.srgan_igemm16_wgrad(dref, p, p, p, p, BIG, None))
+            # round 6: conv + activation with 16-bit tensors (the discriminator trunks' 4x4 / stride-2 layers; the generator's 7x7
+            # RGB layers, whose 3-channel side is always fp32)
+            for act in (0, 2):
+                if mode != 1 or not lib.srgan_conv2d_io_applicable(dref, act):
+                    continue
+                ins = (0,) if I == 3 else (0, 1)
+                outs = (0,) if O == 3 else (0, 1)
+                for i16 in ins:
+                    for o16 in outs:
+                        mark(f"{tag} io act{act} fwd in16={i16} out16={o16}".encode())
+                        call("io_fwd", lib.srgan_conv2d_io_fwd(dref, p, i16, p, None, p, o16, act, 0.01, p, BIG, None))
+                        mark(f"{tag} io act{act} dgrad dy16={o16} dx16={i16}".encode())
+                        call("io_dgrad", lib.srgan_conv2d_io_dgrad(dref, p, o16, p, p, i16, p, BIG, None))
+                        if k == 7:
+                            mark(f"{tag} io wgrad x16={i16} d16={o16}".encode())
+                            call("io_wgrad", lib.srgan_halo16_wgrad(dref, p, i16, p, o16, p, p, BIG, None))
         # the instance norms of G (CBIN: 64 @ H, 128 @ H/2, 256 @ H/4) and E (64 @ he ... 512 @ he/8)
         he = (H + 2 - 7) // 2 + 1
         shapes = [(H * H, 64), (H * H // 4, 128), (H * H // 16, 256)] + [((he >> b) ** 2, 64 << b) for b in range(4)]
