@@ -8,10 +8,19 @@ rows = []
 for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", ""))))
 rows.sort()
-end = max(r[1] for r in rows)
-# the timed region ends a little before the process does: skip the tail (eager roofline steps are excluded by --no-micro runs)
-t1 = end
-t0 = t1 - int(ms * 1e6 * steps)
+# the replayed steps are the densest stretch of the trace (the eager first step, the capture and the eager steps of the roofline
+# record that follow the timed region launch the same kernels with host gaps between them): the window of `steps` step times
+# that holds the most kernels
+span_ns = int(ms * 1e6 * steps)
+starts = [r[0] for r in rows]
+best, t0 = -1, rows[0][0]
+j = 0
+for i in range(len(rows)):
+    while rows[j][0] < rows[i][0] - span_ns:
+        j += 1
+    if i - j > best:
+        best, t0 = i - j, rows[i][0] - span_ns
+t1 = t0 + span_ns
 win = [r for r in rows if r[0] >= t0 and r[1] <= t1]
 busy, cur_s, cur_e, gaps = 0, None, None, []
 for s, e, n, q in win:
