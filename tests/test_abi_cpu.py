@@ -59,6 +59,36 @@ def test_invalid_arguments_are_reported_without_a_gpu(built_lib):
     assert lib.srgan_reparam_fwd(None, buf, buf, buf, buf, 256, None) != 0
     assert b"reparam_fwd" in lib.srgan_last_error()
     assert lib.srgan_reparam_bwd(buf, buf, buf, buf, 0, None) != 0
+    # round 6: conv + activation with 16-bit tensors -- the discriminator trunks' 4x4 / stride-2 layers and the generator's 7x7
+    # RGB layers, whose 3-channel side is fp32 (a bf16 flag there is an argument error, reported before any launch)
+    rgb_in = built_lib.ConvDesc(2, 64, 64, 3, 64, 64, 64, 7, 7, 1, 3, 0, 147, 49, 7, 1)
+    rgb_out = built_lib.ConvDesc(2, 64, 64, 64, 64, 64, 3, 7, 7, 1, 3, 0, 64 * 49, 49, 7, 1)
+    d_c2 = built_lib.ConvDesc(4, 64, 64, 64, 32, 32, 128, 4, 4, 2, 1, 0, 64 * 16, 16, 4, 1)
+    for desc in (rgb_in, rgb_out, d_c2):
+        assert lib.srgan_conv2d_io_applicable(ctypes.byref(desc), 0) == 0          # fp32 compute mode: not served
+    assert lib.srgan_conv2d_io_fwd(ctypes.byref(rgb_in), buf, 0, buf, None, buf, 1, 0, 0.0, None, 0, None) != 0
+    assert b"not applicable" in lib.srgan_last_error()
+    assert lib.srgan_set_compute_mode(1) == 0
+    try:
+        assert lib.srgan_conv2d_io_applicable(ctypes.byref(rgb_in), 0) == 1 and lib.srgan_conv2d_io_applicable(ctypes.byref(rgb_out), 0) == 1
+        assert lib.srgan_conv2d_io_applicable(ctypes.byref(rgb_in), 2) == 0        # no activation epilogue on the RGB layers
+        assert lib.srgan_conv2d_io_applicable(ctypes.byref(d_c2), 2) == 1
+        assert lib.srgan_conv2d_io_fwd(ctypes.byref(rgb_in), buf, 1, buf, None, buf, 1, 0, 0.0, None, 0, None) != 0
+        assert b"3-channel input of the RGB input layer is fp32" in lib.srgan_last_error()
+        assert lib.srgan_conv2d_io_fwd(ctypes.byref(rgb_out), buf, 1, buf, None, buf, 1, 0, 0.0, None, 0, None) != 0
+        assert b"3-channel result of the RGB output layer is fp32" in lib.srgan_last_error()
+        assert lib.srgan_conv2d_io_dgrad(ctypes.byref(rgb_in), buf, 1, buf, buf, 1, None, 0, None) != 0
+        assert b"3-channel input gradient" in lib.srgan_last_error()
+        assert lib.srgan_conv2d_io_dgrad(ctypes.byref(rgb_out), buf, 1, buf, buf, 1, None, 0, None) != 0
+        assert b"3-channel gradient" in lib.srgan_last_error()
+        assert lib.srgan_halo16_wgrad(ctypes.byref(rgb_in), buf, 1, buf, 1, buf, buf, 1 << 30, None) != 0
+        assert b"3-channel tensor of an RGB layer is fp32" in lib.srgan_last_error()
+        assert lib.srgan_halo16_wgrad(ctypes.byref(rgb_out), buf, 1, buf, 1, buf, buf, 1 << 30, None) != 0
+        assert b"3-channel tensor of an RGB layer is fp32" in lib.srgan_last_error()
+        assert lib.srgan_conv2d_io_fwd(ctypes.byref(d_c2), None, 1, buf, None, buf, 1, 2, 0.01, None, 0, None) != 0
+        assert b"null pointer" in lib.srgan_last_error()
+    finally:
+        assert lib.srgan_set_compute_mode(0) == 0
 
 
 def test_product_refuses_cpu_tensors(built_lib):
