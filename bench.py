@@ -392,8 +392,8 @@ def _trainer_has_graph():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)      # (the counts every evidence line under profiles/ was measured with)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--k", type=int, default=5)
